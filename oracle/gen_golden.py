@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE'S OWN C CODE.
+
+TEST INFRASTRUCTURE ONLY.  Needs /root/reference and oracle/_ref/libqmann_ref.so
+(`python q-mann_amd/build.py`).  Run from the repo root:
+
+    python oracle/gen_golden.py
+
+What is written (all small .npz files; inputs AND the reference's outputs):
+
+  ref_quant.npz      FLOAT_QUANT / FLOAT2FIXED / FIXED_MUL / FIXED_ADD  (lib/common.h:178-227)
+  ref_hamming.npz    hamming_similarity, hamming_similarity_w           (lib/common.c:223-312)
+  ref_softmax.npz    softmax_fwd CPU branch: 2^x, shift-based, exp_plan (lib/layer.c:1184-1258)
+  ref_sum_vec.npz    sum_vec_fwd CPU branch                             (lib/layer.c:1502-1511)
+  ref_dense_mat.npz  dense_mat_fwd CPU branch                           (lib/layer.c:2671-2696)
+  ref_cross_entropy.npz, ref_activation.npz                             (lib/layer.c:3190-3208, 4226-4244)
+  babi_qa1_test64.npz, babi_qa3_test16.npz
+                     bag-of-words vectors produced by MemN2N/sample.c from the reference's
+                     pre-parsed bAbI files (data, not code)
+  oracle_e2e_qa1.npz our restated oracle's full 3-hop forward on those 64 stories with seeded
+                     weights -- NOT reference output (the composite needs the CUDA-only ops);
+                     a regression pin for the oracle itself, labelled as such.
+
+Seeds are fixed; re-running reproduces the files bit-for-bit.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "oracle"))
+from pyoracle import Oracle, Reference, SM_CPU_POW2  # noqa: E402
+
+GOLD = ROOT / "tests" / "golden"
+DATA = Path("/root/reference/MemN2N/dataset")
+FORMATS = [(0, 7), (2, 5), (4, 3), (5, 2), (6, 1), (0, 0)]
+
+
+def gen_quant(ref: Reference):
+    rng = np.random.default_rng(1)
+    xs = [k / 512.0 for k in range(-600, 601, 7)]
+    xs += [0.0, -0.0, 1e-9, -1e-9, 0.0039, -0.0039, 1e6, -1e6]
+    for iwl, frac in FORMATS:
+        if iwl + frac:
+            M = (1 << (iwl + frac)) - 1
+            lim = M / (1 << frac)
+            xs += [lim, -lim, np.nextafter(np.float32(lim), np.float32(1e9)), -np.nextafter(np.float32(lim), np.float32(1e9)),
+                   lim + 1.0 / (1 << frac), -(lim + 1.0 / (1 << frac))]
+    xs += list(rng.normal(0, 8, 400))
+    x = np.array(xs, dtype=np.float32)
+    fmts = np.array(FORMATS, dtype=np.uint32)
+    q = np.zeros((len(FORMATS), x.size), np.float32)
+    w = np.zeros((len(FORMATS), x.size), np.int32)
+    for i, (iwl, frac) in enumerate(FORMATS):
+        for j, v in enumerate(x):
+            q[i, j] = ref.L.ref_float_quant(float(v), iwl, frac)
+            if iwl + frac:
+                w[i, j] = ref.L.ref_float2fixed(float(v), iwl, frac)
+    a = rng.normal(0, 4, 500).astype(np.float32)
+    b = rng.normal(0, 4, 500).astype(np.float32)
+    mul = np.zeros((len(FORMATS) - 1, a.size), np.float32)
+    add = np.zeros_like(mul)
+    for i, (iwl, frac) in enumerate(FORMATS[:-1]):
+        for j in range(a.size):
+            mul[i, j] = ref.L.ref_fixed_mul(float(a[j]), float(b[j]), iwl, frac)
+            add[i, j] = ref.L.ref_fixed_add(float(a[j]), float(b[j]), iwl, frac)
+    np.savez_compressed(GOLD / "ref_quant.npz", x=x, formats=fmts, quant=q, word=w, a=a, b=b, mul=mul, add=add)
+
+
+def gen_hamming(ref: Reference):
+    rng = np.random.default_rng(2)
+    a = rng.integers(-2**31, 2**31, 4096, dtype=np.int64).astype(np.int32)
+    b = rng.integers(-2**31, 2**31, 4096, dtype=np.int64).astype(np.int32)
+    # make a quarter of the pairs close to each other (few differing bits)
+    flip = (1 << rng.integers(0, 32, 1024)).astype(np.int64)
+    b[:1024] = (a[:1024].astype(np.int64) ^ flip).astype(np.int32)
+    nbits = np.array([1, 4, 8, 16, 32], np.uint32)
+    s = np.zeros((nbits.size, a.size), np.uint32)
+    sw = np.zeros((nbits.size, a.size), np.float32)
+    for i, n in enumerate(nbits):
+        for j in range(a.size):
+            s[i, j] = ref.L.hamming_similarity(int(a[j]), int(b[j]), int(n))
+            sw[i, j] = ref.L.hamming_similarity_w(int(a[j]), int(b[j]), int(n), False)
+    np.savez_compressed(GOLD / "ref_hamming.npz", a=a, b=b, num_bit=nbits, sim=s, sim_w=sw)
+
+
+def gen_softmax(ref: Reference):
+    rng = np.random.default_rng(3)
+    out = {}
+    for k, dim in enumerate([1, 2, 4, 10, 50, 256, 1000]):
+        x = (rng.integers(-127, 128, dim) / 4.0).astype(np.float32)      # Q5.2 grid scores
+        if k % 2:
+            x = rng.normal(0, 3, dim).astype(np.float32)
+        out[f"x{k}"] = x
+        out[f"pow2_{k}"] = ref.softmax_fwd(x)
+        out[f"shift_{k}"] = ref.softmax_fwd(x, shift_based=True)
+        out[f"plan_{k}"] = ref.softmax_fwd(x, exp_plan=True)
+    out["x_survey"] = np.array([1, 2, 3, 0.5], np.float32)
+    out["pow2_survey"] = ref.softmax_fwd(out["x_survey"])
+    np.savez_compressed(GOLD / "ref_softmax.npz", **out)
+
+
+def gen_sum_vec(ref: Reference):
+    rng = np.random.default_rng(4)
+    out = {}
+    a = rng.normal(0, 6, 256).astype(np.float32)
+    b = rng.normal(0, 6, 256).astype(np.float32)
+    out["a"], out["b"] = a, b
+    out["float"] = ref.sum_vec_fwd(a, b, False, (5, 2))
+    for iwl, frac in FORMATS[:-1]:
+        out[f"q{iwl}_{frac}"] = ref.sum_vec_fwd(a, b, True, (iwl, frac))
+    np.savez_compressed(GOLD / "ref_sum_vec.npz", **out)
+
+
+def bow_like(rng, n_sen, dim_input, dim_dict):
+    """bAbI-shaped story matrix: <=6 word counts per sentence + one time bit (sample.c:466-475,527-555)."""
+    X = np.zeros((n_sen, dim_input), np.float32)
+    for s in range(n_sen):
+        for w in rng.integers(1, dim_dict, rng.integers(2, 7)):
+            X[s, w] += 1.0
+        X[s, dim_dict + (n_sen - 1 - s)] = 1.0
+    return X
+
+
+def gen_dense_mat(ref: Reference):
+    rng = np.random.default_rng(5)
+    out = {}
+    cases = []
+    k = 0
+    for n_sen in [1, 2, 10, 50]:
+        for dim_input, dim_dict in [(30, 20), (256, 192)]:
+            for (iwl, frac), sigma in [((5, 2), 1.0), ((6, 1), 2.0), ((4, 3), 0.5), ((2, 5), 0.1)]:
+                if n_sen > dim_input - dim_dict:
+                    continue
+                X = bow_like(rng, n_sen, dim_input, dim_dict)
+                W = rng.normal(0, sigma, (60, dim_input)).astype(np.float32)
+                out[f"X{k}"], out[f"W{k}"] = X, W
+                out[f"fixed{k}"] = ref.dense_mat_fwd(W, X, True, (iwl, frac))
+                out[f"float{k}"] = ref.dense_mat_fwd(W, X, False, (iwl, frac))
+                cases.append((n_sen, dim_input, iwl, frac))
+                k += 1
+    # dense inputs (not BoW): exercises saturation of products and of the sum
+    X = rng.normal(0, 8, (7, 33)).astype(np.float32)
+    W = rng.normal(0, 8, (13, 33)).astype(np.float32)
+    out[f"X{k}"], out[f"W{k}"] = X, W
+    out[f"fixed{k}"] = ref.dense_mat_fwd(W, X, True, (5, 2))
+    out[f"float{k}"] = ref.dense_mat_fwd(W, X, False, (5, 2))
+    cases.append((7, 33, 5, 2))
+    out["cases"] = np.array(cases, np.int32)
+    np.savez_compressed(GOLD / "ref_dense_mat.npz", **out)
+
+
+def gen_ce_act(ref: Reference):
+    rng = np.random.default_rng(6)
+    out = {}
+    for k, dim in enumerate([2, 30, 256]):
+        h = rng.random(dim).astype(np.float32); h /= h.sum()
+        y = np.zeros(dim, np.float32); y[rng.integers(0, dim)] = 1.0
+        cost, g = ref.cross_entropy_run(h, y)
+        out[f"h{k}"], out[f"y{k}"], out[f"cost{k}"], out[f"grad{k}"] = h, y, np.float32(cost), g
+    np.savez_compressed(GOLD / "ref_cross_entropy.npz", **out)
+    x = rng.normal(0, 3, 128).astype(np.float32)
+    np.savez_compressed(GOLD / "ref_activation.npz", x=x, null=ref.activation_fwd(x, b"NULL"),
+                        sigmoid=ref.activation_fwd(x, b"SIGMOID"), relu=ref.activation_fwd(x, b"RELU"))
+
+
+def gen_babi(ref: Reference, sub: str, task: str, n_take: int, name: str, max_sen_len=50):
+    tr = str(DATA / sub / f"{task}_train_set").encode()
+    te = str(DATA / sub / f"{task}_test_set").encode()
+    di, dd, ml = C.c_uint(), C.c_uint(), C.c_uint()
+    n = ref.L.ref_babi_load(tr, te, max_sen_len, 200000, 20000, C.byref(di), C.byref(dd), C.byref(ml))
+    assert n > 0, n
+    dim_input = di.value
+    n_take = min(n_take, n)
+    n_sen = np.array([ref.L.ref_babi_nsen(i) for i in range(n_take)], np.uint32)
+    story = np.zeros((int(n_sen.sum()), dim_input), np.float32)
+    q = np.zeros((n_take, dim_input), np.float32)
+    a = np.zeros((n_take, dim_input), np.float32)
+    off = 0
+    fp = C.POINTER(C.c_float)
+    for i in range(n_take):
+        s = np.zeros((int(n_sen[i]), dim_input), np.float32)
+        ref.L.ref_babi_get(i, s.ctypes.data_as(fp), q[i].ctypes.data_as(fp), a[i].ctypes.data_as(fp))
+        story[off:off + n_sen[i]] = s
+        off += int(n_sen[i])
+    np.savez_compressed(GOLD / name, story=story.astype(np.uint8), question=q.astype(np.uint8),
+                        answer=a.astype(np.uint8), n_sen=n_sen, dim_input=np.uint32(dim_input),
+                        dim_dict=np.uint32(dd.value), max_line=np.uint32(ml.value), n_total=np.uint32(n))
+    return story, q, a, n_sen, dim_input
+
+
+def seeded_weights(seed, n_hop, D, V, sigma):
+    rng = np.random.default_rng(seed)
+    return {
+        "w_q": rng.normal(0, sigma, (D, V)).astype(np.float32),
+        "w_a": [rng.normal(0, sigma, (D, V)).astype(np.float32) for _ in range(n_hop)],
+        "w_c": [rng.normal(0, sigma, (D, V)).astype(np.float32) for _ in range(n_hop)],
+        "w_h": [rng.normal(0, sigma, (D, D)).astype(np.float32) for _ in range(n_hop)],
+        "w_ans": rng.normal(0, 0.1, (V, D)).astype(np.float32),
+    }
+
+
+def babi_cfg(dim_input, attention_mode, softmax_variant, iwl=5, n_hop=3, D=60):
+    """run.sh default iwl=5 (MemN2N/run.sh:6,18) with the EN_MQ weight formats (MemN2N.c:748-754)."""
+    frac = 7 - iwl
+    fmt = [(iwl, frac)] * n_hop
+    fmt_w = list(fmt)
+    if n_hop >= 3:
+        fmt_w[0] = (iwl + 1, frac - 1)
+        fmt_w[2] = (iwl - 1, frac + 1)
+    return dict(n_hop=n_hop, dim_emb=D, dim_input=int(dim_input), attention_mode=attention_mode,
+                softmax_variant=softmax_variant, f_fixed=True, en_lin_map=True, fmt=fmt, fmt_w=fmt_w,
+                fmt_att=list(fmt), fmt_bin=(iwl, frac))
+
+
+def gen_e2e(ora: Oracle, story, q, a, n_sen, dim_input):
+    out = {}
+    for mode in (2, 3):
+        cfg = babi_cfg(dim_input, mode, 0)
+        wts = seeded_weights(1234, 3, 60, int(dim_input), 1.0)
+        m = ora.make_model(cfg, wts)
+        preds, scores, probs, us, logits = [], [], [], [], []
+        off = 0
+        for i in range(len(n_sen)):
+            ns = int(n_sen[i])
+            pred, t = ora.forward(m, story[off:off + ns], q[i])
+            off += ns
+            preds.append(pred); scores.append(t["scores"].ravel()); probs.append(t["probs"].ravel())
+            us.append(t["u"]); logits.append(t["logits"])
+        out[f"pred_m{mode}"] = np.array(preds, np.uint32)
+        out[f"scores_m{mode}"] = np.concatenate(scores)
+        out[f"probs_m{mode}"] = np.concatenate(probs)
+        out[f"u_m{mode}"] = np.stack(us)
+        out[f"logits_m{mode}"] = np.stack(logits)
+    np.savez_compressed(GOLD / "oracle_e2e_qa1.npz", **out)
+
+
+def main():
+    GOLD.mkdir(parents=True, exist_ok=True)
+    ref = Reference()
+    ora = Oracle()
+    gen_quant(ref)
+    gen_hamming(ref)
+    gen_softmax(ref)
+    gen_sum_vec(ref)
+    gen_dense_mat(ref)
+    gen_ce_act(ref)
+    story, q, a, n_sen, dim_input = gen_babi(ref, "en_10k_parsed", "qa1_single-supporting-fact", 64,
+                                             "babi_qa1_test64.npz")
+    gen_e2e(ora, story, q, a, n_sen, dim_input)
+    gen_babi(ref, "en_1k_parsed", "qa3_three-supporting-facts", 16, "babi_qa3_test16.npz")
+    for p in sorted(GOLD.glob("*.npz")):
+        print(f"{p.name:28s} {p.stat().st_size:8d} B")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,282 @@
+"""ctypes bindings to the CPU oracle (and, when built, to the reference's own C code).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never by the product package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+ORACLE_SO = HERE / "libqmann_oracle.so"
+REF_SO = HERE / "_ref" / "libqmann_ref.so"
+
+QO_MAX_HOP = 8
+SM_CUDA, SM_CPU_POW2, SM_CPU_EXP_PLAN = 0, 1, 2
+
+_f32p = C.POINTER(C.c_float)
+
+
+def _fp(a):
+    if a is None:
+        return None
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_f32p)
+
+
+class QoModel(C.Structure):
+    _fields_ = [
+        ("n_hop", C.c_uint), ("dim_emb", C.c_uint), ("dim_input", C.c_uint),
+        ("attention_mode", C.c_uint), ("softmax_variant", C.c_int),
+        ("f_fixed", C.c_bool), ("en_lin_map", C.c_bool),
+        ("iwl", C.c_uint * QO_MAX_HOP), ("frac", C.c_uint * QO_MAX_HOP),
+        ("iwl_w", C.c_uint * QO_MAX_HOP), ("frac_w", C.c_uint * QO_MAX_HOP),
+        ("iwl_att", C.c_uint * QO_MAX_HOP), ("frac_att", C.c_uint * QO_MAX_HOP),
+        ("iwl_bin", C.c_uint), ("frac_bin", C.c_uint),
+        ("w_q", _f32p),
+        ("w_a", _f32p * QO_MAX_HOP), ("w_c", _f32p * QO_MAX_HOP), ("w_h", _f32p * QO_MAX_HOP),
+        ("w_ans", _f32p),
+    ]
+
+
+class QoTaps(C.Structure):
+    _fields_ = [(n, _f32p) for n in
+                ("u0", "keys", "vals", "scores", "probs", "o", "lu", "u", "logits", "out_probs")]
+
+
+class Oracle:
+    def __init__(self, path: Path = ORACLE_SO):
+        if not path.exists():
+            raise FileNotFoundError(f"{path} missing: run `make -C oracle oracle`")
+        L = self.L = C.CDLL(str(path))
+        u, f, i32 = C.c_uint, C.c_float, C.c_int32
+        L.qo_float2fixed.restype = i32; L.qo_float2fixed.argtypes = [f, u, u]
+        L.qo_fixed2float.restype = f; L.qo_fixed2float.argtypes = [i32, u]
+        L.qo_quant.restype = f; L.qo_quant.argtypes = [f, u, u]
+        L.qo_fixed_mul.restype = f; L.qo_fixed_mul.argtypes = [f, f, u, u, u, u]
+        L.qo_fixed_add.restype = f; L.qo_fixed_add.argtypes = [f, f, u, u, u, u]
+        L.qo_code8.restype = C.c_int; L.qo_code8.argtypes = [f, u, u]
+        L.qo_hamming_similarity.restype = u; L.qo_hamming_similarity.argtypes = [i32, i32, u]
+        L.qo_hamming_similarity_w.restype = f; L.qo_hamming_similarity_w.argtypes = [i32, i32, u]
+        L.qo_cuda_hamming_similarity.restype = f
+        L.qo_cuda_hamming_similarity.argtypes = [i32, i32, u, C.c_bool]
+        L.qo_dense_fwd.restype = None
+        L.qo_dense_fwd.argtypes = [_f32p, _f32p, _f32p, u, u, C.c_char_p, C.c_bool, u, u, u, u]
+        L.qo_dense_mat_fwd.restype = None
+        L.qo_dense_mat_fwd.argtypes = [_f32p, _f32p, _f32p, u, u, u, C.c_bool, u, u]
+        L.qo_dot_mat_vec_fwd.restype = None
+        L.qo_dot_mat_vec_fwd.argtypes = [_f32p, _f32p, _f32p, u, u, C.c_bool, C.c_bool, u, u, u, u]
+        L.qo_dot_mat_vec_fwd_appx.restype = None
+        L.qo_dot_mat_vec_fwd_appx.argtypes = [_f32p, _f32p, _f32p, u, u, C.c_bool, u, u, u, C.c_bool]
+        L.qo_attention_hamming.restype = None
+        L.qo_attention_hamming.argtypes = [_f32p, _f32p, _f32p, u, u, u, u, u, C.c_int]
+        L.qo_softmax_fwd.restype = None
+        L.qo_softmax_fwd.argtypes = [_f32p, _f32p, u, C.c_int, C.c_bool]
+        L.qo_sum_vec_fwd.restype = None
+        L.qo_sum_vec_fwd.argtypes = [_f32p, _f32p, _f32p, u, C.c_bool, u, u]
+        L.qo_activation_fwd.restype = None
+        L.qo_activation_fwd.argtypes = [_f32p, _f32p, u, C.c_char_p, C.c_bool, u, u]
+        L.qo_argmax_hi.restype = u; L.qo_argmax_hi.argtypes = [_f32p, u]
+        L.qo_cross_entropy_run.restype = u
+        L.qo_cross_entropy_run.argtypes = [_f32p, _f32p, u, _f32p, C.POINTER(u), _f32p]
+        L.qo_memn2n_forward.restype = u
+        L.qo_memn2n_forward.argtypes = [C.POINTER(QoModel), _f32p, u, _f32p, C.POINTER(QoTaps)]
+        L.qo_memn2n_forward_mem.restype = u
+        L.qo_memn2n_forward_mem.argtypes = [C.POINTER(QoModel), _f32p, _f32p, u, _f32p, C.POINTER(QoTaps)]
+
+    # ---- scalar helpers (vectorised over numpy inputs for convenience) ----
+    def quant(self, x, iwl, frac):
+        x = np.asarray(x, dtype=np.float32)
+        return np.array([self.L.qo_quant(float(v), iwl, frac) for v in x.ravel()],
+                        dtype=np.float32).reshape(x.shape)
+
+    def float2fixed(self, x, iwl, frac):
+        x = np.asarray(x, dtype=np.float32)
+        return np.array([self.L.qo_float2fixed(float(v), iwl, frac) for v in x.ravel()],
+                        dtype=np.int32).reshape(x.shape)
+
+    def code8(self, x, iwl, frac):
+        x = np.asarray(x, dtype=np.float32)
+        return np.array([self.L.qo_code8(float(v), iwl, frac) for v in x.ravel()],
+                        dtype=np.int32).reshape(x.shape)
+
+    # ---- operators ----
+    def dense_fwd(self, w, x, f_fixed, fmt_in, fmt_w, act=b"NULL"):
+        w = np.ascontiguousarray(w, np.float32); x = np.ascontiguousarray(x, np.float32)
+        out = np.empty(w.shape[0], np.float32)
+        self.L.qo_dense_fwd(_fp(w), _fp(x), _fp(out), w.shape[1], w.shape[0], act, f_fixed,
+                            fmt_in[0], fmt_in[1], fmt_w[0], fmt_w[1])
+        return out
+
+    def dense_mat_fwd(self, w, in_mat, f_fixed, fmt):
+        w = np.ascontiguousarray(w, np.float32); in_mat = np.ascontiguousarray(in_mat, np.float32)
+        out = np.empty((in_mat.shape[0], w.shape[0]), np.float32)
+        self.L.qo_dense_mat_fwd(_fp(w), _fp(in_mat), _fp(out), w.shape[1], w.shape[0], in_mat.shape[0],
+                                f_fixed, fmt[0], fmt[1])
+        return out
+
+    def dot_mat_vec_fwd(self, mat, vec, f_trans, f_fixed, fmt_m, fmt_v):
+        mat = np.ascontiguousarray(mat, np.float32); vec = np.ascontiguousarray(vec, np.float32)
+        r, c = mat.shape
+        out = np.empty(c if f_trans else r, np.float32)
+        self.L.qo_dot_mat_vec_fwd(_fp(mat), _fp(vec), _fp(out), r, c, f_trans, f_fixed,
+                                  fmt_m[0], fmt_m[1], fmt_v[0], fmt_v[1])
+        return out
+
+    def dot_mat_vec_fwd_appx(self, mat, vec, f_trans, f_fixed, iwl, frac, num_bit):
+        mat = np.ascontiguousarray(mat, np.float32); vec = np.ascontiguousarray(vec, np.float32)
+        r, c = mat.shape
+        out = np.empty(c if f_trans else r, np.float32)
+        self.L.qo_dot_mat_vec_fwd_appx(_fp(mat), _fp(vec), _fp(out), r, c, f_fixed, iwl, frac, num_bit, f_trans)
+        return out
+
+    def attention_hamming(self, mat, vec, iwl, frac_code, num_bit, variant):
+        mat = np.ascontiguousarray(mat, np.float32); vec = np.ascontiguousarray(vec, np.float32)
+        out = np.empty(mat.shape[0], np.float32)
+        self.L.qo_attention_hamming(_fp(mat), _fp(vec), _fp(out), mat.shape[0], mat.shape[1], iwl, frac_code,
+                                    num_bit, variant)
+        return out
+
+    def softmax_fwd(self, x, variant=SM_CUDA, shift_based=False):
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.empty_like(x)
+        self.L.qo_softmax_fwd(_fp(x), _fp(out), x.size, variant, shift_based)
+        return out
+
+    def sum_vec_fwd(self, a, b, f_fixed, fmt):
+        a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+        out = np.empty_like(a)
+        self.L.qo_sum_vec_fwd(_fp(a), _fp(b), _fp(out), a.size, f_fixed, fmt[0], fmt[1])
+        return out
+
+    def activation_fwd(self, x, act, f_fixed=False, fmt=(0, 0)):
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.empty_like(x)
+        self.L.qo_activation_fwd(_fp(x), _fp(out), x.size, act, f_fixed, fmt[0], fmt[1])
+        return out
+
+    def argmax_hi(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        return int(self.L.qo_argmax_hi(_fp(x), x.size))
+
+    def cross_entropy_run(self, h, y):
+        h = np.ascontiguousarray(h, np.float32); y = np.ascontiguousarray(y, np.float32)
+        cost = np.zeros(1, np.float32); cnt = C.c_uint(0); grad = np.empty_like(h)
+        pred = self.L.qo_cross_entropy_run(_fp(h), _fp(y), h.size, _fp(cost), C.byref(cnt), _fp(grad))
+        return int(pred), float(cost[0]), int(cnt.value), grad
+
+    # ---- composite ----
+    def make_model(self, cfg: dict, weights: dict):
+        """cfg: n_hop, dim_emb, dim_input, attention_mode, softmax_variant, f_fixed, en_lin_map,
+        fmt (list of (iwl,frac) per hop), fmt_w, fmt_att, fmt_bin.  weights: w_q, w_a[h], w_c[h], w_h[h], w_ans
+        (float32 arrays; kept alive on the returned object)."""
+        m = QoModel()
+        m.n_hop, m.dim_emb, m.dim_input = cfg["n_hop"], cfg["dim_emb"], cfg["dim_input"]
+        m.attention_mode = cfg["attention_mode"]
+        m.softmax_variant = cfg.get("softmax_variant", SM_CUDA)
+        m.f_fixed = cfg.get("f_fixed", True)
+        m.en_lin_map = cfg.get("en_lin_map", True)
+        for h in range(cfg["n_hop"]):
+            m.iwl[h], m.frac[h] = cfg["fmt"][h]
+            m.iwl_w[h], m.frac_w[h] = cfg["fmt_w"][h]
+            m.iwl_att[h], m.frac_att[h] = cfg["fmt_att"][h]
+        m.iwl_bin, m.frac_bin = cfg["fmt_bin"]
+        keep = []
+
+        def hold(a):
+            a = np.ascontiguousarray(a, np.float32)
+            keep.append(a)
+            return _fp(a)
+        if weights.get("w_q") is not None:
+            m.w_q = hold(weights["w_q"])
+        for h in range(cfg["n_hop"]):
+            if weights.get("w_a") is not None:
+                m.w_a[h] = hold(weights["w_a"][h]); m.w_c[h] = hold(weights["w_c"][h])
+            if m.en_lin_map:
+                m.w_h[h] = hold(weights["w_h"][h])
+        m.w_ans = hold(weights["w_ans"])
+        m._keep = keep
+        return m
+
+    def _taps(self, m, n_sen, want):
+        H, D, V = m.n_hop, m.dim_emb, m.dim_input
+        shapes = {"u0": (D,), "keys": (H, n_sen, D), "vals": (H, n_sen, D), "scores": (H, n_sen),
+                  "probs": (H, n_sen), "o": (H, D), "lu": (H, D), "u": (H, D), "logits": (V,), "out_probs": (V,)}
+        t = QoTaps(); arrs = {}
+        for k in want:
+            arrs[k] = np.zeros(shapes[k], np.float32)
+            setattr(t, k, _fp(arrs[k]))
+        return t, arrs
+
+    def forward(self, m, story, question, taps=("u0", "scores", "probs", "o", "lu", "u", "logits", "out_probs")):
+        story = np.ascontiguousarray(story, np.float32); question = np.ascontiguousarray(question, np.float32)
+        n_sen = story.shape[0]
+        t, arrs = self._taps(m, n_sen, taps)
+        pred = self.L.qo_memn2n_forward(C.byref(m), _fp(story), n_sen, _fp(question), C.byref(t))
+        return int(pred), arrs
+
+    def forward_mem(self, m, keys, vals, u0, taps=("scores", "probs", "o", "lu", "u", "logits", "out_probs")):
+        keys = np.ascontiguousarray(keys, np.float32); vals = np.ascontiguousarray(vals, np.float32)
+        u0 = np.ascontiguousarray(u0, np.float32)
+        n_sen = keys.shape[1]
+        t, arrs = self._taps(m, n_sen, taps)
+        pred = self.L.qo_memn2n_forward_mem(C.byref(m), _fp(keys), _fp(vals), n_sen, _fp(u0), C.byref(t))
+        return int(pred), arrs
+
+
+class Reference:
+    """The reference's own live C code (oracle/_ref); available wherever the prebuilt .so is."""
+
+    def __init__(self, path: Path = REF_SO):
+        if not path.exists():
+            raise FileNotFoundError(f"{path} missing: run `make -C oracle ref` where /root/reference exists")
+        L = self.L = C.CDLL(str(path))
+        u, f = C.c_uint, C.c_float
+        L.ref_float_quant.restype = f; L.ref_float_quant.argtypes = [f, u, u]
+        L.ref_float2fixed.restype = C.c_int; L.ref_float2fixed.argtypes = [f, u, u]
+        L.ref_fixed2float.restype = f; L.ref_fixed2float.argtypes = [C.c_int, u, u]
+        L.ref_fixed_mul.restype = f; L.ref_fixed_mul.argtypes = [f, f, u, u]
+        L.ref_fixed_add.restype = f; L.ref_fixed_add.argtypes = [f, f, u, u]
+        L.hamming_similarity.restype = u; L.hamming_similarity.argtypes = [C.c_int, C.c_int, u]
+        L.hamming_similarity_w.restype = f; L.hamming_similarity_w.argtypes = [C.c_int, C.c_int, u, C.c_bool]
+        L.exp_plan.restype = f; L.exp_plan.argtypes = [f]
+        L.ref_softmax_fwd.restype = None; L.ref_softmax_fwd.argtypes = [_f32p, _f32p, u, C.c_int, C.c_int]
+        L.ref_sum_vec_fwd.restype = None; L.ref_sum_vec_fwd.argtypes = [_f32p, _f32p, _f32p, u, C.c_int, u, u]
+        L.ref_dense_mat_fwd.restype = None
+        L.ref_dense_mat_fwd.argtypes = [_f32p, _f32p, _f32p, u, u, u, C.c_int, u, u]
+        L.ref_cross_entropy_run.restype = f; L.ref_cross_entropy_run.argtypes = [_f32p, _f32p, _f32p, u]
+        L.ref_activation_fwd.restype = None; L.ref_activation_fwd.argtypes = [_f32p, _f32p, u, C.c_char_p]
+        L.ref_babi_load.restype = C.c_int
+        L.ref_babi_load.argtypes = [C.c_char_p, C.c_char_p, u, u, u, C.POINTER(u), C.POINTER(u), C.POINTER(u)]
+        L.ref_babi_nsen.restype = u; L.ref_babi_nsen.argtypes = [u]
+        L.ref_babi_get.restype = None; L.ref_babi_get.argtypes = [u, _f32p, _f32p, _f32p]
+
+    def softmax_fwd(self, x, exp_plan=False, shift_based=False):
+        x = np.ascontiguousarray(x, np.float32); out = np.empty_like(x)
+        self.L.ref_softmax_fwd(_fp(x), _fp(out), x.size, int(exp_plan), int(shift_based))
+        return out
+
+    def sum_vec_fwd(self, a, b, f_fixed, fmt):
+        a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32); out = np.empty_like(a)
+        self.L.ref_sum_vec_fwd(_fp(a), _fp(b), _fp(out), a.size, int(f_fixed), fmt[0], fmt[1])
+        return out
+
+    def dense_mat_fwd(self, w, in_mat, f_fixed, fmt):
+        w = np.ascontiguousarray(w, np.float32); in_mat = np.ascontiguousarray(in_mat, np.float32)
+        out = np.empty((in_mat.shape[0], w.shape[0]), np.float32)
+        self.L.ref_dense_mat_fwd(_fp(w), _fp(in_mat), _fp(out), w.shape[1], w.shape[0], in_mat.shape[0],
+                                 int(f_fixed), fmt[0], fmt[1])
+        return out
+
+    def cross_entropy_run(self, h, y):
+        h = np.ascontiguousarray(h, np.float32); y = np.ascontiguousarray(y, np.float32); g = np.empty_like(h)
+        cost = self.L.ref_cross_entropy_run(_fp(h), _fp(y), _fp(g), h.size)
+        return float(cost), g
+
+    def activation_fwd(self, x, act):
+        x = np.ascontiguousarray(x, np.float32); out = np.empty_like(x)
+        self.L.ref_activation_fwd(_fp(x), _fp(out), x.size, act)
+        return out

@@ -1,0 +1,130 @@
+/*
+ * qmann_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C11, scalar, single thread) of the arithmetic on the
+ * test-phase forward path of seongsikpark/Q-MANN.  It is the *checker* that the
+ * HIP kernels are compared against.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may link, load or call anything in this
+ * directory; the product library (q-mann_amd/csrc) never does.
+ *
+ * Parity status (see DESIGN.md "Oracle"):
+ *   pinned by outputs of the reference's own live C code run in this container
+ *   (oracle/_ref, fixtures in tests/golden/ref_*.npz):
+ *       quantiser macros, hamming_similarity{,_w}, softmax_fwd CPU branch,
+ *       sum_vec_fwd, dense_mat_fwd, cross_entropy_run CPU cost/grad,
+ *       activation_fwd.
+ *   restated from CUDA source text that cannot be built here (no nvcc, no
+ *   NVIDIA GPU) and therefore PARITY UNPINNED beyond the shared pieces above:
+ *       _cuda_softmax_fwd's exp base / double total, _cuda_approximate_attention
+ *       (Hamming "V2"), _cuda_max/_cuda_max_i tie rule, _cuda_cross_entropy_cost.
+ *
+ * Every function cites the reference file:line it follows
+ * (paths relative to /root/reference).
+ */
+#ifndef QMANN_ORACLE_H
+#define QMANN_ORACLE_H
+
+#include <stdint.h>
+#include <stdbool.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- numeric core: lib/layer_cuda.h:207-259, lib/common.h:178-227 ---- */
+int32_t  qo_float2fixed(float x, unsigned iwl, unsigned frac);   /* sign-magnitude word */
+float    qo_fixed2float(int32_t w, unsigned frac);
+float    qo_quant(float x, unsigned iwl, unsigned frac);          /* FLOAT_QUANT */
+float    qo_fixed_mul(float a, float b, unsigned iwl_a, unsigned frac_a,
+                      unsigned iwl_b, unsigned frac_b);           /* CUDA_FIXED_MUL */
+float    qo_fixed_add(float a, float b, unsigned iwl_a, unsigned frac_a,
+                      unsigned iwl_b, unsigned frac_b);           /* CUDA_FIXED_ADD */
+/* two's-complement int8 code of Q(x) for word length 8 (|code| <= 127) */
+int      qo_code8(float x, unsigned iwl, unsigned frac);
+
+/* ---- Hamming family: lib/common.c:223-312, lib/layer_cuda.cu:218-326 ---- */
+unsigned qo_hamming_similarity(int32_t a, int32_t b, unsigned num_bit);          /* V0 */
+float    qo_hamming_similarity_w(int32_t a, int32_t b, unsigned num_bit);        /* V1 (CPU weights 2^-(i+1)) */
+float    qo_cuda_hamming_similarity(int32_t a, int32_t b, unsigned num_bit, bool weighted); /* CUDA weights 2^-i */
+
+/* ---- operators (float in / float out, row-major) ---- */
+/* lib/layer_cuda.cu:49-83 via cuda_dense_fwd :3163-3208.  act: "NULL"|"SIGMOID"|"RELU" */
+void qo_dense_fwd(const float *w, const float *in, float *out,
+                  unsigned dim_in, unsigned dim_out, const char *act, bool f_fixed,
+                  unsigned iwl_in, unsigned frac_in, unsigned iwl_w, unsigned frac_w);
+/* lib/layer_cuda.cu:105-172 via cuda_dense_mat_fwd :3512-3531; CPU twin lib/layer.c:2671-2696 */
+void qo_dense_mat_fwd(const float *w, const float *in_mat, float *out_mat,
+                      unsigned dim_in, unsigned dim_out, unsigned dim_len,
+                      bool f_fixed, unsigned iwl, unsigned frac);
+/* lib/layer_cuda.cu:2406-2448 (-> :105-172 non-trans, :547-635 trans) */
+void qo_dot_mat_vec_fwd(const float *mat, const float *vec, float *out,
+                        unsigned r, unsigned c, bool f_trans, bool f_fixed,
+                        unsigned iwl_m, unsigned frac_m, unsigned iwl_v, unsigned frac_v);
+/* lib/layer_cuda.cu:2491-2517 (-> :355-541 non-trans "V2", :547-635 trans) */
+void qo_dot_mat_vec_fwd_appx(const float *mat, const float *vec, float *out,
+                             unsigned r, unsigned c, bool f_fixed,
+                             unsigned iwl, unsigned frac, unsigned num_bit, bool f_trans);
+/* Row scorers built on the CPU hamming functions (dead caller lib/layer.c:322-356):
+ * out[i] = sum_j sim(F2F(mat[i][j],iwl,frac_code), F2F(vec[j],iwl,frac_code), num_bit).
+ * variant 0 -> hamming_similarity (V0, unsigned count), 1 -> hamming_similarity_w (V1). */
+void qo_attention_hamming(const float *mat, const float *vec, float *out,
+                          unsigned r, unsigned c, unsigned iwl, unsigned frac_code,
+                          unsigned num_bit, int variant);
+
+enum { QO_SM_CUDA = 0,      /* lib/layer_cuda.cu:1969-2060: __expf, double total  */
+       QO_SM_CPU_POW2 = 1,  /* lib/layer.c:1184-1258: pow(2,.), float total        */
+       QO_SM_CPU_EXP_PLAN = 2, /* lib/layer.c:1196-1198 + lib/common.c:51-73       */
+};
+void qo_softmax_fwd(const float *in, float *out, unsigned dim, int variant, bool f_shift_based);
+/* lib/layer_cuda.cu:1535-1542; CPU lib/layer.c:1502-1511 */
+void qo_sum_vec_fwd(const float *a, const float *b, float *out, unsigned dim,
+                    bool f_fixed, unsigned iwl, unsigned frac);
+/* lib/layer_cuda.cu:1664-1703 */
+void qo_activation_fwd(const float *in, float *out, unsigned dim, const char *act,
+                       bool f_fixed, unsigned iwl, unsigned frac);
+/* lib/layer_cuda.cu:1895-1939: tree arg-max, ties -> highest index */
+unsigned qo_argmax_hi(const float *in, unsigned dim);
+/* lib/layer_cuda.cu:3750-3781, 2191-2251: returns pred index; accumulates cost/m_cnt */
+unsigned qo_cross_entropy_run(const float *h, const float *y, unsigned dim,
+                              float *cost_acc, unsigned *m_cnt_acc, float *grad_out);
+
+/* ---- composite: one query through the test-phase forward, MemN2N/MemN2N.c:2626-2697 ---- */
+#define QO_MAX_HOP 8
+typedef struct {
+    unsigned n_hop, dim_emb, dim_input;
+    unsigned attention_mode;      /* 1 float, 2 fixed dot, 3 appx (V2); define.h:10-15 */
+    int      softmax_variant;     /* QO_SM_* for the in-hop softmax and the output softmax */
+    bool     f_fixed;             /* EN_FIXED_POINT, define.h:31 */
+    bool     en_lin_map;          /* define.h:291 */
+    unsigned iwl[QO_MAX_HOP],     frac[QO_MAX_HOP];      /* activations  MemN2N.c:715-716 */
+    unsigned iwl_w[QO_MAX_HOP],   frac_w[QO_MAX_HOP];    /* weights      :718-719,748-754 */
+    unsigned iwl_att[QO_MAX_HOP], frac_att[QO_MAX_HOP];  /* attention    :721-722 */
+    unsigned iwl_bin, frac_bin;                          /* :769-775 */
+    const float *w_q;                 /* [D][dim_input]          emb_q   :826 */
+    const float *w_a[QO_MAX_HOP];     /* [D][dim_input]          emb_m   :835 */
+    const float *w_c[QO_MAX_HOP];     /* [D][dim_input]          emb_c   :838 */
+    const float *w_h[QO_MAX_HOP];     /* [D][D]                  lin_map :873 */
+    const float *w_ans;               /* [dim_input][D], float   ds_ans  :902-906 */
+} qo_model;
+
+typedef struct {                 /* optional taps; any pointer may be NULL */
+    float *u0;                   /* [D] */
+    float *keys, *vals;          /* [n_hop][n_sen][D] */
+    float *scores, *probs;       /* [n_hop][n_sen] */
+    float *o, *lu, *u;           /* [n_hop][D] */
+    float *logits, *out_probs;   /* [dim_input] */
+} qo_taps;
+
+/* story [n_sen][dim_input], question [dim_input]; returns arg-max prediction */
+unsigned qo_memn2n_forward(const qo_model *m, const float *story, unsigned n_sen,
+                           const float *question, qo_taps *taps);
+
+/* Same forward, but starting from already-embedded memories (the synthetic
+ * |mem|=10000 configs): keys/vals [n_hop][n_sen][D] float-on-grid, u0 [D]. */
+unsigned qo_memn2n_forward_mem(const qo_model *m, const float *keys, const float *vals,
+                               unsigned n_sen, const float *u0, qo_taps *taps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

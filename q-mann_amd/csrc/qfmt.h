@@ -1,0 +1,75 @@
+// qfmt.h -- the Q(iwl.frac) number format of Q-MANN, shared by every kernel.
+//
+// Behaviour restated from lib/layer_cuda.h:207-259 (device macros) and
+// lib/common.h:178-227 (host macros) of the reference: a value is
+// t = trunc(x * 2^frac) toward zero, saturated symmetrically at
+// +-(2^(iwl+frac) - 1); the reference carries t as a sign-magnitude word and
+// immediately decodes it back to the float t / 2^frac.  For word length 8
+// (iwl + frac == 7) |t| <= 127, so t fits an int8 two's-complement code and
+// all products / sums of such values are exact small integers.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define QM_HD __host__ __device__ __forceinline__
+#else
+#define QM_HD static inline
+#endif
+
+struct QFmt {
+    uint32_t iwl;
+    uint32_t frac;
+};
+
+// two's-complement integer code of Q(x)
+QM_HD int32_t qm_code(float x, uint32_t iwl, uint32_t frac)
+{
+    const int32_t M = (int32_t)((1u << (iwl + frac)) - 1u);
+    const float scale = (float)(1 << frac);
+    const float maxf = (float)M / scale;
+    if (x > maxf) return M;
+    if (x < -maxf) return -M;
+    float p = x * scale;
+    // only reachable when iwl + frac == 31: the device conversion saturates
+    if (p >= 2147483648.0f) return 2147483647;
+    if (p <= -2147483648.0f) return (int32_t)0x80000000;
+    return (int32_t)p;
+}
+
+// sign-magnitude word as the reference builds it (negative values that
+// truncate to zero keep the sign bit: 0x80000000)
+QM_HD uint32_t qm_signmag(float x, uint32_t iwl, uint32_t frac)
+{
+    int32_t t = qm_code(x, iwl, frac);
+    if (x >= 0.0f) return (uint32_t)t & 0x7FFFFFFFu;
+    return (uint32_t)(-(int64_t)t) | 0x80000000u;
+}
+
+QM_HD float qm_decode(int32_t code, uint32_t frac)
+{
+    return (float)code / (float)(1 << frac);
+}
+
+// FLOAT_QUANT, including the iwl + frac == 0 binarisation
+QM_HD float qm_quant(float x, uint32_t iwl, uint32_t frac)
+{
+    if (iwl + frac == 0) return (x >= 0.0f) ? 1.0f : -1.0f;
+    return qm_decode(qm_code(x, iwl, frac), frac);
+}
+
+// FIXED_MUL: Qa(Qa(a) * Qb(b))
+QM_HD float qm_fixed_mul(float a, float b, QFmt fa, QFmt fb)
+{
+    return qm_quant(qm_quant(a, fa.iwl, fa.frac) * qm_quant(b, fb.iwl, fb.frac), fa.iwl, fa.frac);
+}
+
+// integer form of FIXED_MUL for word-length-8 codes: ka in format a, kb in
+// format b; result code in format a.  ka*kb / 2^frac_b truncated toward zero,
+// saturated at +-max_a.
+QM_HD int32_t qm_mul_code(int32_t ka, int32_t kb, uint32_t frac_b, int32_t max_a)
+{
+    int32_t p = ka * kb;
+    int32_t t = (p + ((p >> 31) & ((1 << frac_b) - 1))) >> frac_b;
+    return t > max_a ? max_a : (t < -max_a ? -max_a : t);
+}
