@@ -1,0 +1,123 @@
+/*
+ * qmann_batch.h -- batched, int8-native entry points of libqmann_hip.so.
+ *
+ * These have no counterpart in the reference (which runs one query at a time
+ * through ~31 kernel launches, MemN2N/MemN2N.c:2378-2697); they are the
+ * throughput face of the same arithmetic: many independent queries per launch,
+ * memories stored as true int8 codes of the reference's Q(iwl.frac) grid
+ * values (lossless for word length 8), the multi-hop loop fused
+ * into one kernel.  Plain C ABI: device pointers, sizes, an opaque stream
+ * handle (hipStream_t passed as void*; NULL = the null stream).
+ *
+ * Return value of every function: 0 on success, a negative QMANN_E* code on a
+ * caller error (nothing is launched); HIP runtime failures follow the
+ * boundary's convention instead -- message on stderr and exit().
+ *
+ * Data layout ("memory" = the per-query story slots):
+ *   keys, vals : int8 [n_hop][rows_total][Dp]    two's-complement codes
+ *                Dp = dim_emb_pad (multiple of 16, >= D); columns D..Dp-1 are 0.
+ *                keys[h] carry Q(att[h]) codes, vals[h] carry Q(act[h]) codes --
+ *                i.e. what the reference's dot_mat_vec layers see after their
+ *                own operand quantisation (lib/layer_cuda.cu:120, :562).
+ *   row_off    : uint32 [n_query + 1]            first row of each query's
+ *                slots; query q owns rows row_off[q] .. row_off[q+1]-1 in every
+ *                hop plane (ragged, like the reference's pools
+ *                MemN2N/MemN2N.c:2294-2333).
+ *   u vectors  : float [n_query][D]              values on the producer's grid,
+ *                exactly the floats the reference passes between layers.
+ */
+#ifndef QMANN_BATCH_H
+#define QMANN_BATCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QMANN_MAX_HOP 8
+
+enum { QMANN_OK = 0, QMANN_EINVAL = -1, QMANN_ERANGE = -2, QMANN_EUNSUPPORTED = -3 };
+
+/* attention_mode: MemN2N/define.h:10-15 (1..3) plus the packed-code Hamming forms */
+enum {
+    QMANN_ATT_FLOAT = 1,      /* float dot product over the grid values, float read-out           */
+    QMANN_ATT_FIXED = 2,      /* per-product quantised dot product, quantised read-out            */
+    QMANN_ATT_APPX = 3,       /* CUDA "approximate" Hamming attention (lib/layer_cuda.cu:355-541) */
+    QMANN_ATT_HAMMING_V0 = 10,/* bit-agreement count over the top n bits (lib/common.c:223-246)   */
+    QMANN_ATT_HAMMING_V1 = 11,/* signed, weighted bit agreement (lib/common.c:249-312)            */
+    QMANN_ATT_SIGN = 12       /* +-1 dot product of the sign bits (BINARY_MODE, n = 1)            */
+};
+
+enum { QMANN_SOFTMAX_EXP = 0 /* lib/layer_cuda.cu:2006 */, QMANN_SOFTMAX_POW2 = 1 /* lib/layer.c:1225 */ };
+
+typedef struct qmann_fmt {
+    uint32_t iwl;
+    uint32_t frac;
+} qmann_fmt;
+
+typedef struct qmann_net {
+    uint32_t n_hop;
+    uint32_t dim_emb;        /* D */
+    uint32_t dim_emb_pad;    /* Dp: 64, 128 or 256 */
+    uint32_t dim_input;      /* V: dictionary + time slots */
+    uint32_t attention_mode;
+    uint32_t softmax_base;
+    uint32_t en_lin_map;     /* MemN2N/define.h:291 */
+    uint32_t num_bit;        /* Hamming forms: bits compared (<= 8) */
+    qmann_fmt act[QMANN_MAX_HOP];   /* (iwl[h], frac[h])          MemN2N/MemN2N.c:715-716 */
+    qmann_fmt w[QMANN_MAX_HOP];     /* (iwl_w[h], frac_w[h])      :718-719, 748-754       */
+    qmann_fmt att[QMANN_MAX_HOP];   /* (iwl_att[h], frac_att[h])  :721-722                */
+    qmann_fmt bin;                  /* (iwl_bin, frac_bin)        :769-775                */
+    const int8_t *lin_map[QMANN_MAX_HOP]; /* device, [D][Dp] codes in format w[h]; NULL when !en_lin_map */
+} qmann_net;
+
+/* optional per-query taps for parity tests; any pointer may be NULL */
+typedef struct qmann_taps {
+    int32_t *score_codes;   /* [n_hop][rows_total]  integer score in units of 2^-frac_att (fixed) or 2^-10 (appx) */
+    float   *scores;        /* [n_hop][rows_total]  the same as float, as the reference's dev_out_vec */
+    float   *probs;         /* [n_hop][rows_total] */
+    float   *o;             /* [n_query][n_hop][D] */
+    float   *u;             /* [n_query][n_hop][D] */
+} qmann_taps;
+
+/* float -> int8 code of Q(iwl.frac)(x); n elements; rows of `cols` values are written with pitch
+ * `pitch` (>= cols, padding zeroed).  Rejects formats with iwl + frac > 7. */
+int qmann_quantize_i8(const float *src, int8_t *dst, size_t rows, uint32_t cols, uint32_t pitch,
+                      qmann_fmt fmt, void *stream);
+
+/* The hot path: all hops of all queries in one launch (one workgroup per query).
+ *   u0    [n_query][D] float   -- question embedding (emb_q output)
+ *   u_out [n_query][D] float   -- sv[n_hop-1] output, input of the answer layer
+ * Replaces, per query and hop, the reference sequence dot_mat_vec_fwd -> softmax_fwd ->
+ * dot_mat_vec_fwd(trans) -> dense_fwd(lin_map) -> sum_vec_fwd (MemN2N/MemN2N.c:2644-2666). */
+int qmann_hops_i8(const qmann_net *net, const int8_t *keys, const int8_t *vals, size_t hop_stride,
+                  const uint32_t *row_off, uint32_t max_slots, const float *u0, float *u_out,
+                  const qmann_taps *taps, uint32_t n_query, void *stream);
+
+/* Answer layer for a batch: logits = W_ans . u (float, ds_ans is always float: MemN2N.c:902-906),
+ * softmax over V, arg-max with ties to the highest index, and -- when `answer` is given -- the
+ * test-phase bookkeeping of cross_entropy_run mode 3 (cost += -p[answer], match += pred==answer).
+ *   w_ans [V][D] float, answer [n_query] uint32 or NULL, pred [n_query] uint32,
+ *   probs [n_query][V] float or NULL, cost/match: single device words (accumulated) or NULL. */
+int qmann_answer_f32(const qmann_net *net, const float *w_ans, const float *u, const uint32_t *answer,
+                     uint32_t *pred, float *probs, float *cost, uint32_t *match, uint32_t n_query,
+                     void *stream);
+
+/* Story / question embedding for a batch of bag-of-words inputs (dense_mat_fwd / dense_fwd,
+ * lib/layer_cuda.cu:3511, :3162), writing the int8 memories directly.
+ *   story [rows_total][V] float (word counts + time bit), w_a[h], w_c[h], w_q : [D][V] float. */
+int qmann_embed_story(const qmann_net *net, const float *story, uint32_t rows_total,
+                      const float *const *w_a, const float *const *w_c, int8_t *keys, int8_t *vals,
+                      size_t hop_stride, void *stream);
+int qmann_embed_query(const qmann_net *net, const float *question, const float *w_q, float *u0,
+                      uint32_t n_query, void *stream);
+
+/* bytes of LDS one workgroup of qmann_hops_i8 needs for `max_slots` slots (for sizing checks) */
+size_t qmann_hops_lds_bytes(uint32_t max_slots);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QMANN_BATCH_H */

@@ -1,0 +1,19 @@
+"""qmann_amd -- MI355X-native quantized MemN2N inference path (Q-MANN test-phase forward).
+
+The product is the C-ABI shared library `lib/libqmann_hip.so` (hand-written HIP
+for gfx950; headers in /include).  This Python package is only the host-side
+plumbing used by tests and bench.py: it loads the library with ctypes and hands
+it raw device pointers (torch is used for device memory and torch.distributed,
+nothing else).  There is no CPU fallback: if the library is missing or cannot be
+loaded, importing `qmann_amd.abi` raises.
+
+The directory is named `q-mann_amd`; import it through `load_pkg()` in
+tests/conftest.py / bench.py (module name `qmann_amd`).
+"""
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+ROOT = PKG_DIR.parent
+LIB_PATH = PKG_DIR / "lib" / "libqmann_hip.so"
+
+__all__ = ["PKG_DIR", "ROOT", "LIB_PATH"]

@@ -1,0 +1,112 @@
+"""ctypes binding of libqmann_hip.so (the C-ABI product).  No fallback: a missing or
+unloadable library is an ImportError here, and every op below goes through it."""
+from __future__ import annotations
+
+import ctypes as C
+import re
+from pathlib import Path
+
+from . import LIB_PATH, ROOT
+
+if not LIB_PATH.exists():
+    raise ImportError(
+        f"{LIB_PATH} is missing -- build it with `python q-mann_amd/build.py` "
+        "(there is no CPU or PyTorch fallback for the HIP path)")
+
+lib = C.CDLL(str(LIB_PATH))
+
+QMANN_MAX_HOP = 8
+ATT_FLOAT, ATT_FIXED, ATT_APPX, ATT_HAMMING_V0, ATT_HAMMING_V1, ATT_SIGN = 1, 2, 3, 10, 11, 12
+SOFTMAX_EXP, SOFTMAX_POW2 = 0, 1
+
+_vp = C.c_void_p
+_u = C.c_uint
+_b = C.c_bool
+
+
+class Fmt(C.Structure):
+    _fields_ = [("iwl", C.c_uint32), ("frac", C.c_uint32)]
+
+
+class Net(C.Structure):
+    _fields_ = [
+        ("n_hop", C.c_uint32), ("dim_emb", C.c_uint32), ("dim_emb_pad", C.c_uint32), ("dim_input", C.c_uint32),
+        ("attention_mode", C.c_uint32), ("softmax_base", C.c_uint32), ("en_lin_map", C.c_uint32),
+        ("num_bit", C.c_uint32),
+        ("act", Fmt * QMANN_MAX_HOP), ("w", Fmt * QMANN_MAX_HOP), ("att", Fmt * QMANN_MAX_HOP), ("bin", Fmt),
+        ("lin_map", _vp * QMANN_MAX_HOP),
+    ]
+
+
+class Taps(C.Structure):
+    _fields_ = [("score_codes", _vp), ("scores", _vp), ("probs", _vp), ("o", _vp), ("u", _vp)]
+
+
+def header_symbols(header: str):
+    """Function names declared in include/<header> (used by the export test)."""
+    text = (ROOT / "include" / header).read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b((?:cuda|qmann)_[a-z0-9_]+)\s*\(", text)))
+
+
+def _proto(name, restype, argtypes):
+    fn = getattr(lib, name)
+    fn.restype = restype
+    fn.argtypes = argtypes
+    return fn
+
+
+# ---- boundary B (include/qmann_abi.h): the forward / utility verbs the tests drive ----
+_pp = C.POINTER(_vp)
+_proto("cuda_dot_mat_vec_constructor", None, [_pp, _pp, _pp, _pp, _pp, _u, _u, _b])
+_proto("cuda_dot_mat_vec_init", None, [_vp] * 5 + [_u, _u, _b])
+_proto("cuda_dot_mat_vec_fwd", None, [_vp] * 4 + [_u, _u, _b, _b, _u, _u, _u, _u, _u, _b])
+_proto("cuda_dot_mat_vec_fwd_appx", None, [_vp] * 5 + [_u, _u, _b, _u, _u, _u, _u, _b, _b])
+_proto("cuda_dot_mat_vec_destructor", None, [_vp] * 5)
+_proto("cuda_softmax_constructor", None, [_pp, _pp, _pp, _u])
+_proto("cuda_softmax_init", None, [_vp, _vp, _vp, _u])
+_proto("cuda_softmax_fwd", None, [_vp] * 5 + [_u, _b, _b])
+_proto("cuda_softmax_destructor", None, [_vp] * 3)
+_proto("cuda_sum_vec_constructor", None, [_pp, _pp, _u])
+_proto("cuda_sum_vec_fwd", None, [_vp] * 3 + [_u, _b, _u, _u, _u, _b])
+_proto("cuda_sum_vec_destructor", None, [_vp] * 2)
+_proto("cuda_dense_constructor", None, [_pp] * 10 + [_u, _u])
+_proto("cuda_dense_init", None, [_vp] * 9 + [_u, _u])
+_proto("cuda_dense_fwd", None, [_vp] * 5 + [_u, _u, C.c_char_p, _b, _u, _u, _u, _u, _u, _b])
+_proto("cuda_dense_destructor", None, [_vp] * 8)
+_proto("cuda_dense_mat_constructor", None, [_pp] * 10 + [_u, _u, _u])
+_proto("cuda_dense_mat_init", None, [_vp] * 9 + [_u, _u, _u])
+_proto("cuda_dense_mat_fwd", None, [_vp] * 5 + [_u, _u, _u, _b, _u, _u, _u, _b])
+_proto("cuda_dense_mat_destructor", None, [_vp] * 7)
+_proto("cuda_cross_entropy_constructor", None, [_pp] * 8 + [_u])
+_proto("cuda_cross_entropy_init", None, [_vp] * 7 + [_u])
+_proto("cuda_cross_entropy_run", None, [_vp] * 14 + [_u, _u])
+_proto("cuda_cross_entropy_cost_load", None, [_vp] * 6)
+_proto("cuda_cross_entropy_m_cnt_load", None, [_vp] * 6)
+_proto("cuda_cross_entropy_destructor", None, [_vp] * 8)
+_proto("cuda_activation_fwd", None, [_vp, _vp, C.c_char_p, _u, _b, _u, _u, _u])
+_proto("cuda_scale_fwd", None, [_vp, _vp, _vp, _u, _b, _u, _u, _u, _b])
+_proto("cuda_data_constructor", None, [_pp, _pp, _pp, _u, _u, _u])
+_proto("cuda_data_in", None, [_vp] * 6 + [_u, _u, _u])
+_proto("cuda_data_destructor", None, [_vp] * 3)
+_proto("cuda_copy_mat", None, [_vp, _vp, _u, _u, _b])
+_proto("cuda_accum_mat", None, [_vp, _vp, _u, _u, _b])
+_proto("cuda_set_value", None, [_vp, C.c_float, _u, _u, _u])
+_proto("cuda_copy_dev2host", None, [_vp, _vp, _u])
+_proto("qmann_abi_set_softmax_base", None, [C.c_int])
+_proto("qmann_abi_symbol_count", _u, [])
+
+# ---- batched int8 API (include/qmann_batch.h) ----
+_proto("qmann_hops_lds_bytes", C.c_size_t, [C.c_uint32])
+_proto("qmann_quantize_i8", C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, C.c_uint32, Fmt, _vp])
+_proto("qmann_hops_i8", C.c_int, [C.POINTER(Net), _vp, _vp, C.c_size_t, _vp, C.c_uint32, _vp, _vp,
+                                  C.POINTER(Taps), C.c_uint32, _vp])
+_proto("qmann_answer_f32", C.c_int, [C.POINTER(Net), _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_uint32, _vp])
+_proto("qmann_embed_story", C.c_int, [C.POINTER(Net), _vp, C.c_uint32, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp,
+                                      C.c_size_t, _vp])
+_proto("qmann_embed_query", C.c_int, [C.POINTER(Net), _vp, _vp, _vp, C.c_uint32, _vp])
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed with code {rc}")

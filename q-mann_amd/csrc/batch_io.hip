@@ -1,0 +1,269 @@
+// batch_io.hip -- the stages either side of the hop loop, batched over queries:
+// story / question embedding into int8 memories, and the answer layer
+// (projection, softmax, arg-max, test-phase bookkeeping).
+#include "qfmt.h"
+#include "rt.h"
+#include "../../include/qmann_batch.h"
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / kWave;
+
+// ---------------------------------------------------------------------------
+// Answer layer.  One workgroup per query.  Thread v owns logit v and sums over
+// the embedding axis serially in float (separate multiply and add), which is the
+// exact operation order of the reference's serial loop (lib/layer_cuda.cu:70-80),
+// so logits are bit-identical to it.  Softmax: e^(x-max), double normaliser,
+// float quotient (:2006-2042) or the CPU form 2^(x-max) with float arithmetic
+// (lib/layer.c:1225-1243).  Arg-max ties go to the highest index (:1918-1939).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+k_answer(const float *__restrict__ w_ans, const float *__restrict__ u, const uint32_t *__restrict__ answer,
+         uint32_t *__restrict__ pred, float *__restrict__ probs, float *cost, uint32_t *match, uint32_t D,
+         uint32_t V, uint32_t softmax_base)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *us = (float *)smem;            // [D]
+    float *lg = us + ((D + 3) & ~3u);     // [V]
+    __shared__ double red_d[kWaves];
+    __shared__ float red_f[kWaves];
+    __shared__ uint32_t red_i[kWaves];
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const uint32_t q = blockIdx.x;
+    for (uint32_t c = tid; c < D; c += kBlock) us[c] = u[(size_t)q * D + c];
+    __syncthreads();
+
+    float mx = -INFINITY;
+    for (uint32_t v = tid; v < V; v += kBlock) {
+        const float *wr = w_ans + (size_t)v * D;
+        float sum = 0.0f;
+        for (uint32_t c = 0; c < D; c++) {
+            const float t = wr[c] * us[c];
+            sum += t;
+        }
+        lg[v] = sum;
+        mx = sum > mx ? sum : mx;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float t = __shfl_xor(mx, o);
+        mx = t > mx ? t : mx;
+    }
+    if (lane == 0) red_f[wave] = mx;
+    __syncthreads();
+    mx = red_f[0];
+    for (int i = 1; i < kWaves; i++) mx = red_f[i] > mx ? red_f[i] : mx;
+
+    double part = 0.0;
+    for (uint32_t v = tid; v < V; v += kBlock) {
+        const float e = (softmax_base == QMANN_SOFTMAX_EXP) ? expf(lg[v] - mx) : exp2f(lg[v] - mx);
+        lg[v] = e;
+        part += (double)e;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    if (lane == 0) red_d[wave] = part;
+    __syncthreads();
+    const double total = (red_d[0] + red_d[1]) + (red_d[2] + red_d[3]);
+
+    float bv = -INFINITY;
+    uint32_t bi = 0;
+    for (uint32_t v = tid; v < V; v += kBlock) {
+        const float p = (softmax_base == QMANN_SOFTMAX_EXP) ? (float)((double)lg[v] / total)
+                                                            : lg[v] / (float)total;
+        lg[v] = p;
+        if (probs) probs[(size_t)q * V + v] = p;
+        if (!(bv > p)) { bv = p; bi = v; }           // later index wins a tie
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float tv = __shfl_xor(bv, o);
+        const uint32_t ti = __shfl_xor(bi, o);
+        if (tv > bv || (tv == bv && ti > bi)) { bv = tv; bi = ti; }
+    }
+    __syncthreads();
+    if (lane == 0) { red_f[wave] = bv; red_i[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int i = 1; i < kWaves; i++)
+            if (red_f[i] > bv || (red_f[i] == bv && red_i[i] > bi)) { bv = red_f[i]; bi = red_i[i]; }
+        pred[q] = bi;
+        if (answer) {
+            const uint32_t y = answer[q];
+            if (y < V) {
+                if (cost) atomicAdd(cost, -lg[y]);
+                if (match && y == bi) atomicAdd(match, 1u);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Story embedding: E[s][j] = Qw( sum_k Qw( Qw(X[s][k]) . Qw(W[j][k]) ) )
+// (lib/layer_cuda.cu:105-172 via :3531) for the A and C tables of every hop, then
+// re-quantised to the format its consumer applies (keys: att[h], lib/layer_cuda.cu:120;
+// values: act[h], :562) and stored as int8.  X is a bag of words: a handful of
+// non-zeros per row, so rows are first compacted to (index, value) pairs in LDS
+// and the sum becomes a short gather over table columns.  One workgroup per
+// story row; thread j < D owns output column j for all 2.n_hop tables.
+// ---------------------------------------------------------------------------
+constexpr int kMaxNnz = 64;
+
+struct EmbedArgs {
+    const float *story;
+    const float *w_a[QMANN_MAX_HOP];
+    const float *w_c[QMANN_MAX_HOP];
+    int8_t *keys;
+    int8_t *vals;
+    size_t hop_stride;
+    uint32_t n_hop, D, Dp, V;
+    QFmt act[QMANN_MAX_HOP], w[QMANN_MAX_HOP], att[QMANN_MAX_HOP];
+};
+
+__global__ void __launch_bounds__(kBlock)
+k_embed_story(const EmbedArgs a)
+{
+    __shared__ uint32_t nz_idx[kMaxNnz];
+    __shared__ float nz_val[kMaxNnz];
+    __shared__ uint32_t nnz;
+    const uint32_t tid = threadIdx.x;
+    const size_t s = blockIdx.x;
+    const float *x = a.story + s * a.V;
+    if (tid == 0) nnz = 0;
+    __syncthreads();
+    for (uint32_t k = tid; k < a.V; k += kBlock) {
+        const float v = x[k];
+        if (v != 0.0f) {
+            const uint32_t i = atomicAdd(&nnz, 1u);
+            if (i < (uint32_t)kMaxNnz) { nz_idx[i] = k; nz_val[i] = v; }
+        }
+    }
+    __syncthreads();
+    const uint32_t n = nnz;
+    const bool dense = n > (uint32_t)kMaxNnz;       // not a bag of words: fall back to the full row
+    for (uint32_t j = tid; j < a.Dp; j += kBlock) {
+        for (uint32_t h = 0; h < a.n_hop; h++) {
+            const QFmt fw = a.w[h];
+            int8_t kcode = 0, vcode = 0;
+            if (j < a.D) {
+                const float *wa = a.w_a[h] + (size_t)j * a.V;
+                const float *wc = a.w_c[h] + (size_t)j * a.V;
+                float sa = 0.0f, sc = 0.0f;           // exact: multiples of 2^-frac below 2^24 units
+                if (!dense) {
+                    for (uint32_t i = 0; i < n; i++) {
+                        const uint32_t k = nz_idx[i];
+                        sa += qm_fixed_mul(nz_val[i], wa[k], fw, fw);
+                        sc += qm_fixed_mul(nz_val[i], wc[k], fw, fw);
+                    }
+                } else {
+                    for (uint32_t k = 0; k < a.V; k++) {
+                        sa += qm_fixed_mul(x[k], wa[k], fw, fw);
+                        sc += qm_fixed_mul(x[k], wc[k], fw, fw);
+                    }
+                }
+                const float ea = qm_quant(sa, fw.iwl, fw.frac);
+                const float ec = qm_quant(sc, fw.iwl, fw.frac);
+                kcode = (int8_t)qm_code(ea, a.att[h].iwl, a.att[h].frac);
+                vcode = (int8_t)qm_code(ec, a.act[h].iwl, a.act[h].frac);
+            }
+            a.keys[(size_t)h * a.hop_stride + s * a.Dp + j] = kcode;
+            a.vals[(size_t)h * a.hop_stride + s * a.Dp + j] = vcode;
+        }
+    }
+}
+
+// Question embedding u0[j] = Qw0( sum_k Qw0( Qw0(W[j][k]) . Qw0(q[k]) ) ) (lib/layer_cuda.cu:49-83 via :3184)
+__global__ void __launch_bounds__(kBlock)
+k_embed_query(const float *__restrict__ question, const float *__restrict__ w_q, float *__restrict__ u0,
+              uint32_t D, uint32_t V, QFmt fw)
+{
+    __shared__ uint32_t nz_idx[kMaxNnz];
+    __shared__ float nz_val[kMaxNnz];
+    __shared__ uint32_t nnz;
+    const uint32_t tid = threadIdx.x;
+    const size_t q = blockIdx.x;
+    const float *x = question + q * V;
+    if (tid == 0) nnz = 0;
+    __syncthreads();
+    for (uint32_t k = tid; k < V; k += kBlock) {
+        const float v = x[k];
+        if (v != 0.0f) {
+            const uint32_t i = atomicAdd(&nnz, 1u);
+            if (i < (uint32_t)kMaxNnz) { nz_idx[i] = k; nz_val[i] = v; }
+        }
+    }
+    __syncthreads();
+    const uint32_t n = nnz;
+    for (uint32_t j = tid; j < D; j += kBlock) {
+        const float *wr = w_q + (size_t)j * V;
+        float s = 0.0f;
+        if (n <= (uint32_t)kMaxNnz) {
+            for (uint32_t i = 0; i < n; i++) s += qm_fixed_mul(wr[nz_idx[i]], nz_val[i], fw, fw);
+        } else {
+            for (uint32_t k = 0; k < V; k++) s += qm_fixed_mul(wr[k], x[k], fw, fw);
+        }
+        u0[q * D + j] = qm_quant(s, fw.iwl, fw.frac);
+    }
+}
+
+inline bool fmt8(qmann_fmt f) { return f.iwl + f.frac >= 1 && f.iwl + f.frac <= 7; }
+
+}  // namespace
+
+extern "C" {
+
+int qmann_answer_f32(const qmann_net *net, const float *w_ans, const float *u, const uint32_t *answer,
+                     uint32_t *pred, float *probs, float *cost, uint32_t *match, uint32_t n_query, void *stream)
+{
+    if (!net || !w_ans || !u || !pred) return QMANN_EINVAL;
+    const uint32_t D = net->dim_emb, V = net->dim_input;
+    if (D == 0 || V == 0) return QMANN_EINVAL;
+    const size_t lds = ((size_t)((D + 3) & ~3u) + V) * sizeof(float);
+    if (lds > 128 * 1024) return QMANN_ERANGE;
+    if (n_query == 0) return QMANN_OK;
+    if (lds > 48 * 1024)
+        QM_HIP(hipFuncSetAttribute((const void *)k_answer, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_answer<<<n_query, kBlock, lds, (hipStream_t)stream>>>(w_ans, u, answer, pred, probs, cost, match, D, V,
+                                                          net->softmax_base);
+    QM_LAUNCH_CHECK();
+    return QMANN_OK;
+}
+
+int qmann_embed_story(const qmann_net *net, const float *story, uint32_t rows_total, const float *const *w_a,
+                      const float *const *w_c, int8_t *keys, int8_t *vals, size_t hop_stride, void *stream)
+{
+    if (!net || !story || !w_a || !w_c || !keys || !vals) return QMANN_EINVAL;
+    if (net->n_hop == 0 || net->n_hop > QMANN_MAX_HOP || net->dim_emb > net->dim_emb_pad) return QMANN_EINVAL;
+    if (hop_stride < (size_t)rows_total * net->dim_emb_pad) return QMANN_EINVAL;
+    EmbedArgs a{};
+    a.story = story; a.keys = keys; a.vals = vals; a.hop_stride = hop_stride;
+    a.n_hop = net->n_hop; a.D = net->dim_emb; a.Dp = net->dim_emb_pad; a.V = net->dim_input;
+    for (uint32_t h = 0; h < net->n_hop; h++) {
+        if (!w_a[h] || !w_c[h]) return QMANN_EINVAL;
+        if (!fmt8(net->act[h]) || !fmt8(net->w[h]) || !fmt8(net->att[h])) return QMANN_ERANGE;
+        a.w_a[h] = w_a[h]; a.w_c[h] = w_c[h];
+        a.act[h] = QFmt{net->act[h].iwl, net->act[h].frac};
+        a.w[h] = QFmt{net->w[h].iwl, net->w[h].frac};
+        a.att[h] = QFmt{net->att[h].iwl, net->att[h].frac};
+    }
+    if (rows_total == 0) return QMANN_OK;
+    k_embed_story<<<rows_total, kBlock, 0, (hipStream_t)stream>>>(a);
+    QM_LAUNCH_CHECK();
+    return QMANN_OK;
+}
+
+int qmann_embed_query(const qmann_net *net, const float *question, const float *w_q, float *u0, uint32_t n_query,
+                      void *stream)
+{
+    if (!net || !question || !w_q || !u0) return QMANN_EINVAL;
+    if (!fmt8(net->w[0])) return QMANN_ERANGE;
+    if (n_query == 0) return QMANN_OK;
+    k_embed_query<<<n_query, kBlock, 0, (hipStream_t)stream>>>(question, w_q, u0, net->dim_emb, net->dim_input,
+                                                             QFmt{net->w[0].iwl, net->w[0].frac});
+    QM_LAUNCH_CHECK();
+    return QMANN_OK;
+}
+
+}  // extern "C"

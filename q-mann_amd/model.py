@@ -1,0 +1,159 @@
+"""Host-side mirror of the reference's test-phase forward, driving the C-ABI library.
+
+The reference wires `dense`, `dense_mat`, `dot_mat_vec`, `softmax`, `sum_vec`, `dense`,
+`softmax`, `cross_entropy` layer structs per query (MemN2N/MemN2N.c:2406-2697).  `QNet`
+holds the same configuration (formats per hop, attention mode, weight tables) and runs the
+same stages for a whole batch through the batched entry points of include/qmann_batch.h.
+torch is used for device buffers only; every computation is a call into libqmann_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import abi
+
+
+def pad16(d: int) -> int:
+    for p in (64, 128, 256):
+        if d <= p:
+            return p
+    raise ValueError(f"dim_emb {d} > 256 is not supported by the batched kernels")
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def babi_cfg(dim_input, attention_mode=2, softmax_base=0, iwl=5, n_hop=3, D=60, en_mq=True):
+    """run.sh default iwl=5 (MemN2N/run.sh:6,18); EN_MQ shifts the weight formats of hops 0 and 2
+    (MemN2N/MemN2N.c:748-754)."""
+    frac = 7 - iwl
+    fmt = [(iwl, frac)] * n_hop
+    fmt_w = list(fmt)
+    if en_mq and n_hop >= 3:
+        fmt_w[0] = (iwl + 1, frac - 1)
+        fmt_w[2] = (iwl - 1, frac + 1)
+    return dict(n_hop=n_hop, dim_emb=D, dim_input=int(dim_input), attention_mode=attention_mode,
+                softmax_variant=softmax_base, f_fixed=True, en_lin_map=True, fmt=fmt, fmt_w=fmt_w,
+                fmt_att=list(fmt), fmt_bin=(iwl, frac))
+
+
+@dataclass
+class HopTaps:
+    score_codes: torch.Tensor
+    scores: torch.Tensor
+    probs: torch.Tensor
+    o: torch.Tensor
+    u: torch.Tensor
+
+
+class QNet:
+    """cfg: the dict shape used by oracle/pyoracle.py (n_hop, dim_emb, dim_input, attention_mode,
+    softmax_variant (0 e^x / 1 2^x), en_lin_map, fmt, fmt_w, fmt_att, fmt_bin).
+    weights: float32 numpy arrays w_q [D][V], w_a[h]/w_c[h] [D][V], w_h[h] [D][D], w_ans [V][D];
+    w_q / w_a / w_c may be absent for nets that start from ready-made memories."""
+
+    def __init__(self, cfg: dict, weights: dict, device="cuda:0", stream=None):
+        self.cfg = cfg
+        self.dev = torch.device(device)
+        self.H, self.D, self.V = cfg["n_hop"], cfg["dim_emb"], cfg["dim_input"]
+        self.Dp = pad16(self.D)
+        self.stream = stream
+        n = self.net = abi.Net()
+        n.n_hop, n.dim_emb, n.dim_emb_pad, n.dim_input = self.H, self.D, self.Dp, self.V
+        n.attention_mode = cfg["attention_mode"]
+        n.softmax_base = cfg.get("softmax_variant", 0)
+        n.en_lin_map = 1 if cfg.get("en_lin_map", True) else 0
+        n.num_bit = cfg.get("num_bit", 8)
+        for h in range(self.H):
+            n.act[h] = abi.Fmt(*cfg["fmt"][h])
+            n.w[h] = abi.Fmt(*cfg["fmt_w"][h])
+            n.att[h] = abi.Fmt(*cfg["fmt_att"][h])
+        n.bin = abi.Fmt(*cfg["fmt_bin"])
+
+        def up(a):
+            return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(self.dev)
+        self.w_ans = up(weights["w_ans"])
+        self.w_q = up(weights["w_q"]) if weights.get("w_q") is not None else None
+        self.w_a = [up(w) for w in weights["w_a"]] if weights.get("w_a") is not None else None
+        self.w_c = [up(w) for w in weights["w_c"]] if weights.get("w_c") is not None else None
+        self.lin_map_i8 = []
+        if n.en_lin_map:
+            for h in range(self.H):
+                wf = up(weights["w_h"][h])
+                self.lin_map_i8.append(self.quantize_i8(wf, cfg["fmt_w"][h]))
+                n.lin_map[h] = self.lin_map_i8[h].data_ptr()
+
+    # ---- helpers -------------------------------------------------------------------------
+    def _s(self):
+        return C.c_void_p(self.stream) if self.stream else None
+
+    def quantize_i8(self, x: torch.Tensor, fmt) -> torch.Tensor:
+        """float [rows][cols] -> int8 codes [rows][Dp-padded cols] of Q(fmt)(x)."""
+        assert x.dtype == torch.float32 and x.is_contiguous()
+        rows = x.numel() // x.shape[-1]
+        cols = x.shape[-1]
+        pitch = pad16(cols) if cols <= 256 else cols
+        out = torch.empty((*x.shape[:-1], pitch), dtype=torch.int8, device=x.device)
+        abi.check(abi.lib.qmann_quantize_i8(_ptr(x), _ptr(out), rows, cols, pitch, abi.Fmt(*fmt), self._s()),
+                  "qmann_quantize_i8")
+        return out
+
+    # ---- stages --------------------------------------------------------------------------
+    def embed(self, story: torch.Tensor, question: torch.Tensor):
+        """story [rows_total][V] float, question [B][V] float -> keys, vals int8 [H][rows][Dp], u0 [B][D]."""
+        rows = story.shape[0]
+        keys = torch.empty((self.H, rows, self.Dp), dtype=torch.int8, device=self.dev)
+        vals = torch.empty_like(keys)
+        wa = (C.c_void_p * self.H)(*[w.data_ptr() for w in self.w_a])
+        wc = (C.c_void_p * self.H)(*[w.data_ptr() for w in self.w_c])
+        abi.check(abi.lib.qmann_embed_story(C.byref(self.net), _ptr(story), rows, wa, wc, _ptr(keys), _ptr(vals),
+                                            rows * self.Dp, self._s()), "qmann_embed_story")
+        u0 = torch.empty((question.shape[0], self.D), dtype=torch.float32, device=self.dev)
+        abi.check(abi.lib.qmann_embed_query(C.byref(self.net), _ptr(question), _ptr(self.w_q), _ptr(u0),
+                                            question.shape[0], self._s()), "qmann_embed_query")
+        return keys, vals, u0
+
+    def hops(self, keys, vals, row_off, max_slots, u0, taps=False, u_out=None):
+        """keys/vals int8 [H][rows][Dp]; row_off uint32 (as int32 tensor) [B+1]; u0 [B][D] float."""
+        B = u0.shape[0]
+        rows = keys.shape[1]
+        assert keys.shape == (self.H, rows, self.Dp) and keys.is_contiguous() and vals.is_contiguous()
+        if u_out is None:
+            u_out = torch.empty_like(u0)
+        tp, tobj = None, None
+        if taps:
+            tobj = HopTaps(
+                torch.zeros((self.H, rows), dtype=torch.int32, device=self.dev),
+                torch.zeros((self.H, rows), dtype=torch.float32, device=self.dev),
+                torch.zeros((self.H, rows), dtype=torch.float32, device=self.dev),
+                torch.zeros((B, self.H, self.D), dtype=torch.float32, device=self.dev),
+                torch.zeros((B, self.H, self.D), dtype=torch.float32, device=self.dev))
+            tp = abi.Taps(tobj.score_codes.data_ptr(), tobj.scores.data_ptr(), tobj.probs.data_ptr(),
+                          tobj.o.data_ptr(), tobj.u.data_ptr())
+        abi.check(abi.lib.qmann_hops_i8(C.byref(self.net), _ptr(keys), _ptr(vals), rows * self.Dp, _ptr(row_off),
+                                        max_slots, _ptr(u0), _ptr(u_out), C.byref(tp) if tp else None, B,
+                                        self._s()), "qmann_hops_i8")
+        return (u_out, tobj) if taps else u_out
+
+    def answer(self, u, answer=None, want_probs=False):
+        B = u.shape[0]
+        pred = torch.empty(B, dtype=torch.int32, device=self.dev)
+        probs = torch.empty((B, self.V), dtype=torch.float32, device=self.dev) if want_probs else None
+        cost = torch.zeros(1, dtype=torch.float32, device=self.dev) if answer is not None else None
+        match = torch.zeros(1, dtype=torch.int32, device=self.dev) if answer is not None else None
+        abi.check(abi.lib.qmann_answer_f32(C.byref(self.net), _ptr(self.w_ans), _ptr(u), _ptr(answer), _ptr(pred),
+                                           _ptr(probs), _ptr(cost), _ptr(match), B, self._s()), "qmann_answer_f32")
+        return pred, probs, cost, match
+
+    def forward_bow(self, story, question, row_off, max_slots, answer=None, taps=False):
+        keys, vals, u0 = self.embed(story, question)
+        r = self.hops(keys, vals, row_off, max_slots, u0, taps=taps)
+        u = r[0] if taps else r
+        pred, probs, cost, match = self.answer(u, answer, want_probs=taps)
+        return dict(pred=pred, probs=probs, cost=cost, match=match, u=u, u0=u0, keys=keys, vals=vals,
+                    taps=r[1] if taps else None)
