@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the quantized MemN2N inference hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+
+One "step" = one pass of the hot path (all hops of every query, then the answer layer) over
+one resident batch of synthetic queries.  Prints ONE JSON line (rank 0).
+
+Workloads (config.workload):
+  synth10k_d128   BASELINE.json configs[3], one GPU's shard: |memory| = 10 000 slots, D = 128,
+                  int8 Q5.2 (run.sh default iwl = 5), 3 hops, fixed-point dot attention
+                  (ATTENTION_MODE 2), 8 192 queries per GPU, per-query memories (62.9 GB).  Default:
+                  this is the configuration the north-star roofline target is quoted on.
+  babi_mem50      bAbI-shaped: |memory| = 50 (MAX_SEN_LEN cap), D = 60, V = 30+50, 3 hops, int8 --
+                  the |mem| = 50 size of BASELINE.json's metric string; latency/VALU bound.
+
+N > 1: launched by torch.distributed.run, one rank per GPU.  Queries are independent, so the
+batch is sharded with no data-path collective (weak scaling: 8 192 queries per GPU); RCCL is
+used once, to broadcast the quantized parameters from rank 0 (timed separately).
+"""
+from __future__ import annotations
+
+import argparse
+import importlib.util
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def load_pkg():
+    if "qmann_amd" in sys.modules:
+        return sys.modules["qmann_amd"]
+    d = ROOT / "q-mann_amd"
+    spec = importlib.util.spec_from_file_location("qmann_amd", d / "__init__.py", submodule_search_locations=[str(d)])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["qmann_amd"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+WORKLOADS = {
+    # name: (slots, D, V, queries per GPU, sigma of key/query codes, sigma of value codes)
+    "synth10k_d128": dict(S=10000, D=128, V=256, B=8192, sk=3.5, sv=30.0, su=3.5),
+    "synth10k_d256": dict(S=10000, D=256, V=256, B=4096, sk=2.5, sv=30.0, su=2.5),
+    "babi_mem50": dict(S=50, D=60, V=80, B=262144, sk=8.0, sv=30.0, su=8.0),
+}
+
+
+def gauss_i8(shape, sigma, gen, dev, pad_from=None):
+    """int8 codes clip(round(N(0, sigma)), +-127), generated on the device in chunks."""
+    out = torch.empty(shape, dtype=torch.int8, device=dev)
+    flat = out.view(-1)
+    n = flat.numel()
+    chunk = 1 << 28
+    for a in range(0, n, chunk):
+        b = min(n, a + chunk)
+        x = torch.randn(b - a, device=dev, generator=gen, dtype=torch.float32)
+        flat[a:b] = x.mul_(sigma).round_().clamp_(-127, 127).to(torch.int8)
+    if pad_from is not None and pad_from < shape[-1]:
+        out[..., pad_from:] = 0
+    return out
+
+
+def make_params(cfg, D, V, seed):
+    rng = np.random.default_rng(seed)
+    return {"w_h": [rng.normal(0, 1.0, (D, D)).astype(np.float32) for _ in range(cfg["n_hop"])],
+            "w_ans": rng.normal(0, 0.1, (V, D)).astype(np.float32)}
+
+
+def cpu_baseline(cfg, wts, keys, vals, u0, S, D, budget_s=15.0):
+    """The CPU oracle (our scalar restatement of the reference arithmetic, 1 thread) on a bounded
+    sample of the SAME queries.  Checker infrastructure used as a reported baseline only."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    from pyoracle import Oracle
+    ora = Oracle()
+    m = ora.make_model(cfg, wts)
+    H = cfg["n_hop"]
+    done, t_used, preds = 0, 0.0, []
+    B = u0.shape[0]
+    while done < B and (t_used < budget_s or done < 2):
+        q = done
+        kf = np.stack([keys[h, q * S:(q + 1) * S, :D].cpu().numpy().astype(np.float32)
+                       / np.float32(1 << cfg["fmt_att"][h][1]) for h in range(H)])
+        vf = np.stack([vals[h, q * S:(q + 1) * S, :D].cpu().numpy().astype(np.float32)
+                       / np.float32(1 << cfg["fmt"][h][1]) for h in range(H)])
+        uq = u0[q].cpu().numpy()
+        t0 = time.perf_counter()
+        pred, _ = ora.forward_mem(m, kf, vf, uq, taps=())
+        t_used += time.perf_counter() - t0
+        preds.append(pred)
+        done += 1
+        if done >= 4096:
+            break
+    return done / t_used, done, t_used, preds
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="synth10k_d128", choices=sorted(WORKLOADS))
+    ap.add_argument("--queries", type=int, default=0, help="queries per GPU (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+
+    load_pkg()
+    import qmann_amd.model as model
+
+    wl = WORKLOADS[args.workload]
+    S, D, V = wl["S"], wl["D"], wl["V"]
+    B = args.queries or wl["B"]
+    H = 3
+    cfg = model.babi_cfg(V, attention_mode=2, softmax_base=0, iwl=5, n_hop=H, D=D, en_mq=False)
+
+    # parameters: created on rank 0, broadcast once over RCCL (xGMI) -- the only collective
+    wts = make_params(cfg, D, V, seed=0x51A44)
+    bcast_ms = None
+    if world > 1:
+        import torch.distributed as dist
+        blob = torch.from_numpy(np.concatenate([w.ravel() for w in wts["w_h"]] + [wts["w_ans"].ravel()])).to(dev)
+        if rank != 0:
+            blob.zero_()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        dist.broadcast(blob, src=0)
+        torch.cuda.synchronize()
+        bcast_ms = (time.perf_counter() - t0) * 1e3
+        flat = blob.cpu().numpy()
+        o = 0
+        for h in range(H):
+            wts["w_h"][h] = flat[o:o + D * D].reshape(D, D).copy(); o += D * D
+        wts["w_ans"] = flat[o:o + V * D].reshape(V, D).copy()
+    net = model.QNet(cfg, wts, device=str(dev))
+    Dp = net.Dp
+
+    # synthetic per-query memories, resident in HBM before the timed region
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0x51A44 + rank)
+    keys = gauss_i8((H, B * S, Dp), wl["sk"], gen, dev, pad_from=D)
+    vals = gauss_i8((H, B * S, Dp), wl["sv"], gen, dev, pad_from=D)
+    u0 = (torch.randn((B, D), device=dev, generator=gen) * wl["su"]).round_().clamp_(-127, 127) / 4.0
+    row_off = (torch.arange(B + 1, device=dev, dtype=torch.int64) * S).to(torch.int32)
+    u_out = torch.empty_like(u0)
+    torch.cuda.synchronize()
+
+    def step():
+        net.hops(keys, vals, row_off, S, u0, u_out=u_out)
+        return net.answer(u_out)[0]
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record()
+        net.hops(keys, vals, row_off, S, u0, u_out=u_out)
+        ev[i][1].record()
+        pred = net.answer(u_out)[0]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    hop_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))      # dominant kernel, HIP events
+    bytes_per_query = H * S * Dp                                      # key planes: the addressing scan
+    achieved = bytes_per_query * B / (hop_ms * 1e-3) / 1e9
+
+    out = {
+        "metric": "queries/sec", "value": world * B * args.steps / elapsed, "unit": "queries/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "int8", "data": "synthetic",
+        "config": {"workload": args.workload, "slots": S, "dim_emb": D, "dim_emb_pad": Dp, "hops": H,
+                   "queries_per_gpu": B, "format": "Q5.2", "attention_mode": 2,
+                   "parallelism": f"replicas x{world}, query-sharded"},
+        "roofline": {"bound": "hbm", "kernel": "k_hops_fixed", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "bytes_per_query": bytes_per_query, "kernel_ms": hop_ms},
+    }
+    if bcast_ms is not None:
+        out["param_broadcast_ms"] = bcast_ms
+    if rank == 0 and not args.no_cpu_baseline:
+        qps, n, secs, preds = cpu_baseline(cfg, wts, keys, vals, u0, S, D)
+        gp = pred[:n].cpu().numpy().tolist()
+        out["cpu_baseline"] = {"value": qps, "unit": "queries/s", "cores": 1, "kind": "port",
+                               "sample": f"first {n} queries of the same batch, {secs:.1f} s, scalar C oracle -O2",
+                               "pred_agree": int(sum(int(a == b) for a, b in zip(gp, preds))), "pred_total": n}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
