@@ -55,7 +55,7 @@ WORKLOADS = {
 
 
 def gauss_i8(shape, sigma, gen, dev, pad_from=None):
-    """int8 codes clip(round(N(0, sigma)), +-127), generated on the device in chunks."""
+    """sign-magnitude int8 codes of clip(round(N(0, sigma)), +-127), generated on the device in chunks."""
     out = torch.empty(shape, dtype=torch.int8, device=dev)
     flat = out.view(-1)
     n = flat.numel()
@@ -63,7 +63,8 @@ def gauss_i8(shape, sigma, gen, dev, pad_from=None):
     for a in range(0, n, chunk):
         b = min(n, a + chunk)
         x = torch.randn(b - a, device=dev, generator=gen, dtype=torch.float32)
-        flat[a:b] = x.mul_(sigma).round_().clamp_(-127, 127).to(torch.int8)
+        c = x.mul_(sigma).round_().clamp_(-127, 127).to(torch.int8)
+        flat[a:b] = torch.where(c < 0, (-c) | -128, c)
     if pad_from is not None and pad_from < shape[-1]:
         out[..., pad_from:] = 0
     return out
@@ -80,6 +81,7 @@ def cpu_baseline(cfg, wts, keys, vals, u0, S, D, budget_s=15.0):
     sample of the SAME queries.  Checker infrastructure used as a reported baseline only."""
     sys.path.insert(0, str(ROOT / "oracle"))
     from pyoracle import Oracle
+    from qmann_amd.model import from_signmag
     ora = Oracle()
     m = ora.make_model(cfg, wts)
     H = cfg["n_hop"]
@@ -87,9 +89,9 @@ def cpu_baseline(cfg, wts, keys, vals, u0, S, D, budget_s=15.0):
     B = u0.shape[0]
     while done < B and (t_used < budget_s or done < 2):
         q = done
-        kf = np.stack([keys[h, q * S:(q + 1) * S, :D].cpu().numpy().astype(np.float32)
+        kf = np.stack([from_signmag(keys[h, q * S:(q + 1) * S, :D].cpu().numpy()).astype(np.float32)
                        / np.float32(1 << cfg["fmt_att"][h][1]) for h in range(H)])
-        vf = np.stack([vals[h, q * S:(q + 1) * S, :D].cpu().numpy().astype(np.float32)
+        vf = np.stack([from_signmag(vals[h, q * S:(q + 1) * S, :D].cpu().numpy()).astype(np.float32)
                        / np.float32(1 << cfg["fmt"][h][1]) for h in range(H)])
         uq = u0[q].cpu().numpy()
         t0 = time.perf_counter()

@@ -14,7 +14,9 @@
  * boundary's convention instead -- message on stderr and exit().
  *
  * Data layout ("memory" = the per-query story slots):
- *   keys, vals : int8 [n_hop][rows_total][Dp]    two's-complement codes
+ *   keys, vals : int8 [n_hop][rows_total][Dp]    SIGN-MAGNITUDE codes: bit 7 = sign, bits 6..0 =
+ *                |code| -- the top byte of the reference's own FLOAT2FIXED word
+ *                (lib/common.h:210), so "minus zero" (0x80) is representable as it is there.
  *                Dp = dim_emb_pad (multiple of 16, >= D); columns D..Dp-1 are 0.
  *                keys[h] carry Q(att[h]) codes, vals[h] carry Q(act[h]) codes --
  *                i.e. what the reference's dot_mat_vec layers see after their
@@ -50,6 +52,9 @@ enum {
     QMANN_ATT_SIGN = 12       /* +-1 dot product of the sign bits (BINARY_MODE, n = 1)            */
 };
 
+/* byte layout of an int8 code */
+enum { QMANN_CODE_TWOS = 0 /* two's complement (weights) */, QMANN_CODE_SIGNMAG = 1 /* memories */ };
+
 enum { QMANN_SOFTMAX_EXP = 0 /* lib/layer_cuda.cu:2006 */, QMANN_SOFTMAX_POW2 = 1 /* lib/layer.c:1225 */ };
 
 typedef struct qmann_fmt {
@@ -70,7 +75,7 @@ typedef struct qmann_net {
     qmann_fmt w[QMANN_MAX_HOP];     /* (iwl_w[h], frac_w[h])      :718-719, 748-754       */
     qmann_fmt att[QMANN_MAX_HOP];   /* (iwl_att[h], frac_att[h])  :721-722                */
     qmann_fmt bin;                  /* (iwl_bin, frac_bin)        :769-775                */
-    const int8_t *lin_map[QMANN_MAX_HOP]; /* device, [D][Dp] codes in format w[h]; NULL when !en_lin_map */
+    const int8_t *lin_map[QMANN_MAX_HOP]; /* device, [D][Dp] two's-complement codes in format w[h]; NULL when !en_lin_map */
 } qmann_net;
 
 /* optional per-query taps for parity tests; any pointer may be NULL */
@@ -82,10 +87,10 @@ typedef struct qmann_taps {
     float   *u;             /* [n_query][n_hop][D] */
 } qmann_taps;
 
-/* float -> int8 code of Q(iwl.frac)(x); n elements; rows of `cols` values are written with pitch
- * `pitch` (>= cols, padding zeroed).  Rejects formats with iwl + frac > 7. */
+/* float -> int8 code of Q(iwl.frac)(x) in the given byte layout; rows of `cols` values are written
+ * with pitch `pitch` (>= cols, padding zeroed).  Rejects formats with iwl + frac > 7. */
 int qmann_quantize_i8(const float *src, int8_t *dst, size_t rows, uint32_t cols, uint32_t pitch,
-                      qmann_fmt fmt, void *stream);
+                      qmann_fmt fmt, int layout, void *stream);
 
 /* The hot path: all hops of all queries in one launch (one workgroup per query).
  *   u0    [n_query][D] float   -- question embedding (emb_q output)

@@ -18,6 +18,7 @@ lib = C.CDLL(str(LIB_PATH))
 QMANN_MAX_HOP = 8
 ATT_FLOAT, ATT_FIXED, ATT_APPX, ATT_HAMMING_V0, ATT_HAMMING_V1, ATT_SIGN = 1, 2, 3, 10, 11, 12
 SOFTMAX_EXP, SOFTMAX_POW2 = 0, 1
+CODE_TWOS, CODE_SIGNMAG = 0, 1
 
 _vp = C.c_void_p
 _u = C.c_uint
@@ -98,7 +99,8 @@ _proto("qmann_abi_symbol_count", _u, [])
 
 # ---- batched int8 API (include/qmann_batch.h) ----
 _proto("qmann_hops_lds_bytes", C.c_size_t, [C.c_uint32])
-_proto("qmann_quantize_i8", C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, C.c_uint32, Fmt, _vp])
+_proto("qmann_quantize_i8", C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, C.c_uint32, Fmt, C.c_int, _vp])
+_proto("qmann_debug_set_tune", None, [C.c_int])
 _proto("qmann_hops_i8", C.c_int, [C.POINTER(Net), _vp, _vp, C.c_size_t, _vp, C.c_uint32, _vp, _vp,
                                   C.POINTER(Taps), C.c_uint32, _vp])
 _proto("qmann_answer_f32", C.c_int, [C.POINTER(Net), _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_uint32, _vp])

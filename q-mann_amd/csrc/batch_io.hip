@@ -104,12 +104,19 @@ k_answer(const float *__restrict__ w_ans, const float *__restrict__ u, const uin
 // Story embedding: E[s][j] = Qw( sum_k Qw( Qw(X[s][k]) . Qw(W[j][k]) ) )
 // (lib/layer_cuda.cu:105-172 via :3531) for the A and C tables of every hop, then
 // re-quantised to the format its consumer applies (keys: att[h], lib/layer_cuda.cu:120;
-// values: act[h], :562) and stored as int8.  X is a bag of words: a handful of
+// values: act[h], :562) and stored as sign-magnitude int8.  X is a bag of words: a handful of
 // non-zeros per row, so rows are first compacted to (index, value) pairs in LDS
 // and the sum becomes a short gather over table columns.  One workgroup per
 // story row; thread j < D owns output column j for all 2.n_hop tables.
 // ---------------------------------------------------------------------------
 constexpr int kMaxNnz = 64;
+
+// sign-magnitude byte of Q(f)(x): the top byte of the reference's FLOAT2FIXED word
+__device__ __forceinline__ int8_t sm_byte(float x, QFmt f)
+{
+    const int k = qm_code(x, f.iwl, f.frac);
+    return (int8_t)((uint32_t)(k < 0 ? -k : k) | ((x >= 0.0f) ? 0u : 0x80u));
+}
 
 struct EmbedArgs {
     const float *story;
@@ -165,8 +172,8 @@ k_embed_story(const EmbedArgs a)
                 }
                 const float ea = qm_quant(sa, fw.iwl, fw.frac);
                 const float ec = qm_quant(sc, fw.iwl, fw.frac);
-                kcode = (int8_t)qm_code(ea, a.att[h].iwl, a.att[h].frac);
-                vcode = (int8_t)qm_code(ec, a.act[h].iwl, a.act[h].frac);
+                kcode = sm_byte(ea, a.att[h]);
+                vcode = sm_byte(ec, a.act[h]);
             }
             a.keys[(size_t)h * a.hop_stride + s * a.Dp + j] = kcode;
             a.vals[(size_t)h * a.hop_stride + s * a.Dp + j] = vcode;

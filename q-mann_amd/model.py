@@ -24,6 +24,20 @@ def pad16(d: int) -> int:
     raise ValueError(f"dim_emb {d} > 256 is not supported by the batched kernels")
 
 
+def to_signmag(codes):
+    """two's-complement int8 codes (numpy or torch, |code| <= 127) -> sign-magnitude bytes"""
+    if isinstance(codes, torch.Tensor):
+        return torch.where(codes < 0, (-codes) | -128, codes).to(torch.int8)
+    c = codes.astype(np.int16)
+    return np.where(c < 0, (-c) | 0x80, c).astype(np.uint8).view(np.int8)
+
+
+def from_signmag(b):
+    """sign-magnitude bytes (numpy int8/uint8) -> integer codes (int16)"""
+    u = b.view(np.uint8).astype(np.int16)
+    return np.where(u & 0x80, -(u & 0x7F), u & 0x7F).astype(np.int16)
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -92,14 +106,14 @@ class QNet:
     def _s(self):
         return C.c_void_p(self.stream) if self.stream else None
 
-    def quantize_i8(self, x: torch.Tensor, fmt) -> torch.Tensor:
+    def quantize_i8(self, x: torch.Tensor, fmt, layout=abi.CODE_TWOS) -> torch.Tensor:
         """float [rows][cols] -> int8 codes [rows][Dp-padded cols] of Q(fmt)(x)."""
         assert x.dtype == torch.float32 and x.is_contiguous()
         rows = x.numel() // x.shape[-1]
         cols = x.shape[-1]
         pitch = pad16(cols) if cols <= 256 else cols
         out = torch.empty((*x.shape[:-1], pitch), dtype=torch.int8, device=x.device)
-        abi.check(abi.lib.qmann_quantize_i8(_ptr(x), _ptr(out), rows, cols, pitch, abi.Fmt(*fmt), self._s()),
+        abi.check(abi.lib.qmann_quantize_i8(_ptr(x), _ptr(out), rows, cols, pitch, abi.Fmt(*fmt), layout, self._s()),
                   "qmann_quantize_i8")
         return out
 

@@ -69,7 +69,8 @@ def run_case(env, oracle, cfg, B, S_list, seed, sigma_u=20.0, sigma_k=30.0, sigm
     keys[:, :, :D] = np.clip(np.rint(rng.normal(0, sigma_k, (H, max(R, 1), D))), -127, 127)
     vals[:, :, :D] = np.clip(np.rint(rng.normal(0, sigma_k, (H, max(R, 1), D))), -127, 127)
     u0 = (np.clip(np.rint(rng.normal(0, sigma_u, (B, D))), -127, 127) / (1 << cfg["fmt_w"][0][1])).astype(np.float32)
-    dk, dv = torch.from_numpy(keys).to(env.dev), torch.from_numpy(vals).to(env.dev)
+    dk = torch.from_numpy(model.to_signmag(keys)).to(env.dev)      # memories are sign-magnitude bytes
+    dv = torch.from_numpy(model.to_signmag(vals)).to(env.dev)
     u_out, taps = net.hops(dk, dv, torch.from_numpy(row_off).to(env.dev), int(n_slots.max()) if B else 0,
                            torch.from_numpy(u0).to(env.dev), taps=True)
     pred, probs, _, _ = net.answer(u_out, want_probs=True)
@@ -182,8 +183,8 @@ def test_babi_end_to_end_from_bag_of_words(env, oracle, gold):
                 for h in range(H):
                     fa, fm = cfg["fmt"][h], cfg["fmt_att"][h]
                     # stored codes are the consumer-side quantisation of the embedding outputs
-                    np.testing.assert_array_equal(g_keys[h, a:e, :D], oracle.code8(t["keys"][h], *fm))
-                    np.testing.assert_array_equal(g_vals[h, a:e, :D], oracle.code8(t["vals"][h], *fa))
+                    np.testing.assert_array_equal(model.from_signmag(g_keys[h, a:e, :D]), oracle.code8(t["keys"][h], *fm))
+                    np.testing.assert_array_equal(model.from_signmag(g_vals[h, a:e, :D]), oracle.code8(t["vals"][h], *fa))
                     assert not g_keys[h, a:e, D:].any() and not g_vals[h, a:e, D:].any()
                     if ok:
                         np.testing.assert_array_equal(g_codes[h, a:e], np.rint(t["scores"][h] * (1 << fm[1])))

@@ -1,0 +1,67 @@
+// readbw.hip -- development microbenchmark: HBM read ceiling for 16 B/lane streaming loads on this chip,
+// in the two shapes the hop kernel could use.  Not part of the product.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include <algorithm>
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+// shape A: each 256-thread block streams its own contiguous chunk (like one query's key plane)
+template <int UN, bool NT>
+__global__ void __launch_bounds__(256) k_chunk(const i32x4 *__restrict__ src, size_t chunk_vec, int *out)
+{
+    const i32x4 *p = src + (size_t)blockIdx.x * chunk_vec;
+    i32x4 acc = {0, 0, 0, 0};
+    for (size_t i = threadIdx.x; i + (UN - 1) * 256 < chunk_vec; i += UN * 256) {
+        i32x4 x[UN];
+#pragma unroll
+        for (int j = 0; j < UN; j++) x[j] = NT ? __builtin_nontemporal_load(p + i + j * 256) : p[i + j * 256];
+#pragma unroll
+        for (int j = 0; j < UN; j++) acc += x[j];
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678) out[0] = 1;
+}
+// shape B: grid-stride over the whole buffer with a fixed-size grid
+template <int UN, bool NT>
+__global__ void __launch_bounds__(256) k_stride(const i32x4 *__restrict__ src, size_t n_vec, int *out)
+{
+    i32x4 acc = {0, 0, 0, 0};
+    const size_t stride = (size_t)gridDim.x * 256 * UN;
+    for (size_t i = (size_t)blockIdx.x * 256 * UN + threadIdx.x; i + (UN - 1) * 256 < n_vec; i += stride) {
+        i32x4 x[UN];
+#pragma unroll
+        for (int j = 0; j < UN; j++) x[j] = NT ? __builtin_nontemporal_load(src + i + j * 256) : src[i + j * 256];
+#pragma unroll
+        for (int j = 0; j < UN; j++) acc += x[j];
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678) out[0] = 1;
+}
+template <typename F> double timeit(F f, int reps)
+{
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    std::vector<float> t;
+    for (int r = 0; r < reps; r++) { CK(hipEventRecord(a)); f(); CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); float ms; CK(hipEventElapsedTime(&ms, a, b)); t.push_back(ms); }
+    std::sort(t.begin(), t.end()); return t[t.size() / 2];
+}
+int main()
+{
+    const size_t bytes = (size_t)24 << 30; const size_t n_vec = bytes / 16;
+    i32x4 *src; int *out; CK(hipMalloc(&src, bytes)); CK(hipMalloc(&out, 4)); CK(hipMemset(src, 1, bytes));
+    const size_t chunk = 1280000 / 16;    // one key plane of one query
+    const int nblk = (int)(n_vec / chunk);
+    printf("buffer %.1f GB, %d chunks of 1.28 MB\n", bytes / 1e9, nblk);
+#define RUN(name, launch) { launch; CK(hipDeviceSynchronize()); double ms = timeit([&] { launch; }, 7); printf("%-34s %.3f ms  %.0f GB/s\n", name, ms, (double)nblk * chunk * 16 / ms / 1e6); }
+    RUN("chunk un4", (k_chunk<4, false><<<nblk, 256>>>(src, chunk, out)));
+    RUN("chunk un8", (k_chunk<8, false><<<nblk, 256>>>(src, chunk, out)));
+    RUN("chunk un8 nt", (k_chunk<8, true><<<nblk, 256>>>(src, chunk, out)));
+    RUN("chunk un16", (k_chunk<16, false><<<nblk, 256>>>(src, chunk, out)));
+    for (int g : {1024, 2048, 4096, 8192}) {
+        char nm[64]; snprintf(nm, 64, "stride un8 grid %d", g);
+        RUN(nm, (k_stride<8, false><<<g, 256>>>(src, (size_t)nblk * chunk, out)));
+    }
+    RUN("stride un8 nt grid 2048", (k_stride<8, true><<<2048, 256>>>(src, (size_t)nblk * chunk, out)));
+    RUN("stride un4 grid 4096", (k_stride<4, false><<<4096, 256>>>(src, (size_t)nblk * chunk, out)));
+    return 0;
+}
