@@ -96,10 +96,28 @@ int qmann_quantize_i8(const float *src, int8_t *dst, size_t rows, uint32_t cols,
  *   u0    [n_query][D] float   -- question embedding (emb_q output)
  *   u_out [n_query][D] float   -- sv[n_hop-1] output, input of the answer layer
  * Replaces, per query and hop, the reference sequence dot_mat_vec_fwd -> softmax_fwd ->
- * dot_mat_vec_fwd(trans) -> dense_fwd(lin_map) -> sum_vec_fwd (MemN2N/MemN2N.c:2644-2666). */
+ * dot_mat_vec_fwd(trans) -> dense_fwd(lin_map) -> sum_vec_fwd (MemN2N/MemN2N.c:2644-2666).
+ * attention_mode QMANN_ATT_FIXED (define.h mode 2) or QMANN_ATT_APPX (mode 3; needs att formats with
+ * iwl + frac = 7 and u grids no finer / wider than the attention grid, else QMANN_EUNSUPPORTED). */
 int qmann_hops_i8(const qmann_net *net, const int8_t *keys, const int8_t *vals, size_t hop_stride,
                   const uint32_t *row_off, uint32_t max_slots, const float *u0, float *u_out,
                   const qmann_taps *taps, uint32_t n_query, void *stream);
+
+/* Packed binary codes for the Hamming forms: sign-magnitude bytes [rows][Dp] -> bit planes
+ * uint64 [rows][Dp/64][num_bit] (plane 0 = sign bits, plane i = magnitude bit 7-i; bit b of a word
+ * is column 64.g + b).  num_bit in 1..8. */
+int qmann_pack_bitplanes(const int8_t *sm_codes, uint64_t *planes, size_t rows, uint32_t dim_emb_pad,
+                         uint32_t num_bit, void *stream);
+
+/* qmann_hops_i8 for QMANN_ATT_HAMMING_V0 / _V1: keys are packed planes (layout above, per hop
+ * key_hop_stride bytes apart, num_bit = net->num_bit in {1,2,4,8}), values stay int8.  Scores:
+ * V0 = number of agreeing bits over the top num_bit bits of every column (lib/common.c:223-246),
+ * V1 = sum over columns of sgn.sgn.sum_{i>=1} 2^-(i+1) [bit i agrees] (lib/common.c:249-312),
+ * both on the left-aligned words the CUDA path builds (frac = 31 - iwl, lib/layer_cuda.cu:2515). */
+int qmann_hops_packed(const qmann_net *net, const uint64_t *key_planes, size_t key_hop_stride,
+                      const int8_t *vals, size_t val_hop_stride, const uint32_t *row_off,
+                      uint32_t max_slots, const float *u0, float *u_out, const qmann_taps *taps,
+                      uint32_t n_query, void *stream);
 
 /* Answer layer for a batch: logits = W_ans . u (float, ds_ans is always float: MemN2N.c:902-906),
  * softmax over V, arg-max with ties to the highest index, and -- when `answer` is given -- the

@@ -30,7 +30,7 @@ def _fp(a):
 class QoModel(C.Structure):
     _fields_ = [
         ("n_hop", C.c_uint), ("dim_emb", C.c_uint), ("dim_input", C.c_uint),
-        ("attention_mode", C.c_uint), ("softmax_variant", C.c_int),
+        ("attention_mode", C.c_uint), ("num_bit", C.c_uint), ("softmax_variant", C.c_int),
         ("f_fixed", C.c_bool), ("en_lin_map", C.c_bool),
         ("iwl", C.c_uint * QO_MAX_HOP), ("frac", C.c_uint * QO_MAX_HOP),
         ("iwl_w", C.c_uint * QO_MAX_HOP), ("frac_w", C.c_uint * QO_MAX_HOP),
@@ -176,6 +176,7 @@ class Oracle:
         m = QoModel()
         m.n_hop, m.dim_emb, m.dim_input = cfg["n_hop"], cfg["dim_emb"], cfg["dim_input"]
         m.attention_mode = cfg["attention_mode"]
+        m.num_bit = cfg.get("num_bit", 8)
         m.softmax_variant = cfg.get("softmax_variant", SM_CUDA)
         m.f_fixed = cfg.get("f_fixed", True)
         m.en_lin_map = cfg.get("en_lin_map", True)

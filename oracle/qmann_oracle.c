@@ -415,15 +415,18 @@ static void hop_forward(const qo_model *m, unsigned h, const float *keys, const 
     else if (m->attention_mode == 2)
         qo_dot_mat_vec_fwd(keys, u, s, n_sen, D, false, true,
                            m->iwl_att[h], m->frac_att[h], m->iwl_bin, m->frac_bin);
-    else
+    else if (m->attention_mode == 3)
         qo_dot_mat_vec_fwd_appx(keys, u, s, n_sen, D, m->f_fixed, m->iwl_att[h], m->frac_att[h],
                                 1 + m->iwl_att[h] + m->frac_att[h], false);
+    else /* 10 / 11: the CPU hamming functions on the CUDA word alignment (frac = 31 - iwl) */
+        qo_attention_hamming(keys, u, s, n_sen, D, m->iwl_att[h], 31 - m->iwl_att[h], m->num_bit,
+                             m->attention_mode == 10 ? 0 : 1);
     /* softmax over slots: sf_in[h] (MemN2N.c:2651) */
     qo_softmax_fwd(s, p, n_sen, m->softmax_variant, false);
     /* weighted read-out: w_sum[h] (constructor MemN2N.c:863, formats (iwl[h],frac[h])) */
     if (m->attention_mode == 1)
         qo_dot_mat_vec_fwd(vals, p, o, n_sen, D, true, false, 0, 0, 0, 0);
-    else if (m->attention_mode == 2)
+    else if (m->attention_mode == 2 || m->attention_mode >= 10)
         qo_dot_mat_vec_fwd(vals, p, o, n_sen, D, true, true,
                            m->iwl[h], m->frac[h], m->iwl[h], m->frac[h]);
     else

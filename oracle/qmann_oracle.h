@@ -92,7 +92,9 @@ unsigned qo_cross_entropy_run(const float *h, const float *y, unsigned dim,
 #define QO_MAX_HOP 8
 typedef struct {
     unsigned n_hop, dim_emb, dim_input;
-    unsigned attention_mode;      /* 1 float, 2 fixed dot, 3 appx (V2); define.h:10-15 */
+    unsigned attention_mode;      /* 1 float, 2 fixed dot, 3 appx (V2); define.h:10-15;
+                                   * 10 / 11: hamming_similarity / hamming_similarity_w row scorers */
+    unsigned num_bit;             /* bits compared in modes 10 / 11 */
     int      softmax_variant;     /* QO_SM_* for the in-hop softmax and the output softmax */
     bool     f_fixed;             /* EN_FIXED_POINT, define.h:31 */
     bool     en_lin_map;          /* define.h:291 */

@@ -1,0 +1,390 @@
+// batch_hops_ham.hip -- fused hop kernel for the Hamming family of attention scores.
+//
+// Same skeleton as batch_hops.hip (one workgroup per query, all hops, streaming row scan,
+// sparse exact read-out, in-kernel linear map); what changes is the score of a slot:
+//
+//   QMANN_ATT_APPX        the reference's live CUDA "approximate attention"
+//                         (lib/layer_cuda.cu:355-541 with :218-326), on sign-magnitude int8 keys.
+//                         For operands on the Q(iwl_att.7-iwl_att) grid the 32-bit word procedure
+//                         reduces to byte arithmetic: same sign   -> +(127 - |ka - kb|)
+//                                                     opposite    -> +-(127 - ((ka + kb) & 127)),
+//                         positive only when ka + kb carries out of 7 bits and the larger
+//                         operand (the key on ties) is the positive one; the row score is the sum
+//                         in units of 2^-10, clamped at +-2^iwl.  Sums of |ka - kb| over the
+//                         same-sign bytes of a dword are one v_sad_u8.
+//   QMANN_ATT_HAMMING_V0  bit-agreement count over the top num_bit bits (lib/common.c:223-246)
+//   QMANN_ATT_HAMMING_V1  signed, weighted bit agreement (lib/common.c:249-312)
+//                         both on PACKED BINARY CODES: bit-plane i of a 64-column group is one
+//                         uint64 (plane 0 = sign, plane i = magnitude bit 7-i), a row is
+//                         [Dp/64 groups][num_bit planes]; agreement is ~(K ^ U), counted with
+//                         popcount (v_bcnt), split by sign agreement for V1.
+//
+// Scores are not on an 8-bit grid here, so they are kept as int32 in LDS and the softmax is
+// evaluated per slot (max, sum of exp in double, quotient), as lib/layer_cuda.cu:1969-2060 does.
+#include "hops_common.h"
+
+namespace {
+
+constexpr uint32_t kOffUb = kOffHist;                 // u8  [256]  sign-magnitude bytes of Q_att(u)   (reuses the
+constexpr uint32_t kOffUpl = kOffHist + 256;          // u64 [4][8] bit-planes of u                    histogram area)
+static_assert(kOffUpl % 8 == 0 && kOffUpl + 4 * 8 * 8 <= kOffPtab, "u planes must fit the histogram area");
+
+enum { kModeAppx = 0, kModeV0 = 1, kModeV1 = 2 };
+
+// ---- APPX: 4 key bytes against 4 query bytes -------------------------------------------------
+struct AppxConst {
+    uint32_t um[4];   // |u| bytes
+    uint32_t us[4];   // 0x80 where u < 0
+    uint32_t vm[4];   // 0xFF for real columns, 0x00 for padding
+};
+
+__device__ __forceinline__ int appx_lane_sum(const i32x4 x, const AppxConst &c)
+{
+    int acc = 0;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const uint32_t w = (uint32_t)x[d];
+        const uint32_t km = w & 0x7F7F7F7Fu;
+        const uint32_t sd = (w ^ c.us[d]) & 0x80808080u;                    // signs differ
+        const uint32_t dmask = __builtin_amdgcn_perm(0u, 0u, sd) & c.vm[d]; // 0xFF in those bytes
+        const uint32_t smask = c.vm[d] & ~dmask;                            // same sign, real column
+        // same sign: 127 - |ka - kb|
+        const int n_same = __builtin_popcount(smask & 0x01010101u);
+        const uint32_t sad = __builtin_amdgcn_sad_u8(km & smask, c.um[d] & smask, 0u);
+        acc += 127 * n_same - (int)sad;
+        // opposite sign: +-(127 - ((ka + kb) & 127))
+        const uint32_t s4 = (km & dmask) + (c.um[d] & dmask);               // per byte <= 254: no carry across
+        const uint32_t carry = s4 & 0x80808080u;
+        const uint32_t val = (0x7F7F7F7Fu - (s4 & 0x7F7F7F7Fu)) & dmask;
+        const uint32_t ge = ((km | 0x80808080u) - c.um[d]) & 0x80808080u;   // |k| >= |u|
+        const uint32_t lneg = (w & ge) | (c.us[d] & ~ge);                   // sign bit of the larger operand
+        const uint32_t neg = (~(carry & ~lneg)) & 0x80808080u;              // term is negative
+        const uint32_t sg = __builtin_amdgcn_perm(0x01010101u, 0x01010101u, neg);
+        acc = __builtin_amdgcn_sdot4((int)val, (int)sg, acc, false);
+    }
+    return acc;
+}
+
+// ---- V0 / V1: two 64-bit plane words per lane -------------------------------------------------
+struct PlaneConst {
+    uint64_t u[2];      // query plane words at this lane's (group, plane) positions
+    uint64_t valid[2];  // real-column mask of the word's group
+    uint64_t us[2];     // query SIGN plane of the word's group
+    int wgt[2];         // V1 weight 2^(n-1-i) of the word's plane (0 for the sign plane)
+};
+
+template <int MODE, int NB>
+__device__ __forceinline__ int plane_lane_sum(const i32x4 x, const PlaneConst &c)
+{
+    uint64_t k[2];
+    k[0] = (uint64_t)(uint32_t)x[0] | ((uint64_t)(uint32_t)x[1] << 32);
+    k[1] = (uint64_t)(uint32_t)x[2] | ((uint64_t)(uint32_t)x[3] << 32);
+    if (MODE == kModeV0) {
+        return __popcll(~(k[0] ^ c.u[0]) & c.valid[0]) + __popcll(~(k[1] ^ c.u[1]) & c.valid[1]);
+    }
+    // V1: the key's sign plane of each word's group sits in the lane that holds plane 0 of that
+    // group: this lane (NB <= 2), the even lane of the pair (NB == 4) or the first lane of the
+    // quad (NB == 8) -- fetched with quad-permute DPP moves
+    uint64_t ks[2];
+    if (NB == 1) {
+        return 0;                                   // no magnitude planes: every weight is zero
+    } else if (NB == 2) {
+        ks[0] = k[0]; ks[1] = k[0];
+    } else {
+        constexpr int ctrl = (NB == 4) ? 0xA0 /* quad_perm [0,0,2,2] */ : 0x00 /* [0,0,0,0] */;
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, x[0], ctrl, 0xF, 0xF, true);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, x[1], ctrl, 0xF, 0xF, true);
+        ks[0] = (uint64_t)lo | ((uint64_t)hi << 32);
+        ks[1] = ks[0];
+    }
+    int acc = 0;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const uint64_t eq = ~(k[t] ^ c.u[t]);
+        const uint64_t sdiff = (ks[t] ^ c.us[t]) & c.valid[t];
+        const uint64_t ssame = ~(ks[t] ^ c.us[t]) & c.valid[t];
+        acc += c.wgt[t] * (__popcll(eq & ssame) - __popcll(eq & sdiff));
+    }
+    return acc;
+}
+
+// LPRK: lanes per key row; DP: padded embedding width; MODE; NB: planes (packed modes)
+template <int LPRK, int DP, int MODE, int NB>
+__global__ void __launch_bounds__(kBlock)
+k_hops_ham(const HopArgs a, const uint32_t key_row_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint8_t *ub = (uint8_t *)(smem + kOffUb);
+    uint64_t *upl = (uint64_t *)(smem + kOffUpl);
+    float *u_f = (float *)(smem + kOffU);
+    float *o_f = (float *)(smem + kOffO);
+    short *ku = (short *)(smem + kOffKu);
+    uint32_t *live_row = (uint32_t *)(smem + kOffLiveRow);
+    uint8_t *live_kp = (uint8_t *)(smem + kOffLiveKp);
+    uint32_t *misc = (uint32_t *)(smem + kOffMisc);
+    double *red = (double *)(smem + kOffRed);
+    int32_t *sc = (int32_t *)(smem + kOffScores);
+
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const uint32_t q = blockIdx.x;
+    const uint32_t r0 = a.row_off[q];
+    const uint32_t S = a.row_off[q + 1] - r0;
+    const uint32_t D = a.D;
+
+    u_f[tid] = (tid < D) ? a.u0[(size_t)q * D + tid] : 0.0f;
+    __syncthreads();
+
+    for (uint32_t h = 0; h < a.n_hop; h++) {
+        const QFmt fa = a.act[h], fm = a.att[h], fb = a.bin;
+        // codes of u: Q_bin for the linear map, sign-magnitude Q_att bytes for the attention
+        const float uv = u_f[tid];
+        ku[tid] = (short)((tid < D) ? qm_code(uv, fb.iwl, fb.frac) : 0);
+        const int kc = (tid < D) ? qm_code(uv, fm.iwl, fm.frac) : 0;
+        const uint32_t ubyte = (uint32_t)(kc < 0 ? -kc : kc) | ((tid < D && !(uv >= 0.0f)) ? 0x80u : 0u);
+        ub[tid] = (uint8_t)ubyte;
+        if (MODE != kModeAppx) {
+#pragma unroll
+            for (int i = 0; i < NB; i++) {
+                const uint64_t word = __ballot((ubyte >> (7 - i)) & 1u);
+                if (lane == 0) upl[wave * 8 + i] = word;       // wavefront w covers columns 64w .. 64w+63
+            }
+        }
+        if (tid == 0) misc[0] = 0u;
+        __syncthreads();
+
+        float scale = 1.0f;
+        if (S > 0) {
+            const uint8_t *kb = (const uint8_t *)a.keys + (size_t)h * a.key_hop_stride + (size_t)r0 * key_row_bytes;
+            auto retire = [&](uint32_t r, int v) { sc[r] = v; };
+            if (MODE == kModeAppx) {
+                scale = 1.0f / 1024.0f;                         // 2^-(n-1) . 2^ATTENTION_CONST_SCALE, n = 8
+                const int lim = 1 << (fm.iwl + 10);             // final Q(iwl, 31-iwl) clamps at +-2^iwl
+                AppxConst c;
+                const uint32_t c0 = (lane % LPRK) * 16;
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    const uint32_t b4 = *(const uint32_t *)(ub + c0 + 4 * d);
+                    c.um[d] = b4 & 0x7F7F7F7Fu;
+                    c.us[d] = b4 & 0x80808080u;
+                    uint32_t vm = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) vm |= (c0 + 4 * d + i < D ? 0xFFu : 0u) << (8 * i);
+                    c.vm[d] = vm;
+                }
+                auto row_sum = [&](const i32x4 x) { return appx_lane_sum(x, c); };
+                auto retire_c = [&](uint32_t r, int v) { sc[r] = v > lim ? lim : (v < -lim ? -lim : v); };
+                if (S >= (kWave / LPRK) * 4) scan_rows<LPRK, 4, true>(kb, S, row_sum, retire_c, lane, wave);
+                else scan_rows_short<LPRK>(kb, S, row_sum, retire_c, lane, wave);
+            } else {
+                if (MODE == kModeV1) scale = 1.0f / (float)(1 << NB);
+                PlaneConst c;
+                const uint32_t chunk = lane % LPRK;
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const uint32_t wi = 2 * chunk + t;          // word index inside the row
+                    const uint32_t grp = wi / NB, pl = wi % NB;
+                    c.u[t] = upl[grp * 8 + pl];
+                    c.us[t] = upl[grp * 8 + 0];
+                    const uint32_t ncol = D > 64 * grp ? D - 64 * grp : 0;
+                    c.valid[t] = ncol >= 64 ? ~0ull : ((1ull << ncol) - 1ull);
+                    c.wgt[t] = pl == 0 ? 0 : (1 << (NB - 1 - pl));
+                }
+                auto row_sum = [&](const i32x4 x) { return plane_lane_sum<MODE, NB>(x, c); };
+                if (S >= (kWave / LPRK) * 4) scan_rows<LPRK, 4, true>(kb, S, row_sum, retire, lane, wave);
+                else scan_rows_short<LPRK>(kb, S, row_sum, retire, lane, wave);
+            }
+        }
+        __syncthreads();
+
+        // softmax over slots, evaluated per slot (lib/layer_cuda.cu:1895-1916, 1969-2060)
+        uint32_t n_live = 0;
+        if (S > 0) {
+            int mx = INT32_MIN;
+            for (uint32_t r = tid; r < S; r += kBlock) mx = sc[r] > mx ? sc[r] : mx;
+            mx = block_max_int(mx, (int *)red, lane, wave);
+            double part = 0.0;
+            for (uint32_t r = tid; r < S; r += kBlock) {
+                const float x = (float)(sc[r] - mx) * scale;           // exact: score - max on the score grid
+                part += (double)((a.softmax_base == QMANN_SOFTMAX_EXP) ? expf(x) : exp2f(x));
+            }
+            const double total = block_sum_double(part, red, lane, wave);
+            const size_t tb = (size_t)h * a.rows_total + r0;
+            for (uint32_t r = tid; r < S; r += kBlock) {
+                const float x = (float)(sc[r] - mx) * scale;
+                float p;
+                if (a.softmax_base == QMANN_SOFTMAX_EXP) p = (float)((double)expf(x) / total);
+                else p = exp2f(x) / (float)total;
+                if (a.tap_codes) a.tap_codes[tb + r] = sc[r];
+                if (a.tap_scores) a.tap_scores[tb + r] = (float)sc[r] * scale;
+                if (a.tap_probs) a.tap_probs[tb + r] = p;
+                const int kp = qm_code(p, fa.iwl, fa.frac);
+                if (kp) {
+                    const uint32_t i = atomicAdd(&misc[0], 1u);
+                    if (i < (uint32_t)kLiveCap) { live_row[i] = r; live_kp[i] = (uint8_t)kp; }
+                }
+            }
+            __syncthreads();
+            n_live = misc[0];
+            if (n_live > (uint32_t)kLiveCap) {                  // keep the overflow path exact: park Q(p) in sc
+                for (uint32_t r = tid; r < S; r += kBlock) {
+                    const float x = (float)(sc[r] - mx) * scale;
+                    const float p = (a.softmax_base == QMANN_SOFTMAX_EXP) ? (float)((double)expf(x) / total)
+                                                                          : exp2f(x) / (float)total;
+                    sc[r] = qm_code(p, fa.iwl, fa.frac);
+                }
+                __syncthreads();
+            }
+        }
+        auto kp_of_row = [&](uint32_t r) { return (int)sc[r]; };
+        finish_hop<DP>(a, q, h, r0, S, n_live, live_row, live_kp, kp_of_row, ku, u_f, o_f, tid);
+    }
+    if (tid < D) a.u_out[(size_t)q * D + tid] = u_f[tid];
+}
+
+// sign-magnitude bytes [rows][Dp] -> bit-planes [rows][Dp/64][nb]: one wavefront per (row, group)
+__global__ void __launch_bounds__(kBlock)
+k_pack_planes(const uint8_t *__restrict__ sm, uint64_t *__restrict__ planes, size_t rows, uint32_t Dp, uint32_t nb)
+{
+    const size_t w = ((size_t)blockIdx.x * kBlock + threadIdx.x) / kWave;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t groups = Dp / 64;
+    if (w >= rows * groups) return;
+    const size_t r = w / groups;
+    const uint32_t g = (uint32_t)(w % groups);
+    const uint32_t b = sm[r * Dp + 64 * g + lane];
+    for (uint32_t i = 0; i < nb; i++) {
+        const uint64_t word = __ballot((b >> (7 - i)) & 1u);
+        if (lane == 0) planes[(r * groups + g) * nb + i] = word;
+    }
+}
+
+inline bool fmt8(qmann_fmt f) { return f.iwl + f.frac >= 1 && f.iwl + f.frac <= 7; }
+
+// u (in format `src`) must be exactly representable on the attention grid Q(iwl.7-iwl) without
+// saturation -- otherwise its 8-bit code is not the reference's 32-bit word and the byte form
+// of the Hamming arithmetic would not be exact
+inline bool grid_within(qmann_fmt src, qmann_fmt att) { return src.iwl <= att.iwl && src.frac <= att.frac; }
+
+int fill_args(HopArgs &a, const qmann_net *net, const void *keys, const int8_t *vals, size_t key_hop_stride,
+              size_t val_hop_stride, const uint32_t *row_off, const float *u0, float *u_out, const qmann_taps *taps)
+{
+    if (!net || !keys || !vals || !row_off || !u0 || !u_out) return QMANN_EINVAL;
+    if (net->n_hop == 0 || net->n_hop > QMANN_MAX_HOP) return QMANN_EINVAL;
+    if (net->dim_emb == 0 || net->dim_emb > net->dim_emb_pad) return QMANN_EINVAL;
+    if (net->dim_emb_pad != 64 && net->dim_emb_pad != 128 && net->dim_emb_pad != 256) return QMANN_EUNSUPPORTED;
+    if (net->softmax_base > QMANN_SOFTMAX_POW2) return QMANN_EINVAL;
+    if (!fmt8(net->bin)) return QMANN_ERANGE;
+    for (uint32_t h = 0; h < net->n_hop; h++) {
+        if (!fmt8(net->act[h]) || !fmt8(net->w[h]) || !fmt8(net->att[h])) return QMANN_ERANGE;
+        if (net->att[h].iwl + net->att[h].frac != 7 || net->att[h].iwl < 1) return QMANN_EUNSUPPORTED;
+        if (net->en_lin_map && !net->lin_map[h]) return QMANN_EINVAL;
+        // u entering hop h comes from emb_q (format w[0]) or from sv[h-1] (format act[h-1])
+        const qmann_fmt src = h == 0 ? net->w[0] : net->act[h - 1];
+        if (!grid_within(src, net->att[h])) return QMANN_EUNSUPPORTED;
+    }
+    a = HopArgs{};
+    a.keys = (const int8_t *)keys; a.vals = vals; a.row_off = row_off;
+    a.hop_stride = val_hop_stride; a.key_hop_stride = key_hop_stride;
+    a.u0 = u0; a.u_out = u_out;
+    if (taps) {
+        a.tap_codes = taps->score_codes; a.tap_scores = taps->scores; a.tap_probs = taps->probs;
+        a.tap_o = taps->o; a.tap_u = taps->u;
+    }
+    a.rows_total = (uint32_t)(val_hop_stride / net->dim_emb_pad);
+    a.n_hop = net->n_hop; a.D = net->dim_emb; a.Dp = net->dim_emb_pad;
+    a.softmax_base = net->softmax_base; a.en_lin_map = net->en_lin_map;
+    for (uint32_t h = 0; h < net->n_hop; h++) {
+        a.lin_map[h] = net->lin_map[h];
+        a.act[h] = QFmt{net->act[h].iwl, net->act[h].frac};
+        a.w[h] = QFmt{net->w[h].iwl, net->w[h].frac};
+        a.att[h] = QFmt{net->att[h].iwl, net->att[h].frac};
+    }
+    a.bin = QFmt{net->bin.iwl, net->bin.frac};
+    return QMANN_OK;
+}
+
+template <int LPRK, int DP, int MODE, int NB>
+void launch(const HopArgs &a, uint32_t key_row_bytes, size_t lds, uint32_t n_query, hipStream_t st)
+{
+    static size_t attr_bytes = 0;
+    if (lds > attr_bytes) {
+        QM_HIP(hipFuncSetAttribute((const void *)k_hops_ham<LPRK, DP, MODE, NB>,
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_bytes = lds;
+    }
+    k_hops_ham<LPRK, DP, MODE, NB><<<n_query, kBlock, lds, st>>>(a, key_row_bytes);
+}
+
+size_t ham_lds_bytes(uint32_t max_slots) { return (size_t)kOffScores + (((size_t)max_slots * 4 + 15) & ~(size_t)15); }
+
+}  // namespace
+
+extern "C" {
+
+int qmann_pack_bitplanes(const int8_t *sm_codes, uint64_t *planes, size_t rows, uint32_t dim_emb_pad,
+                         uint32_t num_bit, void *stream)
+{
+    if (!sm_codes || !planes) return QMANN_EINVAL;
+    if (dim_emb_pad % 64 != 0 || num_bit < 1 || num_bit > 8) return QMANN_EINVAL;
+    const size_t waves = rows * (dim_emb_pad / 64);
+    if (waves == 0) return QMANN_OK;
+    k_pack_planes<<<(unsigned)((waves * kWave + kBlock - 1) / kBlock), kBlock, 0, (hipStream_t)stream>>>(
+        (const uint8_t *)sm_codes, planes, rows, dim_emb_pad, num_bit);
+    QM_LAUNCH_CHECK();
+    return QMANN_OK;
+}
+
+// APPX on sign-magnitude int8 keys (called from qmann_hops_i8)
+int qmann_hops_appx_impl(const qmann_net *net, const int8_t *keys, const int8_t *vals, size_t hop_stride,
+                         const uint32_t *row_off, uint32_t max_slots, const float *u0, float *u_out,
+                         const qmann_taps *taps, uint32_t n_query, void *stream)
+{
+    HopArgs a;
+    const int rc = fill_args(a, net, keys, vals, hop_stride, hop_stride, row_off, u0, u_out, taps);
+    if (rc) return rc;
+    const size_t lds = ham_lds_bytes(max_slots);
+    if (lds > 160 * 1024 - 1024) return QMANN_ERANGE;
+    if (n_query == 0) return QMANN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (net->dim_emb_pad == 64) launch<4, 64, kModeAppx, 8>(a, 64, lds, n_query, st);
+    else if (net->dim_emb_pad == 128) launch<8, 128, kModeAppx, 8>(a, 128, lds, n_query, st);
+    else launch<16, 256, kModeAppx, 8>(a, 256, lds, n_query, st);
+    QM_LAUNCH_CHECK();
+    return QMANN_OK;
+}
+
+int qmann_hops_packed(const qmann_net *net, const uint64_t *key_planes, size_t key_hop_stride, const int8_t *vals,
+                      size_t val_hop_stride, const uint32_t *row_off, uint32_t max_slots, const float *u0,
+                      float *u_out, const qmann_taps *taps, uint32_t n_query, void *stream)
+{
+    if (!net) return QMANN_EINVAL;
+    if (net->attention_mode != QMANN_ATT_HAMMING_V0 && net->attention_mode != QMANN_ATT_HAMMING_V1)
+        return QMANN_EUNSUPPORTED;
+    const uint32_t nb = net->num_bit, Dp = net->dim_emb_pad;
+    if (nb != 1 && nb != 2 && nb != 4 && nb != 8) return QMANN_EUNSUPPORTED;
+    if (key_hop_stride != val_hop_stride / Dp * (Dp / 64) * nb * 8) return QMANN_EINVAL;
+    HopArgs a;
+    const int rc = fill_args(a, net, key_planes, vals, key_hop_stride, val_hop_stride, row_off, u0, u_out, taps);
+    if (rc) return rc;
+    const size_t lds = ham_lds_bytes(max_slots);
+    if (lds > 160 * 1024 - 1024) return QMANN_ERANGE;
+    const uint32_t row_bytes = Dp / 64 * nb * 8;
+    if (row_bytes < 16) return QMANN_EUNSUPPORTED;      // Dp = 64 with a single plane
+    if (n_query == 0) return QMANN_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const bool v1 = net->attention_mode == QMANN_ATT_HAMMING_V1;
+#define QM_HAM(DP, NB)                                                                                   \
+    do {                                                                                                 \
+        constexpr int LPRK = (DP / 64) * NB * 8 / 16;                                                    \
+        if (v1) launch<LPRK, DP, kModeV1, NB>(a, row_bytes, lds, n_query, st);                           \
+        else launch<LPRK, DP, kModeV0, NB>(a, row_bytes, lds, n_query, st);                              \
+    } while (0)
+    if (Dp == 64) { if (nb == 2) QM_HAM(64, 2); else if (nb == 4) QM_HAM(64, 4); else QM_HAM(64, 8); }
+    else if (Dp == 128) { if (nb == 1) QM_HAM(128, 1); else if (nb == 2) QM_HAM(128, 2); else if (nb == 4) QM_HAM(128, 4); else QM_HAM(128, 8); }
+    else { if (nb == 1) QM_HAM(256, 1); else if (nb == 2) QM_HAM(256, 2); else if (nb == 4) QM_HAM(256, 4); else QM_HAM(256, 8); }
+#undef QM_HAM
+    QM_LAUNCH_CHECK();
+    return QMANN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,287 @@
+// hops_common.h -- pieces shared by the fused hop kernels (batch_hops.hip: fixed-point dot
+// attention; batch_hops_ham.hip: Hamming-family attention): the streaming row scan, the LDS
+// carve-up, block reductions, and the stages after the softmax (sparse exact read-out, linear
+// map, hop update).
+#pragma once
+#include "qfmt.h"
+#include "rt.h"
+#include "../../include/qmann_batch.h"
+
+namespace {
+
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / kWave;
+constexpr int kUnrollDefault = 4;  // 16-byte loads per lane and tile in the key scan (two tiles in flight)
+constexpr int kLiveCap = 256;     // surviving rows kept in LDS (at most 2^frac <= 128 can exist)
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// LDS carve-up (bytes); one dynamic allocation, 16-byte aligned pieces
+constexpr uint32_t kOffHist = 0;                                   // u32 [4][256]
+constexpr uint32_t kOffPtab = kOffHist + kWaves * 256 * 4;         // float [256]  p per score code
+constexpr uint32_t kOffU = kOffPtab + 256 * 4;                     // float [256]  current u
+constexpr uint32_t kOffO = kOffU + 256 * 4;                        // float [256]  read-out o
+constexpr uint32_t kOffKu = kOffO + 256 * 4;                       // s16   [256]  Q_bin(u) codes
+constexpr uint32_t kOffKp = kOffKu + 256 * 2;                      // u8    [256]  Q(p) per score code
+constexpr uint32_t kOffLiveRow = kOffKp + 256;                     // u32   [kLiveCap]
+constexpr uint32_t kOffLiveKp = kOffLiveRow + kLiveCap * 4;        // u8    [kLiveCap]
+constexpr uint32_t kOffMisc = kOffLiveKp + kLiveCap;               // u32   [16]
+constexpr uint32_t kOffRed = kOffMisc + 64;                        // double[8]
+constexpr uint32_t kOffScores = kOffRed + 64;                      // i8    [slots]
+static_assert(kOffScores % 16 == 0, "score bytes must start 16-byte aligned");
+
+struct HopArgs {
+    const int8_t *keys;
+    const int8_t *vals;
+    size_t hop_stride;       // bytes between hop planes of the value memory (and of int8 keys)
+    size_t key_hop_stride;   // bytes between hop planes of the key memory (packed-code modes)
+    const uint32_t *row_off;
+    const float *u0;
+    float *u_out;
+    int32_t *tap_codes;
+    float *tap_scores;
+    float *tap_probs;
+    float *tap_o;
+    float *tap_u;
+    const int8_t *lin_map[QMANN_MAX_HOP];
+    uint32_t rows_total;
+    uint32_t n_hop, D, Dp, softmax_base, en_lin_map;
+    QFmt act[QMANN_MAX_HOP], w[QMANN_MAX_HOP], att[QMANN_MAX_HOP], bin;
+};
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_add(int v)
+{
+    return v + __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+
+// sum over the LPR adjacent lanes that share a row (every lane ends with the total)
+template <int LPR>
+__device__ __forceinline__ int row_lanes_sum(int v)
+{
+    if (LPR >= 2) v = dpp_add<0xB1>(v);          // quad_perm [1,0,3,2]
+    if (LPR >= 4) v = dpp_add<0x4E>(v);          // quad_perm [2,3,0,1]
+    if (LPR >= 8) v = dpp_add<0x141>(v);         // row_half_mirror
+    if (LPR >= 16) v = dpp_add<0x140>(v);        // row_mirror
+    return v;
+}
+
+// packed u16 x u16 -> u16 multiply that saturates at 0xFFFF
+__device__ __forceinline__ uint32_t pk_mul_sat_u16(uint32_t a, uint32_t b)
+{
+    uint32_t d;
+    asm("v_pk_mad_u16 %0, %1, %2, 0 clamp" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
+// Per-lane constants of the key scan for the 16 columns a lane owns (4 dwords of 4 columns).
+// Keys are sign-magnitude bytes.  With M = 2^wl - 1 the largest code of the attention format and
+// f = frac of the query format, the reference's per-product term is
+//     sgn(k) sgn(u) . min( floor(|k| |u| / 2^f), M )          (lib/layer_cuda.cu:120)
+// Pre-shifting |u| left by s = 16 - wl - f turns the floor into a plain logical shift and makes
+// the clamp coincide with 16-bit unsigned saturation:
+//     min(floor(|k||u| / 2^f), M) == sat_u16(|k| . (|u| << s)) >> (16 - wl)
+// (the product reaches 2^16 exactly when floor(.) reaches M + 1).
+struct ScanConst {
+    uint32_t ue[4];   // (|u| << s) for columns 4d+0 (low half) and 4d+2 (high half), saturated to 0xFFFF
+    uint32_t uo[4];   // columns 4d+1 and 4d+3
+    uint32_t s7[4];   // 0x80 in byte i where u[4d+i] < 0
+};
+
+// sum over this lane's 16 columns of Qm(Qm(k) . Qv(u)), in units of 2^-frac_m
+__device__ __forceinline__ int lane_row_sum(const i32x4 x, const ScanConst &c, uint32_t sh)
+{
+    int acc = 0;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const uint32_t w = (uint32_t)x[d];
+        const uint32_t ev = w & 0x007F007Fu;                    // |k| of bytes 0 and 2
+        const uint32_t od = (w >> 8) & 0x007F007Fu;             // |k| of bytes 1 and 3
+        const u16x2 te = __builtin_bit_cast(u16x2, pk_mul_sat_u16(ev, c.ue[d])) >> (unsigned short)sh;
+        const u16x2 to = __builtin_bit_cast(u16x2, pk_mul_sat_u16(od, c.uo[d])) >> (unsigned short)sh;
+        const uint32_t tb = __builtin_bit_cast(uint32_t, te) | (__builtin_bit_cast(uint32_t, to) << 8);
+        const uint32_t sb = (w ^ c.s7[d]) & 0x80808080u;        // sign of each product
+        // bytes +1 / -1: v_perm_b32 yields 0xFF for a selector byte >= 13 (0x80 here) and source
+        // byte 0 (= 0x01) for selector 0
+        const uint32_t sg = __builtin_amdgcn_perm(0x01010101u, 0x01010101u, sb);
+        acc = __builtin_amdgcn_sdot4((int)tb, (int)sg, acc, false);
+    }
+    return acc;
+}
+
+template <bool NT>
+__device__ __forceinline__ i32x4 load16(const uint8_t *p)
+{
+    if (NT) return __builtin_nontemporal_load((const i32x4 *)p);
+    return *(const i32x4 *)p;
+}
+
+// Memories shorter than one tile (bAbI-sized stories): one guarded pass, rows spread over the
+// four wavefronts.  Not a bandwidth path.
+template <int LPR, typename RowSum, typename Retire>
+__device__ __forceinline__ void scan_rows_short(const uint8_t *__restrict__ kb, uint32_t S, RowSum row_sum,
+                                                Retire retire, uint32_t lane, uint32_t wave)
+{
+    constexpr uint32_t RPW = kWave / LPR;
+    constexpr uint32_t Dp = LPR * 16;
+    const uint32_t sub = lane / LPR, chunk = lane % LPR;
+    for (uint32_t base = wave * RPW; base < S; base += kWaves * RPW) {
+        const uint32_t r = base + sub;
+        i32x4 x = {0, 0, 0, 0};
+        if (r < S) x = *(const i32x4 *)(kb + (size_t)r * Dp + chunk * 16);
+        const int v = row_lanes_sum<LPR>(row_sum(x));
+        if (chunk == 0 && r < S) retire(r, v);
+    }
+}
+
+// One wavefront streams tiles of UN x (64 / LPR) rows; loads of the next tile are issued before
+// the current one is reduced (addresses are clamped to the last row instead of being predicated,
+// so the loop body has no divergent control flow and the compiler can count its vmcnt waits).
+template <int LPR, int UN, bool NT, typename RowSum, typename Retire>
+__device__ __forceinline__ void scan_rows(const uint8_t *__restrict__ kb, uint32_t S, RowSum row_sum, Retire retire,
+                                          uint32_t lane, uint32_t wave)
+{
+    constexpr uint32_t RPW = kWave / LPR;          // rows per wavefront instruction
+    constexpr uint32_t TILE = RPW * UN;            // rows per wavefront iteration
+    constexpr uint32_t Dp = LPR * 16;
+    const uint32_t sub = lane / LPR, chunk = lane % LPR;
+    const uint32_t n_tiles = (S + TILE - 1) / TILE;
+    const uint8_t *lane_base = kb + chunk * 16;
+
+    // A tile that would run past the last row is moved back to end exactly at row S (the rows it
+    // then repeats are skipped when retiring), so every load is in range with no per-row clamping
+    // and one tile needs a single address plus immediate offsets.  Needs S >= TILE.
+    auto tile_start = [&](uint32_t base) { return base + TILE <= S ? base : S - TILE; };
+    auto issue = [&](i32x4 (&x)[UN], uint32_t base) {
+        const uint8_t *p = lane_base + (size_t)(tile_start(base) + sub) * Dp;
+#pragma unroll
+        for (int j = 0; j < UN; j++) x[j] = load16<NT>(p + (size_t)j * RPW * Dp);
+    };
+    auto reduce = [&](const i32x4 (&x)[UN], uint32_t base) {
+        int s[UN];
+#pragma unroll
+        for (int j = 0; j < UN; j++) s[j] = row_lanes_sum<LPR>(row_sum(x[j]));
+        // after the butterfly every lane of a row group holds that row's sum: lane (sub, chunk)
+        // retires row j = chunk (+ LPR, ...) so that all 64 lanes store at once
+        const uint32_t start = tile_start(base);
+#pragma unroll
+        for (int j0 = 0; j0 < UN; j0 += LPR) {
+            int v = s[j0];
+#pragma unroll
+            for (int t = 1; t < LPR && j0 + t < UN; t++) v = (chunk == (uint32_t)t) ? s[j0 + t] : v;
+            const uint32_t j = j0 + chunk;
+            const uint32_t r = start + j * RPW + sub;
+            if (j < (uint32_t)UN && r >= base) retire(r, v);
+        }
+    };
+
+    if (wave >= n_tiles) return;
+    i32x4 xa[UN], xb[UN];
+    uint32_t base = wave * TILE;
+    constexpr uint32_t STEP = kWaves * TILE;
+    issue(xa, base);
+    for (uint32_t t = wave; t < n_tiles; t += 2 * kWaves) {
+        issue(xb, base + STEP);
+        reduce(xa, base);
+        if (t + kWaves >= n_tiles) break;
+        issue(xa, base + 2 * STEP);
+        reduce(xb, base + STEP);
+        base += 2 * STEP;
+    }
+}
+
+// sign-magnitude byte -> integer code
+__device__ __forceinline__ int sm_decode(uint8_t b)
+{
+    const int m = b & 0x7F;
+    return (b & 0x80) ? -m : m;
+}
+
+__device__ __forceinline__ int block_max_int(int v, int *scratch, uint32_t lane, uint32_t wave)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int t = __shfl_xor(v, o);
+        v = t > v ? t : v;
+    }
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    int r = scratch[0];
+    for (int i = 1; i < kWaves; i++) r = scratch[i] > r ? scratch[i] : r;
+    __syncthreads();
+    return r;
+}
+
+__device__ __forceinline__ double block_sum_double(double v, double *scratch, uint32_t lane, uint32_t wave)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    const double r = (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+    __syncthreads();
+    return r;
+}
+
+
+// Stages after the softmax, shared by every attention mode:
+//   read-out  o[c] = Qa( sum_r Qa( Qa(p[r]) . Qa(C[r][c]) ) )   (lib/layer_cuda.cu:547-635 via :2430/:2512)
+//             over the rows whose weight code Q(p) is non-zero (the others contribute exact zeros),
+//   lin_map   lu = Qw( sum_i Qw( Qw(H[o][i]) . Qbin(u[i]) ) )     (lib/layer_cuda.cu:49-83 via :3184)
+//   update    u' = Qa( Qa(lu) + Qa(o) )                          (lib/layer_cuda.cu:1535-1542)
+// `ku` holds Q_bin(u) codes, `kp_of_row` gives the weight code of a row (used only if the
+// survivor list overflowed).  Ends with a barrier; u_f holds u' afterwards.
+template <uint32_t Dp, typename KpOfRow>
+__device__ __forceinline__ void finish_hop(const HopArgs &a, uint32_t q, uint32_t h, uint32_t r0, uint32_t S,
+                                           uint32_t n_live, const uint32_t *live_row, const uint8_t *live_kp,
+                                           KpOfRow kp_of_row, const short *ku, float *u_f, float *o_f, uint32_t tid)
+{
+    const QFmt fa = a.act[h], fw = a.w[h], fb = a.bin;
+    const int maxa = (1 << (fa.iwl + fa.frac)) - 1;
+    const int maxw = (1 << (fw.iwl + fw.frac)) - 1;
+    const uint32_t D = a.D;
+    if (tid < Dp) {
+        const uint8_t *vb = (const uint8_t *)a.vals + (size_t)h * a.hop_stride + (size_t)r0 * Dp + tid;
+        int acc = 0;
+        if (n_live <= (uint32_t)kLiveCap) {
+            for (uint32_t i = 0; i < n_live; i++)
+                acc += qm_mul_code((int)live_kp[i], sm_decode(vb[(size_t)live_row[i] * Dp]), fa.frac, maxa);
+        } else {                                   // cannot happen for p summing to 1; kept exact anyway
+            for (uint32_t r = 0; r < S; r++) {
+                const int kp = kp_of_row(r);
+                if (kp) acc += qm_mul_code(kp, sm_decode(vb[(size_t)r * Dp]), fa.frac, maxa);
+            }
+        }
+        acc = acc > maxa ? maxa : (acc < -maxa ? -maxa : acc);
+        o_f[tid] = (float)acc / (float)(1 << fa.frac);
+    }
+    __syncthreads();
+    if (tid < D) {
+        float lu = u_f[tid];
+        if (a.en_lin_map) {
+            const int8_t *hr = a.lin_map[h] + (size_t)tid * Dp;
+            int acc = 0;
+            for (uint32_t i = 0; i < Dp; i += 16) {
+                const i32x4 wv = *(const i32x4 *)(hr + i);
+#pragma unroll
+                for (int b = 0; b < 16; b++) {
+                    const int kh = (int)(int8_t)((uint32_t)wv[b >> 2] >> (8 * (b & 3)));
+                    acc += qm_mul_code(kh, (int)ku[i + b], fb.frac, maxw);
+                }
+            }
+            acc = acc > maxw ? maxw : (acc < -maxw ? -maxw : acc);
+            lu = (float)acc / (float)(1 << fw.frac);
+        }
+        const float o = o_f[tid];
+        const float un = qm_quant(qm_quant(lu, fa.iwl, fa.frac) + qm_quant(o, fa.iwl, fa.frac), fa.iwl, fa.frac);
+        if (a.tap_o) a.tap_o[((size_t)q * a.n_hop + h) * D + tid] = o;
+        if (a.tap_u) a.tap_u[((size_t)q * a.n_hop + h) * D + tid] = un;
+        u_f[tid] = un;
+    }
+    __syncthreads();
+}
+
+}  // namespace

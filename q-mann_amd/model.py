@@ -154,6 +154,37 @@ class QNet:
                                         self._s()), "qmann_hops_i8")
         return (u_out, tobj) if taps else u_out
 
+    def pack_planes(self, sm_codes: torch.Tensor, num_bit: int) -> torch.Tensor:
+        """sign-magnitude int8 [..., rows, Dp] -> packed bit planes int64 [..., rows, Dp/64, num_bit]."""
+        assert sm_codes.dtype == torch.int8 and sm_codes.is_contiguous() and sm_codes.shape[-1] == self.Dp
+        rows = sm_codes.numel() // self.Dp
+        out = torch.empty((*sm_codes.shape[:-1], self.Dp // 64, num_bit), dtype=torch.int64, device=sm_codes.device)
+        abi.check(abi.lib.qmann_pack_bitplanes(_ptr(sm_codes), _ptr(out), rows, self.Dp, num_bit, self._s()),
+                  "qmann_pack_bitplanes")
+        return out
+
+    def hops_packed(self, key_planes, vals, row_off, max_slots, u0, taps=False):
+        """Hamming V0 / V1 attention: key_planes int64 [H][rows][Dp/64][num_bit], vals int8 [H][rows][Dp]."""
+        B = u0.shape[0]
+        rows = vals.shape[1]
+        nb = key_planes.shape[-1]
+        u_out = torch.empty_like(u0)
+        tp, tobj = None, None
+        if taps:
+            tobj = HopTaps(
+                torch.zeros((self.H, rows), dtype=torch.int32, device=self.dev),
+                torch.zeros((self.H, rows), dtype=torch.float32, device=self.dev),
+                torch.zeros((self.H, rows), dtype=torch.float32, device=self.dev),
+                torch.zeros((B, self.H, self.D), dtype=torch.float32, device=self.dev),
+                torch.zeros((B, self.H, self.D), dtype=torch.float32, device=self.dev))
+            tp = abi.Taps(tobj.score_codes.data_ptr(), tobj.scores.data_ptr(), tobj.probs.data_ptr(),
+                          tobj.o.data_ptr(), tobj.u.data_ptr())
+        abi.check(abi.lib.qmann_hops_packed(C.byref(self.net), _ptr(key_planes), rows * (self.Dp // 64) * nb * 8,
+                                            _ptr(vals), rows * self.Dp, _ptr(row_off), max_slots, _ptr(u0),
+                                            _ptr(u_out), C.byref(tp) if tp else None, B, self._s()),
+                  "qmann_hops_packed")
+        return (u_out, tobj) if taps else u_out
+
     def answer(self, u, answer=None, want_probs=False):
         B = u.shape[0]
         pred = torch.empty(B, dtype=torch.int32, device=self.dev)

@@ -202,3 +202,86 @@ def test_babi_end_to_end_from_bag_of_words(env, oracle, gold):
             assert int(out["match"].cpu()) == int((g_pred == ans).sum())
             want_cost = -float(g_probs[np.arange(n_take), ans].astype(np.float64).sum())
             assert float(out["cost"].cpu()) == pytest.approx(want_cost, rel=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------
+# Hamming family
+# ---------------------------------------------------------------------------------------------
+def run_hamming_case(env, oracle, mode, D, S_list, B, seed, iwl=5, num_bit=8, sigma=40.0):
+    """mode 3 (CUDA approximate attention, int8 keys) or 10 / 11 (packed bit planes + popcount)."""
+    torch, model = env.torch, env.model
+    H, V = 3, 40
+    frac = 7 - iwl
+    fmt = [(iwl, frac)] * H
+    cfg = dict(n_hop=H, dim_emb=D, dim_input=V, attention_mode=mode, softmax_variant=0, f_fixed=True,
+               en_lin_map=True, fmt=fmt, fmt_w=list(fmt), fmt_att=list(fmt), fmt_bin=(iwl, frac), num_bit=num_bit)
+    rng = np.random.default_rng(seed)
+    wts = weights(seed, H, D, V, 1.0, with_emb=False)
+    net = model.QNet(cfg, wts, device="cuda:0")
+    Dp = net.Dp
+    n_slots = np.array([S_list[i % len(S_list)] for i in range(B)], np.int64)
+    row_off = np.concatenate([[0], np.cumsum(n_slots)]).astype(np.int32)
+    R = int(row_off[-1])
+    keys = np.zeros((H, R, Dp), np.int8); vals = np.zeros((H, R, Dp), np.int8)
+    keys[:, :, :D] = np.clip(np.rint(rng.normal(0, sigma, (H, R, D))), -127, 127)
+    vals[:, :, :D] = np.clip(np.rint(rng.normal(0, sigma, (H, R, D))), -127, 127)
+    # exercise magnitude ties, zeros and full-scale values (carry out of 7 bits in the opposite-sign sum)
+    keys[:, ::3, : D // 2] = np.clip(keys[:, ::3, : D // 2].astype(np.int16) * 3, -127, 127)
+    keys[:, 1::5, ::4] = 0
+    u0 = (np.clip(np.rint(rng.normal(0, sigma, (B, D))), -127, 127) / (1 << frac)).astype(np.float32)
+    u0[:, ::7] = np.float32(127.0 / (1 << frac)) * np.sign(u0[:, ::7] + 0.1)
+    dk = torch.from_numpy(model.to_signmag(keys)).to(env.dev)
+    dv = torch.from_numpy(model.to_signmag(vals)).to(env.dev)
+    dro = torch.from_numpy(row_off).to(env.dev); du0 = torch.from_numpy(u0).to(env.dev)
+    if mode == 3:
+        u_out, taps = net.hops(dk, dv, dro, int(n_slots.max()), du0, taps=True)
+        unit = 1.0 / 1024.0
+    else:
+        planes = net.pack_planes(dk, num_bit)
+        u_out, taps = net.hops_packed(planes, dv, dro, int(n_slots.max()), du0, taps=True)
+        unit = 1.0 if mode == 10 else 1.0 / (1 << num_bit)
+    torch.cuda.synchronize()
+    g_codes = taps.score_codes.cpu().numpy(); g_scores = taps.scores.cpu().numpy()
+    g_probs = taps.probs.cpu().numpy(); g_u = taps.u.cpu().numpy(); g_o = taps.o.cpu().numpy()
+    m = oracle.make_model(cfg, wts)
+    excused = 0
+    for q in range(B):
+        a, b = int(row_off[q]), int(row_off[q + 1])
+        kf = np.stack([keys[h, a:b, :D].astype(np.float32) / (1 << frac) for h in range(H)])
+        vf = np.stack([vals[h, a:b, :D].astype(np.float32) / (1 << frac) for h in range(H)])
+        _, t = oracle.forward_mem(m, kf, vf, u0[q])
+        ok = True
+        for h in range(H):
+            if not ok:
+                break
+            # bit-exact Hamming scores: integers in units of `unit`
+            np.testing.assert_array_equal(g_scores[h, a:b], t["scores"][h], err_msg=f"scores q{q} h{h} mode {mode}")
+            np.testing.assert_array_equal(g_codes[h, a:b], np.rint(t["scores"][h] / unit).astype(np.int32))
+            np.testing.assert_allclose(g_probs[h, a:b], t["probs"][h], rtol=1e-5, atol=1e-7)
+            if not (np.array_equal(g_o[q, h], t["o"][h]) and np.array_equal(g_u[q, h], t["u"][h])):
+                assert near_step(t["probs"][h], frac).any(), f"o/u differ q{q} h{h}"
+                ok = False
+        excused += not ok
+    assert excused <= max(1, B // 8)
+
+
+@pytest.mark.parametrize("D", [60, 128, 256])
+def test_hops_appx_cuda_hamming_bit_exact(env, oracle, D):
+    run_hamming_case(env, oracle, 3, D, [1, 5, 10, 33, 50, 64, 200], B=14, seed=21 + D)
+
+
+def test_hops_appx_other_iwl_and_full_size(env, oracle):
+    run_hamming_case(env, oracle, 3, 128, [10, 50], B=6, seed=5, iwl=2)
+    run_hamming_case(env, oracle, 3, 128, [10000, 4097], B=3, seed=6, sigma=25.0)
+
+
+@pytest.mark.parametrize("mode", [10, 11])
+@pytest.mark.parametrize("D,num_bit", [(60, 8), (64, 2), (128, 8), (128, 4), (128, 1), (200, 8), (256, 8), (256, 2), (256, 1)])
+def test_hops_packed_popcount_bit_exact(env, oracle, mode, D, num_bit):
+    run_hamming_case(env, oracle, mode, D, [1, 7, 50, 64, 129, 300], B=12, seed=31 + D + num_bit, num_bit=num_bit)
+
+
+def test_hops_packed_full_size_d256(env, oracle):
+    """BASELINE config 5 shape: |memory| = 10 000, D = 256, binary-code Hamming attention."""
+    run_hamming_case(env, oracle, 10, 256, [10000], B=2, seed=41, num_bit=1)
+    run_hamming_case(env, oracle, 11, 256, [10000, 5000], B=2, seed=42, num_bit=8)
