@@ -47,11 +47,15 @@ def load_pkg():
 
 
 WORKLOADS = {
-    # name: (slots, D, V, queries per GPU, sigma of key/query codes, sigma of value codes)
-    "synth10k_d128": dict(S=10000, D=128, V=256, B=8192, sk=3.5, sv=30.0, su=3.5),
-    "synth10k_d256": dict(S=10000, D=256, V=256, B=4096, sk=2.5, sv=30.0, su=2.5),
-    "babi_mem50": dict(S=50, D=60, V=80, B=262144, sk=8.0, sv=30.0, su=8.0),
+    # S slots, D, V, B queries per GPU, attention mode (define.h:10-15; 10 = packed popcount V0), planes,
+    # answer layer ("f32" | "i8" = int8 MFMA), sigma of key/query codes and of value codes
+    "synth10k_d128": dict(S=10000, D=128, V=256, B=8192, mode=2, nb=8, ans="f32", sk=3.5, sv=30.0, su=3.5),
+    "synth10k_d256_ham": dict(S=10000, D=256, V=256, B=8192, mode=10, nb=1, ans="i8", sk=30.0, sv=30.0, su=30.0),
+    "synth10k_d128_appx": dict(S=10000, D=128, V=256, B=8192, mode=3, nb=8, ans="f32", sk=30.0, sv=30.0, su=30.0),
+    "babi_mem50": dict(S=50, D=60, V=80, B=262144, mode=2, nb=8, ans="f32", sk=8.0, sv=30.0, su=8.0),
+    "babi_joint_appx": dict(S=50, D=60, V=256, B=262144, mode=3, nb=8, ans="f32", sk=30.0, sv=30.0, su=30.0),
 }
+KERNEL_OF_MODE = {2: "k_hops_fixed", 3: "k_hops_ham", 10: "k_hops_ham", 11: "k_hops_ham"}
 
 
 def gauss_i8(shape, sigma, gen, dev, pad_from=None):
@@ -127,35 +131,26 @@ def main():
     torch.cuda.set_device(dev)
 
     load_pkg()
+    import qmann_amd.abi as abi
     import qmann_amd.model as model
+    from qmann_amd.parallel import broadcast_params
 
     wl = WORKLOADS[args.workload]
-    S, D, V = wl["S"], wl["D"], wl["V"]
+    S, D, V, mode, nb = wl["S"], wl["D"], wl["V"], wl["mode"], wl["nb"]
     B = args.queries or wl["B"]
     H = 3
-    cfg = model.babi_cfg(V, attention_mode=2, softmax_base=0, iwl=5, n_hop=H, D=D, en_mq=False)
+    cfg = model.babi_cfg(V, attention_mode=mode, softmax_base=0, iwl=5, n_hop=H, D=D, en_mq=False)
+    cfg["num_bit"] = nb
 
     # parameters: created on rank 0, broadcast once over RCCL (xGMI) -- the only collective
-    wts = make_params(cfg, D, V, seed=0x51A44)
-    bcast_ms = None
-    if world > 1:
-        import torch.distributed as dist
-        blob = torch.from_numpy(np.concatenate([w.ravel() for w in wts["w_h"]] + [wts["w_ans"].ravel()])).to(dev)
-        if rank != 0:
-            blob.zero_()
-        torch.cuda.synchronize()
-        dist.barrier()
-        t0 = time.perf_counter()
-        dist.broadcast(blob, src=0)
-        torch.cuda.synchronize()
-        bcast_ms = (time.perf_counter() - t0) * 1e3
-        flat = blob.cpu().numpy()
-        o = 0
-        for h in range(H):
-            wts["w_h"][h] = flat[o:o + D * D].reshape(D, D).copy(); o += D * D
-        wts["w_ans"] = flat[o:o + V * D].reshape(V, D).copy()
+    wts = make_params(cfg, D, V, seed=0x51A44) if rank == 0 else None
+    wts, bcast_ms = broadcast_params(wts, cfg, dev, rank, world)
+    ans_fmt = (1, 6)
+    if wl["ans"] == "i8":                       # answer matrix on an int8 grid -> the MFMA projection is exact
+        wts["w_ans"] = (np.clip(np.rint(wts["w_ans"] * 64.0 * 4), -127, 127) / 64.0).astype(np.float32)
     net = model.QNet(cfg, wts, device=str(dev))
     Dp = net.Dp
+    w_ans_i8 = net.quantize_i8(net.w_ans, ans_fmt, abi.CODE_TWOS) if wl["ans"] == "i8" else None
 
     # synthetic per-query memories, resident in HBM before the timed region
     gen = torch.Generator(device=dev)
@@ -165,27 +160,38 @@ def main():
     u0 = (torch.randn((B, D), device=dev, generator=gen) * wl["su"]).round_().clamp_(-127, 127) / 4.0
     row_off = (torch.arange(B + 1, device=dev, dtype=torch.int64) * S).to(torch.int32)
     u_out = torch.empty_like(u0)
+    key_row_bytes = Dp
+    planes = None
+    if mode in (10, 11):
+        planes = net.pack_planes(keys, nb)      # packed binary codes: [H][rows][Dp/64][nb] uint64
+        key_row_bytes = Dp // 64 * nb * 8
     torch.cuda.synchronize()
 
-    def step():
-        net.hops(keys, vals, row_off, S, u0, u_out=u_out)
-        return net.answer(u_out)[0]
+    def run_hops():
+        if planes is not None:
+            return net.hops_packed(planes, vals, row_off, S, u0)
+        return net.hops(keys, vals, row_off, S, u0, u_out=u_out)
+
+    def run_answer(u):
+        if w_ans_i8 is not None:
+            return net.answer_i8(u, w_ans_i8, ans_fmt)[0]
+        return net.answer(u)[0]
 
     for _ in range(args.warmup):
-        step()
+        run_answer(run_hops())
     torch.cuda.synchronize()
     if world > 1:
-        import torch.distributed as dist
         dist.barrier()
     torch.cuda.synchronize()
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
         ev[i][0].record()
-        net.hops(keys, vals, row_off, S, u0, u_out=u_out)
+        u = run_hops()
         ev[i][1].record()
-        pred = net.answer(u_out)[0]
+        pred = run_answer(u)
+        ev[i][2].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -196,9 +202,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    hop_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))      # dominant kernel, HIP events
-    bytes_per_query = H * S * Dp                                      # key planes: the addressing scan
+    hop_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))    # dominant kernel, HIP events
+    ans_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+    bytes_per_query = H * S * key_row_bytes                           # key planes: the addressing scan
     achieved = bytes_per_query * B / (hop_ms * 1e-3) / 1e9
+    traffic = None
+    tj = ROOT / "profiles" / "traffic.json"
+    if tj.exists():
+        rec = json.loads(tj.read_text()).get(args.workload)
+        if rec and B == wl["B"]:
+            traffic = rec["traffic_bytes_per_launch"]
 
     out = {
         "metric": "queries/sec", "value": world * B * args.steps / elapsed, "unit": "queries/s",
@@ -206,11 +219,16 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int8", "data": "synthetic",
         "config": {"workload": args.workload, "slots": S, "dim_emb": D, "dim_emb_pad": Dp, "hops": H,
-                   "queries_per_gpu": B, "format": "Q5.2", "attention_mode": 2,
+                   "queries_per_gpu": B, "format": "Q5.2", "attention_mode": mode,
+                   "key_row_bytes": key_row_bytes, "answer_layer": wl["ans"], "dim_answer": V,
                    "parallelism": f"replicas x{world}, query-sharded"},
-        "roofline": {"bound": "hbm", "kernel": "k_hops_fixed", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "bytes_per_query": bytes_per_query, "kernel_ms": hop_ms},
+        "roofline": {"bound": "hbm", "kernel": KERNEL_OF_MODE[mode], "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": bytes_per_query * B, "bytes_per_query": bytes_per_query,
+                     "kernel_ms": hop_ms},
+        "answer_layer": {"ms": ans_ms, "int_ops": 2.0 * B * V * D,
+                         "tops": 2.0 * B * V * D / (ans_ms * 1e-3) / 1e12,
+                         "mfma_int8_peak_tops": 5000.0 if wl["ans"] == "i8" else None},
     }
     if bcast_ms is not None:
         out["param_broadcast_ms"] = bcast_ms

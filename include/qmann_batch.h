@@ -128,6 +128,14 @@ int qmann_answer_f32(const qmann_net *net, const float *w_ans, const float *u, c
                      uint32_t *pred, float *probs, float *cost, uint32_t *match, uint32_t n_query,
                      void *stream);
 
+/* The same answer layer when the answer matrix is on an int8 grid: w_ans_i8 [V][Dp] two's-complement
+ * codes of Q(w_fmt); the projection runs on the int8 matrix cores (v_mfma_i32_16x16x64_i8) and is
+ * bit-identical to the float path on the same grid values (exact integers below 2^24).
+ * logits_ws: caller-provided workspace, float [n_query][V]. */
+int qmann_answer_i8(const qmann_net *net, const int8_t *w_ans_i8, qmann_fmt w_fmt, const float *u,
+                    float *logits_ws, const uint32_t *answer, uint32_t *pred, float *probs, float *cost,
+                    uint32_t *match, uint32_t n_query, void *stream);
+
 /* Story / question embedding for a batch of bag-of-words inputs (dense_mat_fwd / dense_fwd,
  * lib/layer_cuda.cu:3511, :3162), writing the int8 memories directly.
  *   story [rows_total][V] float (word counts + time bit), w_a[h], w_c[h], w_q : [D][V] float. */

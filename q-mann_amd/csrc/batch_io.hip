@@ -19,6 +19,9 @@ constexpr int kWaves = kBlock / kWave;
 // float quotient (:2006-2042) or the CPU form 2^(x-max) with float arithmetic
 // (lib/layer.c:1225-1243).  Arg-max ties go to the highest index (:1918-1939).
 // ---------------------------------------------------------------------------
+// PRECOMPUTED: logits come from a buffer (written by the MFMA projection below) instead of being
+// computed here.
+template <bool PRECOMPUTED>
 __global__ void __launch_bounds__(kBlock)
 k_answer(const float *__restrict__ w_ans, const float *__restrict__ u, const uint32_t *__restrict__ answer,
          uint32_t *__restrict__ pred, float *__restrict__ probs, float *cost, uint32_t *match, uint32_t D,
@@ -32,16 +35,22 @@ k_answer(const float *__restrict__ w_ans, const float *__restrict__ u, const uin
     __shared__ uint32_t red_i[kWaves];
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     const uint32_t q = blockIdx.x;
-    for (uint32_t c = tid; c < D; c += kBlock) us[c] = u[(size_t)q * D + c];
-    __syncthreads();
+    if (!PRECOMPUTED) {
+        for (uint32_t c = tid; c < D; c += kBlock) us[c] = u[(size_t)q * D + c];
+        __syncthreads();
+    }
 
     float mx = -INFINITY;
     for (uint32_t v = tid; v < V; v += kBlock) {
-        const float *wr = w_ans + (size_t)v * D;
         float sum = 0.0f;
-        for (uint32_t c = 0; c < D; c++) {
-            const float t = wr[c] * us[c];
-            sum += t;
+        if (PRECOMPUTED) {
+            sum = w_ans[(size_t)q * V + v];          // w_ans aliases the logits buffer [n_query][V]
+        } else {
+            const float *wr = w_ans + (size_t)v * D;
+            for (uint32_t c = 0; c < D; c++) {
+                const float t = wr[c] * us[c];
+                sum += t;
+            }
         }
         lg[v] = sum;
         mx = sum > mx ? sum : mx;
@@ -97,6 +106,57 @@ k_answer(const float *__restrict__ w_ans, const float *__restrict__ u, const uin
                 if (match && y == bi) atomicAdd(match, 1u);
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Answer projection on the matrix cores, for an answer matrix that lives on an int8 grid:
+// logits[q][v] = sum_c U[q][c] . W[v][c] with both operands small integers (codes), so the
+// reference's float serial sum (lib/layer_cuda.cu:70-80) is an exact integer times
+// 2^-(frac_u + frac_w) (|sum| <= 256.127.127 < 2^24) and an int32 MFMA accumulation reproduces it
+// bit for bit.  One wavefront owns a 16 x 16 tile (16 queries x 16 answers) and issues
+// v_mfma_i32_16x16x64_i8 over the embedding axis; both fragments are plain 16-byte row segments
+// (lane l: row l & 15, bytes 16.(l >> 4) .. +15 of the 64-deep K step), so they are loaded straight
+// from global memory -- the query side is converted from the hop kernel's float-on-grid vector in
+// registers.  C/D: lane l holds column l & 15, rows 4.(l >> 4) + r.
+// ---------------------------------------------------------------------------
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(kBlock)
+k_logits_mfma_i8(const float *__restrict__ u, const int8_t *__restrict__ w, float *__restrict__ logits,
+                 uint32_t n_query, uint32_t D, uint32_t Dp, uint32_t V, QFmt fu, float scale)
+{
+    const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const uint32_t m0 = blockIdx.x * 16;
+    const uint32_t n0 = (blockIdx.y * kWaves + wave) * 16;
+    if (n0 >= V) return;                                     // whole wavefront
+    const uint32_t row = lane & 15, kq = lane >> 4;
+    const uint32_t qrow = m0 + row, vrow = n0 + row;
+    i32x4 acc = {0, 0, 0, 0};
+    for (uint32_t k0 = 0; k0 < Dp; k0 += 64) {
+        const uint32_t kb = k0 + 16 * kq;
+        i32x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+        if (qrow < n_query) {
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                uint32_t pk = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t c = kb + 4 * d + i;
+                    const int code = (c < D) ? qm_code(u[(size_t)qrow * D + c], fu.iwl, fu.frac) : 0;
+                    pk |= ((uint32_t)code & 0xFFu) << (8 * i);
+                }
+                a[d] = (int)pk;
+            }
+        }
+        if (vrow < V) b = *(const i32x4 *)(w + (size_t)vrow * Dp + kb);
+        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc, 0, 0, 0);
+    }
+    const uint32_t col = n0 + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const uint32_t qr = m0 + 4 * (lane >> 4) + r;
+        if (qr < n_query && col < V) logits[(size_t)qr * V + col] = (float)acc[r] * scale;
     }
 }
 
@@ -231,9 +291,33 @@ int qmann_answer_f32(const qmann_net *net, const float *w_ans, const float *u, c
     if (lds > 128 * 1024) return QMANN_ERANGE;
     if (n_query == 0) return QMANN_OK;
     if (lds > 48 * 1024)
-        QM_HIP(hipFuncSetAttribute((const void *)k_answer, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    k_answer<<<n_query, kBlock, lds, (hipStream_t)stream>>>(w_ans, u, answer, pred, probs, cost, match, D, V,
-                                                          net->softmax_base);
+        QM_HIP(hipFuncSetAttribute((const void *)k_answer<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_answer<false><<<n_query, kBlock, lds, (hipStream_t)stream>>>(w_ans, u, answer, pred, probs, cost, match, D, V,
+                                                                 net->softmax_base);
+    QM_LAUNCH_CHECK();
+    return QMANN_OK;
+}
+
+int qmann_answer_i8(const qmann_net *net, const int8_t *w_ans_i8, qmann_fmt w_fmt, const float *u, float *logits_ws,
+                    const uint32_t *answer, uint32_t *pred, float *probs, float *cost, uint32_t *match,
+                    uint32_t n_query, void *stream)
+{
+    if (!net || !w_ans_i8 || !u || !logits_ws || !pred) return QMANN_EINVAL;
+    const uint32_t D = net->dim_emb, Dp = net->dim_emb_pad, V = net->dim_input;
+    if (D == 0 || V == 0 || Dp % 64 != 0 || D > Dp) return QMANN_EINVAL;
+    const qmann_fmt fu = net->act[net->n_hop - 1];           // u is the last sum_vec output
+    if (!fmt8(fu) || !fmt8(w_fmt)) return QMANN_ERANGE;
+    const size_t lds = ((size_t)((D + 3) & ~3u) + V) * sizeof(float);
+    if (lds > 128 * 1024) return QMANN_ERANGE;
+    if (n_query == 0) return QMANN_OK;
+    const float scale = 1.0f / (float)(1u << (fu.frac + w_fmt.frac));
+    const dim3 grid((n_query + 15) / 16, (V + 16 * kWaves - 1) / (16 * kWaves));
+    k_logits_mfma_i8<<<grid, kBlock, 0, (hipStream_t)stream>>>(u, w_ans_i8, logits_ws, n_query, D, Dp, V,
+                                                             QFmt{fu.iwl, fu.frac}, scale);
+    if (lds > 48 * 1024)
+        QM_HIP(hipFuncSetAttribute((const void *)k_answer<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    k_answer<true><<<n_query, kBlock, lds, (hipStream_t)stream>>>(logits_ws, nullptr, answer, pred, probs, cost, match,
+                                                                D, V, net->softmax_base);
     QM_LAUNCH_CHECK();
     return QMANN_OK;
 }

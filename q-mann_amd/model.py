@@ -195,6 +195,19 @@ class QNet:
                                            _ptr(probs), _ptr(cost), _ptr(match), B, self._s()), "qmann_answer_f32")
         return pred, probs, cost, match
 
+    def answer_i8(self, u, w_ans_i8, w_fmt, answer=None, want_probs=False):
+        """Answer layer on the int8 matrix cores; w_ans_i8 [V][Dp] two's-complement codes of Q(w_fmt)."""
+        B = u.shape[0]
+        pred = torch.empty(B, dtype=torch.int32, device=self.dev)
+        logits = torch.empty((B, self.V), dtype=torch.float32, device=self.dev)
+        probs = torch.empty((B, self.V), dtype=torch.float32, device=self.dev) if want_probs else None
+        cost = torch.zeros(1, dtype=torch.float32, device=self.dev) if answer is not None else None
+        match = torch.zeros(1, dtype=torch.int32, device=self.dev) if answer is not None else None
+        abi.check(abi.lib.qmann_answer_i8(C.byref(self.net), _ptr(w_ans_i8), abi.Fmt(*w_fmt), _ptr(u), _ptr(logits),
+                                          _ptr(answer), _ptr(pred), _ptr(probs), _ptr(cost), _ptr(match), B,
+                                          self._s()), "qmann_answer_i8")
+        return pred, probs, cost, match, logits
+
     def forward_bow(self, story, question, row_off, max_slots, answer=None, taps=False):
         keys, vals, u0 = self.embed(story, question)
         r = self.hops(keys, vals, row_off, max_slots, u0, taps=taps)

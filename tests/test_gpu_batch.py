@@ -285,3 +285,41 @@ def test_hops_packed_full_size_d256(env, oracle):
     """BASELINE config 5 shape: |memory| = 10 000, D = 256, binary-code Hamming attention."""
     run_hamming_case(env, oracle, 10, 256, [10000], B=2, seed=41, num_bit=1)
     run_hamming_case(env, oracle, 11, 256, [10000, 5000], B=2, seed=42, num_bit=8)
+
+
+# ---------------------------------------------------------------------------------------------
+# answer layer on the int8 matrix cores
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("D,V,B", [(60, 30, 5), (128, 256, 37), (256, 256, 64), (128, 1000, 33), (256, 4096, 17)])
+def test_answer_mfma_i8_bit_identical_to_float_path(env, oracle, D, V, B):
+    torch, model, abi = env.torch, env.model, env.abi
+    rng = np.random.default_rng(D + V + B)
+    cfg = cfg_synth(D, V, 5)
+    w_fmt = (1, 6)
+    # an ASYMMETRIC integer answer matrix on the Q1.6 grid and u on the Q5.2 grid
+    w_codes = np.clip(np.rint(rng.normal(0, 40, (V, D))), -127, 127).astype(np.int32)
+    w_float = (w_codes / 64.0).astype(np.float32)
+    u_codes = np.clip(np.rint(rng.normal(0, 40, (B, D))), -127, 127).astype(np.int32)
+    u = (u_codes / 4.0).astype(np.float32)
+    wts = weights(1, 3, D, V, 1.0, with_emb=False)
+    wts["w_ans"] = w_float
+    net = model.QNet(cfg, wts)
+    du = torch.from_numpy(u).to(env.dev)
+    w_i8 = net.quantize_i8(torch.from_numpy(w_float).to(env.dev), w_fmt, abi.CODE_TWOS)
+    ans = torch.from_numpy(rng.integers(0, V, B).astype(np.int32)).to(env.dev)
+    pred_i, probs_i, cost_i, match_i, logits = net.answer_i8(du, w_i8, w_fmt, answer=ans, want_probs=True)
+    pred_f, probs_f, cost_f, match_f = net.answer(du, answer=ans, want_probs=True)
+    torch.cuda.synchronize()
+    # exact integer matmul as the ground truth for the MFMA lane maps
+    want = (u_codes.astype(np.int64) @ w_codes.T.astype(np.int64)).astype(np.float64) / 256.0
+    np.testing.assert_array_equal(logits.cpu().numpy().astype(np.float64), want)
+    # and the whole layer equals the float path bit for bit
+    np.testing.assert_array_equal(probs_i.cpu().numpy(), probs_f.cpu().numpy())
+    np.testing.assert_array_equal(pred_i.cpu().numpy(), pred_f.cpu().numpy())
+    assert int(match_i.cpu()) == int(match_f.cpu())
+    assert float(cost_i.cpu()) == pytest.approx(float(cost_f.cpu()), rel=1e-6)
+    # against the oracle's float answer layer
+    m = oracle.make_model(cfg, wts)
+    for q in range(min(B, 8)):
+        lo = oracle.dense_fwd(w_float, u[q], False, (8, 7), (8, 7))
+        np.testing.assert_array_equal(logits[q].cpu().numpy(), lo)
