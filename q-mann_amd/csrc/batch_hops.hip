@@ -157,19 +157,21 @@ k_hops_fixed(const HopArgs a)
 __global__ void k_quantize_i8(const float *__restrict__ src, int8_t *__restrict__ dst, size_t rows, uint32_t cols,
                               uint32_t pitch, QFmt f, int signmag)
 {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * pitch) return;
-    const size_t r = i / pitch;
-    const uint32_t c = (uint32_t)(i % pitch);
-    int k = 0;
-    uint32_t neg = 0;
-    if (c < cols) {
-        const float x = src[r * cols + c];
-        k = qm_code(x, f.iwl, f.frac);
-        neg = !(x >= 0.0f);                      // the reference keys the sign on the float (lib/common.h:210)
+    const size_t n = rows * pitch;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;          // grid-stride: n may exceed 2^32
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const size_t r = i / pitch;
+        const uint32_t c = (uint32_t)(i % pitch);
+        int k = 0;
+        uint32_t neg = 0;
+        if (c < cols) {
+            const float x = src[r * cols + c];
+            k = qm_code(x, f.iwl, f.frac);
+            neg = !(x >= 0.0f);                  // the reference keys the sign on the float (lib/common.h:210)
+        }
+        if (signmag) dst[i] = (int8_t)((uint32_t)(k < 0 ? -k : k) | (neg ? 0x80u : 0u));
+        else dst[i] = (int8_t)k;
     }
-    if (signmag) dst[i] = (int8_t)((uint32_t)(k < 0 ? -k : k) | (neg ? 0x80u : 0u));
-    else dst[i] = (int8_t)k;
 }
 
 inline bool fmt8(qmann_fmt f) { return f.iwl + f.frac >= 1 && f.iwl + f.frac <= 7; }
@@ -200,7 +202,8 @@ int qmann_quantize_i8(const float *src, int8_t *dst, size_t rows, uint32_t cols,
     if (layout != QMANN_CODE_TWOS && layout != QMANN_CODE_SIGNMAG) return QMANN_EINVAL;
     const size_t n = rows * pitch;
     if (n == 0) return QMANN_OK;
-    k_quantize_i8<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(src, dst, rows, cols, pitch,
+    const size_t blocks = (n + 255) / 256;
+    k_quantize_i8<<<(unsigned)(blocks < 262144 ? blocks : 262144), 256, 0, (hipStream_t)stream>>>(src, dst, rows, cols, pitch,
                                                                               QFmt{fmt.iwl, fmt.frac}, layout);
     QM_LAUNCH_CHECK();
     return QMANN_OK;
@@ -226,6 +229,7 @@ int qmann_hops_i8(const qmann_net *net, const int8_t *keys, const int8_t *vals, 
     const size_t lds = qmann_hops_lds_bytes(max_slots);
     if (lds > 160 * 1024 - 1024) return QMANN_ERANGE;   // a little static LDS is used besides
     if (n_query == 0) return QMANN_OK;
+    if (n_query >= (1u << 24)) return QMANN_ERANGE;      // one workgroup per query: a launch holds < 2^32 threads
 
     HopArgs a{};
     a.keys = keys; a.vals = vals; a.hop_stride = hop_stride; a.key_hop_stride = hop_stride;

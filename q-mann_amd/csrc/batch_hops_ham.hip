@@ -241,20 +241,23 @@ k_hops_ham(const HopArgs a, const uint32_t key_row_bytes)
     if (tid < D) a.u_out[(size_t)q * D + tid] = u_f[tid];
 }
 
-// sign-magnitude bytes [rows][Dp] -> bit-planes [rows][Dp/64][nb]: one wavefront per (row, group)
+// sign-magnitude bytes [rows][Dp] -> bit-planes [rows][Dp/64][nb]: one wavefront per (row, group),
+// grid-stride (a launch may not exceed 2^32 threads, and memories run to 10^8 rows)
 __global__ void __launch_bounds__(kBlock)
 k_pack_planes(const uint8_t *__restrict__ sm, uint64_t *__restrict__ planes, size_t rows, uint32_t Dp, uint32_t nb)
 {
-    const size_t w = ((size_t)blockIdx.x * kBlock + threadIdx.x) / kWave;
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const uint32_t groups = Dp / 64;
-    if (w >= rows * groups) return;
-    const size_t r = w / groups;
-    const uint32_t g = (uint32_t)(w % groups);
-    const uint32_t b = sm[r * Dp + 64 * g + lane];
-    for (uint32_t i = 0; i < nb; i++) {
-        const uint64_t word = __ballot((b >> (7 - i)) & 1u);
-        if (lane == 0) planes[(r * groups + g) * nb + i] = word;
+    const size_t n = rows * groups;
+    const size_t stride = (size_t)gridDim.x * (kBlock / kWave);
+    for (size_t w = (size_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave; w < n; w += stride) {
+        const size_t r = w / groups;
+        const uint32_t g = (uint32_t)(w % groups);
+        const uint32_t b = sm[r * Dp + 64 * g + lane];
+        for (uint32_t i = 0; i < nb; i++) {
+            const uint64_t word = __ballot((b >> (7 - i)) & 1u);
+            if (lane == 0) planes[(r * groups + g) * nb + i] = word;
+        }
     }
 }
 
@@ -328,7 +331,8 @@ int qmann_pack_bitplanes(const int8_t *sm_codes, uint64_t *planes, size_t rows, 
     if (dim_emb_pad % 64 != 0 || num_bit < 1 || num_bit > 8) return QMANN_EINVAL;
     const size_t waves = rows * (dim_emb_pad / 64);
     if (waves == 0) return QMANN_OK;
-    k_pack_planes<<<(unsigned)((waves * kWave + kBlock - 1) / kBlock), kBlock, 0, (hipStream_t)stream>>>(
+    const size_t blocks = (waves + kBlock / kWave - 1) / (kBlock / kWave);
+    k_pack_planes<<<(unsigned)(blocks < 65536 ? blocks : 65536), kBlock, 0, (hipStream_t)stream>>>(
         (const uint8_t *)sm_codes, planes, rows, dim_emb_pad, num_bit);
     QM_LAUNCH_CHECK();
     return QMANN_OK;
@@ -345,6 +349,7 @@ int qmann_hops_appx_impl(const qmann_net *net, const int8_t *keys, const int8_t 
     const size_t lds = ham_lds_bytes(max_slots);
     if (lds > 160 * 1024 - 1024) return QMANN_ERANGE;
     if (n_query == 0) return QMANN_OK;
+    if (n_query >= (1u << 24)) return QMANN_ERANGE;      // one workgroup per query: a launch holds < 2^32 threads
     hipStream_t st = (hipStream_t)stream;
     if (net->dim_emb_pad == 64) launch<4, 64, kModeAppx, 8>(a, 64, lds, n_query, st);
     else if (net->dim_emb_pad == 128) launch<8, 128, kModeAppx, 8>(a, 128, lds, n_query, st);
@@ -371,6 +376,7 @@ int qmann_hops_packed(const qmann_net *net, const uint64_t *key_planes, size_t k
     const uint32_t row_bytes = Dp / 64 * nb * 8;
     if (row_bytes < 16) return QMANN_EUNSUPPORTED;      // Dp = 64 with a single plane
     if (n_query == 0) return QMANN_OK;
+    if (n_query >= (1u << 24)) return QMANN_ERANGE;      // one workgroup per query: a launch holds < 2^32 threads
     hipStream_t st = (hipStream_t)stream;
     const bool v1 = net->attention_mode == QMANN_ATT_HAMMING_V1;
 #define QM_HAM(DP, NB)                                                                                   \

@@ -185,7 +185,7 @@ struct EmbedArgs {
     int8_t *keys;
     int8_t *vals;
     size_t hop_stride;
-    uint32_t n_hop, D, Dp, V;
+    uint32_t n_hop, D, Dp, V, rows;
     QFmt act[QMANN_MAX_HOP], w[QMANN_MAX_HOP], att[QMANN_MAX_HOP];
 };
 
@@ -196,8 +196,9 @@ k_embed_story(const EmbedArgs a)
     __shared__ float nz_val[kMaxNnz];
     __shared__ uint32_t nnz;
     const uint32_t tid = threadIdx.x;
-    const size_t s = blockIdx.x;
+    for (size_t s = blockIdx.x; s < a.rows; s += gridDim.x) {      // grid-stride over story rows
     const float *x = a.story + s * a.V;
+    __syncthreads();
     if (tid == 0) nnz = 0;
     __syncthreads();
     for (uint32_t k = tid; k < a.V; k += kBlock) {
@@ -238,6 +239,7 @@ k_embed_story(const EmbedArgs a)
             a.keys[(size_t)h * a.hop_stride + s * a.Dp + j] = kcode;
             a.vals[(size_t)h * a.hop_stride + s * a.Dp + j] = vcode;
         }
+    }
     }
 }
 
@@ -290,6 +292,7 @@ int qmann_answer_f32(const qmann_net *net, const float *w_ans, const float *u, c
     const size_t lds = ((size_t)((D + 3) & ~3u) + V) * sizeof(float);
     if (lds > 128 * 1024) return QMANN_ERANGE;
     if (n_query == 0) return QMANN_OK;
+    if (n_query >= (1u << 24)) return QMANN_ERANGE;      // one workgroup per query: a launch holds < 2^32 threads
     if (lds > 48 * 1024)
         QM_HIP(hipFuncSetAttribute((const void *)k_answer<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     k_answer<false><<<n_query, kBlock, lds, (hipStream_t)stream>>>(w_ans, u, answer, pred, probs, cost, match, D, V,
@@ -310,6 +313,7 @@ int qmann_answer_i8(const qmann_net *net, const int8_t *w_ans_i8, qmann_fmt w_fm
     const size_t lds = ((size_t)((D + 3) & ~3u) + V) * sizeof(float);
     if (lds > 128 * 1024) return QMANN_ERANGE;
     if (n_query == 0) return QMANN_OK;
+    if (n_query >= (1u << 24)) return QMANN_ERANGE;      // one workgroup per query: a launch holds < 2^32 threads
     const float scale = 1.0f / (float)(1u << (fu.frac + w_fmt.frac));
     const dim3 grid((n_query + 15) / 16, (V + 16 * kWaves - 1) / (16 * kWaves));
     k_logits_mfma_i8<<<grid, kBlock, 0, (hipStream_t)stream>>>(u, w_ans_i8, logits_ws, n_query, D, Dp, V,
@@ -330,7 +334,7 @@ int qmann_embed_story(const qmann_net *net, const float *story, uint32_t rows_to
     if (hop_stride < (size_t)rows_total * net->dim_emb_pad) return QMANN_EINVAL;
     EmbedArgs a{};
     a.story = story; a.keys = keys; a.vals = vals; a.hop_stride = hop_stride;
-    a.n_hop = net->n_hop; a.D = net->dim_emb; a.Dp = net->dim_emb_pad; a.V = net->dim_input;
+    a.n_hop = net->n_hop; a.D = net->dim_emb; a.Dp = net->dim_emb_pad; a.V = net->dim_input; a.rows = rows_total;
     for (uint32_t h = 0; h < net->n_hop; h++) {
         if (!w_a[h] || !w_c[h]) return QMANN_EINVAL;
         if (!fmt8(net->act[h]) || !fmt8(net->w[h]) || !fmt8(net->att[h])) return QMANN_ERANGE;
@@ -340,7 +344,7 @@ int qmann_embed_story(const qmann_net *net, const float *story, uint32_t rows_to
         a.att[h] = QFmt{net->att[h].iwl, net->att[h].frac};
     }
     if (rows_total == 0) return QMANN_OK;
-    k_embed_story<<<rows_total, kBlock, 0, (hipStream_t)stream>>>(a);
+    k_embed_story<<<rows_total < (1u << 22) ? rows_total : (1u << 22), kBlock, 0, (hipStream_t)stream>>>(a);
     QM_LAUNCH_CHECK();
     return QMANN_OK;
 }
@@ -351,6 +355,7 @@ int qmann_embed_query(const qmann_net *net, const float *question, const float *
     if (!net || !question || !w_q || !u0) return QMANN_EINVAL;
     if (!fmt8(net->w[0])) return QMANN_ERANGE;
     if (n_query == 0) return QMANN_OK;
+    if (n_query >= (1u << 24)) return QMANN_ERANGE;      // one workgroup per query: a launch holds < 2^32 threads
     k_embed_query<<<n_query, kBlock, 0, (hipStream_t)stream>>>(question, w_q, u0, net->dim_emb, net->dim_input,
                                                              QFmt{net->w[0].iwl, net->w[0].frac});
     QM_LAUNCH_CHECK();
