@@ -118,45 +118,58 @@ k_answer(const float *__restrict__ w_ans, const float *__restrict__ u, const uin
 // v_mfma_i32_16x16x64_i8 over the embedding axis; both fragments are plain 16-byte row segments
 // (lane l: row l & 15, bytes 16.(l >> 4) .. +15 of the 64-deep K step), so they are loaded straight
 // from global memory -- the query side is converted from the hop kernel's float-on-grid vector in
-// registers.  C/D: lane l holds column l & 15, rows 4.(l >> 4) + r.
+// registers once and stays resident while the wavefront walks the answer tiles.
+// C/D: lane l holds column l & 15, rows 4.(l >> 4) + r.
 // ---------------------------------------------------------------------------
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
+constexpr int kTilesPerBlockY = 16;      // answer tiles (of 16) one wavefront walks with its query fragment resident
+
+template <int KSTEPS>
 __global__ void __launch_bounds__(kBlock)
 k_logits_mfma_i8(const float *__restrict__ u, const int8_t *__restrict__ w, float *__restrict__ logits,
-                 uint32_t n_query, uint32_t D, uint32_t Dp, uint32_t V, QFmt fu, float scale)
+                 uint32_t n_query, uint32_t D, uint32_t V, QFmt fu, float scale)
 {
+    constexpr uint32_t Dp = KSTEPS * 64;
     const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    const uint32_t m0 = blockIdx.x * 16;
-    const uint32_t n0 = (blockIdx.y * kWaves + wave) * 16;
-    if (n0 >= V) return;                                     // whole wavefront
+    const uint32_t m0 = (blockIdx.x * kWaves + wave) * 16;       // this wavefront's 16 queries
+    if (m0 >= n_query) return;                                   // whole wavefront
     const uint32_t row = lane & 15, kq = lane >> 4;
-    const uint32_t qrow = m0 + row, vrow = n0 + row;
-    i32x4 acc = {0, 0, 0, 0};
-    for (uint32_t k0 = 0; k0 < Dp; k0 += 64) {
-        const uint32_t kb = k0 + 16 * kq;
-        i32x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
-        if (qrow < n_query) {
+    const uint32_t qrow = m0 + row;
+    // A fragments (query codes) for every K step, converted once
+    i32x4 a[KSTEPS];
 #pragma unroll
-            for (int d = 0; d < 4; d++) {
-                uint32_t pk = 0;
+    for (int ks = 0; ks < KSTEPS; ks++) {
+        const uint32_t kb = ks * 64 + 16 * kq;
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const uint32_t c = kb + 4 * d + i;
-                    const int code = (c < D) ? qm_code(u[(size_t)qrow * D + c], fu.iwl, fu.frac) : 0;
-                    pk |= ((uint32_t)code & 0xFFu) << (8 * i);
-                }
-                a[d] = (int)pk;
+        for (int d = 0; d < 4; d++) {
+            uint32_t pk = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t c = kb + 4 * d + i;
+                const int code = (qrow < n_query && c < D) ? qm_code(u[(size_t)qrow * D + c], fu.iwl, fu.frac) : 0;
+                pk |= ((uint32_t)code & 0xFFu) << (8 * i);
             }
+            a[ks][d] = (int)pk;
         }
-        if (vrow < V) b = *(const i32x4 *)(w + (size_t)vrow * Dp + kb);
-        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, acc, 0, 0, 0);
     }
-    const uint32_t col = n0 + (lane & 15);
+    const uint32_t t0 = blockIdx.y * kTilesPerBlockY;
+    for (uint32_t t = t0; t < t0 + kTilesPerBlockY && t * 16 < V; t++) {
+        const uint32_t n0 = t * 16;
+        const uint32_t vrow = n0 + row;
+        i32x4 acc = {0, 0, 0, 0};
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const uint32_t qr = m0 + 4 * (lane >> 4) + r;
-        if (qr < n_query && col < V) logits[(size_t)qr * V + col] = (float)acc[r] * scale;
+        for (int ks = 0; ks < KSTEPS; ks++) {
+            i32x4 b = {0, 0, 0, 0};
+            if (vrow < V) b = *(const i32x4 *)(w + (size_t)vrow * Dp + ks * 64 + 16 * kq);
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks], b, acc, 0, 0, 0);
+        }
+        const uint32_t col = n0 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t qr = m0 + 4 * (lane >> 4) + r;
+            if (qr < n_query && col < V) logits[(size_t)qr * V + col] = (float)acc[r] * scale;
+        }
     }
 }
 
@@ -315,9 +328,13 @@ int qmann_answer_i8(const qmann_net *net, const int8_t *w_ans_i8, qmann_fmt w_fm
     if (n_query == 0) return QMANN_OK;
     if (n_query >= (1u << 24)) return QMANN_ERANGE;      // one workgroup per query: a launch holds < 2^32 threads
     const float scale = 1.0f / (float)(1u << (fu.frac + w_fmt.frac));
-    const dim3 grid((n_query + 15) / 16, (V + 16 * kWaves - 1) / (16 * kWaves));
-    k_logits_mfma_i8<<<grid, kBlock, 0, (hipStream_t)stream>>>(u, w_ans_i8, logits_ws, n_query, D, Dp, V,
-                                                             QFmt{fu.iwl, fu.frac}, scale);
+    const dim3 grid((n_query + 16 * kWaves - 1) / (16 * kWaves), (V + 16 * kTilesPerBlockY - 1) / (16 * kTilesPerBlockY));
+    hipStream_t st = (hipStream_t)stream;
+    const QFmt fuq{fu.iwl, fu.frac};
+    if (Dp == 64) k_logits_mfma_i8<1><<<grid, kBlock, 0, st>>>(u, w_ans_i8, logits_ws, n_query, D, V, fuq, scale);
+    else if (Dp == 128) k_logits_mfma_i8<2><<<grid, kBlock, 0, st>>>(u, w_ans_i8, logits_ws, n_query, D, V, fuq, scale);
+    else if (Dp == 256) k_logits_mfma_i8<4><<<grid, kBlock, 0, st>>>(u, w_ans_i8, logits_ws, n_query, D, V, fuq, scale);
+    else return QMANN_EUNSUPPORTED;
     if (lds > 48 * 1024)
         QM_HIP(hipFuncSetAttribute((const void *)k_answer<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     k_answer<true><<<n_query, kBlock, lds, (hipStream_t)stream>>>(logits_ws, nullptr, answer, pred, probs, cost, match,
