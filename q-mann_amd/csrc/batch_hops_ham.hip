@@ -23,6 +23,8 @@
 // evaluated per slot (max, sum of exp in double, quotient), as lib/layer_cuda.cu:1969-2060 does.
 #include "hops_common.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr uint32_t kOffUb = kOffHist;                 // u8  [256]  sign-magnitude bytes of Q_att(u)   (reuses the
@@ -30,6 +32,14 @@ constexpr uint32_t kOffUpl = kOffHist + 256;          // u64 [4][8] bit-planes o
 static_assert(kOffUpl % 8 == 0 && kOffUpl + 4 * 8 * 8 <= kOffPtab, "u planes must fit the histogram area");
 
 enum { kModeAppx = 0, kModeV0 = 1, kModeV1 = 2 };
+
+// V0 scores are small counts (0 .. num_bit . D <= 2048): they are kept as int16 and the softmax is
+// evaluated once per distinct count through a histogram (as the fixed-point kernel does per code);
+// the other modes keep int32 scores and evaluate the softmax per slot.
+constexpr uint32_t kV0MaxBins = 2049;
+constexpr uint32_t kV0HistBytes = ((kV0MaxBins * 4 + 15) / 16) * 16;
+constexpr uint32_t kV0KpBytes = ((kV0MaxBins + 15) / 16) * 16;
+constexpr uint32_t kV0TableBytes = 2 * kV0HistBytes + kV0KpBytes;     // hist u32, p float, Q(p) u8
 
 // ---- APPX: 4 key bytes against 4 query bytes -------------------------------------------------
 struct AppxConst {
@@ -111,7 +121,7 @@ __device__ __forceinline__ int plane_lane_sum(const i32x4 x, const PlaneConst &c
 // LPRK: lanes per key row; DP: padded embedding width; MODE; NB: planes (packed modes)
 template <int LPRK, int DP, int MODE, int NB>
 __global__ void __launch_bounds__(kBlock)
-k_hops_ham(const HopArgs a, const uint32_t key_row_bytes)
+k_hops_ham(const HopArgs a, const uint32_t key_row_bytes, const uint32_t lds_slots)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint8_t *ub = (uint8_t *)(smem + kOffUb);
@@ -123,13 +133,20 @@ k_hops_ham(const HopArgs a, const uint32_t key_row_bytes)
     uint8_t *live_kp = (uint8_t *)(smem + kOffLiveKp);
     uint32_t *misc = (uint32_t *)(smem + kOffMisc);
     double *red = (double *)(smem + kOffRed);
-    int32_t *sc = (int32_t *)(smem + kOffScores);
+    using score_t = typename std::conditional<MODE == kModeV0, int16_t, int32_t>::type;
+    score_t *sc = (score_t *)(smem + kOffScores);
 
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     const uint32_t q = blockIdx.x;
     const uint32_t r0 = a.row_off[q];
     const uint32_t S = a.row_off[q + 1] - r0;
     const uint32_t D = a.D;
+    // V0 tables sit behind the score array (lds_slots is the launch's slot capacity)
+    unsigned char *tab = smem + kOffScores + (((size_t)lds_slots * sizeof(score_t) + 15) & ~(size_t)15);
+    uint32_t *v0_hist = (uint32_t *)tab;
+    float *v0_p = (float *)(tab + kV0HistBytes);
+    uint8_t *v0_kp = (uint8_t *)(tab + 2 * kV0HistBytes);
+    const uint32_t nbins = NB * D + 1;
 
     u_f[tid] = (tid < D) ? a.u0[(size_t)q * D + tid] : 0.0f;
     __syncthreads();
@@ -150,12 +167,17 @@ k_hops_ham(const HopArgs a, const uint32_t key_row_bytes)
             }
         }
         if (tid == 0) misc[0] = 0u;
+        if (MODE == kModeV0)
+            for (uint32_t d = tid; d < nbins; d += kBlock) v0_hist[d] = 0u;
         __syncthreads();
 
         float scale = 1.0f;
         if (S > 0) {
             const uint8_t *kb = (const uint8_t *)a.keys + (size_t)h * a.key_hop_stride + (size_t)r0 * key_row_bytes;
-            auto retire = [&](uint32_t r, int v) { sc[r] = v; };
+            auto retire = [&](uint32_t r, int v) {
+                sc[r] = (score_t)v;
+                if (MODE == kModeV0) atomicAdd(&v0_hist[v], 1u);
+            };
             if (MODE == kModeAppx) {
                 scale = 1.0f / 1024.0f;                         // 2^-(n-1) . 2^ATTENTION_CONST_SCALE, n = 8
                 const int lim = 1 << (fm.iwl + 10);             // final Q(iwl, 31-iwl) clamps at +-2^iwl
@@ -198,7 +220,42 @@ k_hops_ham(const HopArgs a, const uint32_t key_row_bytes)
 
         // softmax over slots, evaluated per slot (lib/layer_cuda.cu:1895-1916, 1969-2060)
         uint32_t n_live = 0;
-        if (S > 0) {
+        if (MODE == kModeV0 && S > 0) {
+            // one exp per distinct count; normaliser sum_d count[d] . e[d] in double (lib/layer_cuda.cu:2024-2042)
+            int dmax = -1;
+            for (uint32_t d = tid; d < nbins; d += kBlock) dmax = v0_hist[d] ? (int)d : dmax;
+            dmax = block_max_int(dmax, (int *)red, lane, wave);
+            double part = 0.0;
+            for (uint32_t d = tid; d < nbins; d += kBlock) {
+                const float x = (float)((int)d - dmax);
+                const float e = (a.softmax_base == QMANN_SOFTMAX_EXP) ? expf(x) : exp2f(x);
+                v0_p[d] = e;
+                if (v0_hist[d]) part += (double)v0_hist[d] * (double)e;
+            }
+            const double total = block_sum_double(part, red, lane, wave);
+            for (uint32_t d = tid; d < nbins; d += kBlock) {
+                float p = 0.0f;
+                if (v0_hist[d])
+                    p = (a.softmax_base == QMANN_SOFTMAX_EXP) ? (float)((double)v0_p[d] / total) : v0_p[d] / (float)total;
+                v0_p[d] = p;
+                v0_kp[d] = (uint8_t)qm_code(p, fa.iwl, fa.frac);
+            }
+            __syncthreads();
+            const size_t tb = (size_t)h * a.rows_total + r0;
+            for (uint32_t r = tid; r < S; r += kBlock) {
+                const int v = sc[r];
+                if (a.tap_codes) a.tap_codes[tb + r] = v;
+                if (a.tap_scores) a.tap_scores[tb + r] = (float)v;
+                if (a.tap_probs) a.tap_probs[tb + r] = v0_p[v];
+                const uint8_t kp = v0_kp[v];
+                if (kp) {
+                    const uint32_t i = atomicAdd(&misc[0], 1u);
+                    if (i < (uint32_t)kLiveCap) { live_row[i] = r; live_kp[i] = kp; }
+                }
+            }
+            __syncthreads();
+            n_live = misc[0];
+        } else if (S > 0) {
             int mx = INT32_MIN;
             for (uint32_t r = tid; r < S; r += kBlock) mx = sc[r] > mx ? sc[r] : mx;
             mx = block_max_int(mx, (int *)red, lane, wave);
@@ -230,12 +287,12 @@ k_hops_ham(const HopArgs a, const uint32_t key_row_bytes)
                     const float x = (float)(sc[r] - mx) * scale;
                     const float p = (a.softmax_base == QMANN_SOFTMAX_EXP) ? (float)((double)expf(x) / total)
                                                                           : exp2f(x) / (float)total;
-                    sc[r] = qm_code(p, fa.iwl, fa.frac);
+                    sc[r] = (score_t)qm_code(p, fa.iwl, fa.frac);
                 }
                 __syncthreads();
             }
         }
-        auto kp_of_row = [&](uint32_t r) { return (int)sc[r]; };
+        auto kp_of_row = [&](uint32_t r) { return MODE == kModeV0 ? (int)v0_kp[sc[r]] : (int)sc[r]; };
         finish_hop<DP>(a, q, h, r0, S, n_live, live_row, live_kp, kp_of_row, ku, u_f, o_f, tid);
     }
     if (tid < D) a.u_out[(size_t)q * D + tid] = u_f[tid];
@@ -307,7 +364,7 @@ int fill_args(HopArgs &a, const qmann_net *net, const void *keys, const int8_t *
 }
 
 template <int LPRK, int DP, int MODE, int NB>
-void launch(const HopArgs &a, uint32_t key_row_bytes, size_t lds, uint32_t n_query, hipStream_t st)
+void launch(const HopArgs &a, uint32_t key_row_bytes, size_t lds, uint32_t lds_slots, uint32_t n_query, hipStream_t st)
 {
     static size_t attr_bytes = 0;
     if (lds > attr_bytes) {
@@ -315,10 +372,14 @@ void launch(const HopArgs &a, uint32_t key_row_bytes, size_t lds, uint32_t n_que
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_bytes = lds;
     }
-    k_hops_ham<LPRK, DP, MODE, NB><<<n_query, kBlock, lds, st>>>(a, key_row_bytes);
+    k_hops_ham<LPRK, DP, MODE, NB><<<n_query, kBlock, lds, st>>>(a, key_row_bytes, lds_slots);
 }
 
-size_t ham_lds_bytes(uint32_t max_slots) { return (size_t)kOffScores + (((size_t)max_slots * 4 + 15) & ~(size_t)15); }
+size_t ham_lds_bytes(uint32_t max_slots, bool v0)
+{
+    if (v0) return (size_t)kOffScores + (((size_t)max_slots * 2 + 15) & ~(size_t)15) + kV0TableBytes;
+    return (size_t)kOffScores + (((size_t)max_slots * 4 + 15) & ~(size_t)15);
+}
 
 }  // namespace
 
@@ -346,14 +407,14 @@ int qmann_hops_appx_impl(const qmann_net *net, const int8_t *keys, const int8_t 
     HopArgs a;
     const int rc = fill_args(a, net, keys, vals, hop_stride, hop_stride, row_off, u0, u_out, taps);
     if (rc) return rc;
-    const size_t lds = ham_lds_bytes(max_slots);
+    const size_t lds = ham_lds_bytes(max_slots, false);
     if (lds > 160 * 1024 - 1024) return QMANN_ERANGE;
     if (n_query == 0) return QMANN_OK;
     if (n_query >= (1u << 24)) return QMANN_ERANGE;      // one workgroup per query: a launch holds < 2^32 threads
     hipStream_t st = (hipStream_t)stream;
-    if (net->dim_emb_pad == 64) launch<4, 64, kModeAppx, 8>(a, 64, lds, n_query, st);
-    else if (net->dim_emb_pad == 128) launch<8, 128, kModeAppx, 8>(a, 128, lds, n_query, st);
-    else launch<16, 256, kModeAppx, 8>(a, 256, lds, n_query, st);
+    if (net->dim_emb_pad == 64) launch<4, 64, kModeAppx, 8>(a, 64, lds, max_slots, n_query, st);
+    else if (net->dim_emb_pad == 128) launch<8, 128, kModeAppx, 8>(a, 128, lds, max_slots, n_query, st);
+    else launch<16, 256, kModeAppx, 8>(a, 256, lds, max_slots, n_query, st);
     QM_LAUNCH_CHECK();
     return QMANN_OK;
 }
@@ -371,19 +432,19 @@ int qmann_hops_packed(const qmann_net *net, const uint64_t *key_planes, size_t k
     HopArgs a;
     const int rc = fill_args(a, net, key_planes, vals, key_hop_stride, val_hop_stride, row_off, u0, u_out, taps);
     if (rc) return rc;
-    const size_t lds = ham_lds_bytes(max_slots);
+    const bool v1 = net->attention_mode == QMANN_ATT_HAMMING_V1;
+    const size_t lds = ham_lds_bytes(max_slots, !v1);
     if (lds > 160 * 1024 - 1024) return QMANN_ERANGE;
     const uint32_t row_bytes = Dp / 64 * nb * 8;
     if (row_bytes < 16) return QMANN_EUNSUPPORTED;      // Dp = 64 with a single plane
     if (n_query == 0) return QMANN_OK;
     if (n_query >= (1u << 24)) return QMANN_ERANGE;      // one workgroup per query: a launch holds < 2^32 threads
     hipStream_t st = (hipStream_t)stream;
-    const bool v1 = net->attention_mode == QMANN_ATT_HAMMING_V1;
 #define QM_HAM(DP, NB)                                                                                   \
     do {                                                                                                 \
         constexpr int LPRK = (DP / 64) * NB * 8 / 16;                                                    \
-        if (v1) launch<LPRK, DP, kModeV1, NB>(a, row_bytes, lds, n_query, st);                           \
-        else launch<LPRK, DP, kModeV0, NB>(a, row_bytes, lds, n_query, st);                              \
+        if (v1) launch<LPRK, DP, kModeV1, NB>(a, row_bytes, lds, max_slots, n_query, st);                \
+        else launch<LPRK, DP, kModeV0, NB>(a, row_bytes, lds, max_slots, n_query, st);                   \
     } while (0)
     if (Dp == 64) { if (nb == 2) QM_HAM(64, 2); else if (nb == 4) QM_HAM(64, 4); else QM_HAM(64, 8); }
     else if (Dp == 128) { if (nb == 1) QM_HAM(128, 1); else if (nb == 2) QM_HAM(128, 2); else if (nb == 4) QM_HAM(128, 4); else QM_HAM(128, 8); }
