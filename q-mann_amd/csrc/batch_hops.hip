@@ -50,12 +50,13 @@ k_hops_fixed(const HopArgs a)
 
     constexpr uint32_t Dp = LPR * 16;
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const uint32_t nthreads = blockDim.x, nwaves = nthreads / kWave;      // 256 / 4, or 64 / 1 for short memories
     const uint32_t q = blockIdx.x;
     const uint32_t r0 = a.row_off[q];
     const uint32_t S = a.row_off[q + 1] - r0;
     const uint32_t D = a.D;
 
-    u_f[tid] = (tid < D) ? a.u0[(size_t)q * D + tid] : 0.0f;
+    for (uint32_t c = tid; c < 256; c += nthreads) u_f[c] = (c < D) ? a.u0[(size_t)q * D + c] : 0.0f;
     __syncthreads();
 
     for (uint32_t h = 0; h < a.n_hop; h++) {
@@ -64,10 +65,10 @@ k_hops_fixed(const HopArgs a)
         const int maxm = (1 << (fm.iwl + fm.frac)) - 1;
 
         // query codes Q_bin(u), histogram reset
-        const int kuc = (tid < D) ? qm_code(u_f[tid], fb.iwl, fb.frac) : 0;
-        ku[tid] = (short)kuc;
-#pragma unroll
-        for (int i = 0; i < kWaves; i++) hist[i * 256 + tid] = 0u;
+        for (uint32_t c = tid; c < 256; c += nthreads) {
+            ku[c] = (short)((c < D) ? qm_code(u_f[c], fb.iwl, fb.frac) : 0);
+            for (uint32_t i = 0; i < nwaves; i++) hist[i * 256 + c] = 0u;
+        }
         if (tid == 0) misc[0] = 0u;
         __syncthreads();
 
@@ -100,35 +101,45 @@ k_hops_fixed(const HopArgs a)
                 sc[r] = (int8_t)code;
                 atomicAdd(&hw[code + 127], 1u);
             };
-            if (S >= (kWave / LPR) * kUnroll) scan_rows<LPR, kUnroll, NT>(kb, S, row_sum, retire, lane, wave);
-            else scan_rows_short<LPR>(kb, S, row_sum, retire, lane, wave);
+            if (S < (kWave / LPR) * kUnroll) scan_rows_short<LPR>(kb, S, row_sum, retire, lane, wave, nwaves);
+            else if (nwaves == kWaves) scan_rows<LPR, kUnroll, NT, kWaves>(kb, S, row_sum, retire, lane, wave);
+            else scan_rows<LPR, kUnroll, NT, 1>(kb, S, row_sum, retire, lane, wave);
         }
         __syncthreads();
 
         // softmax over slots from the histogram of score codes (bin d <-> code d - 127)
         uint32_t n_live = 0;
         if (S > 0) {
-            const uint32_t cnt = hist[tid] + hist[256 + tid] + hist[512 + tid] + hist[768 + tid];
-            const int dmax = block_max_int(cnt ? (int)tid : -1, (int *)red, lane, wave);
-            const float x = (float)((int)tid - dmax) / (float)(1 << fm.frac);   // score - max, exact
-            float e, p;
-            if (a.softmax_base == QMANN_SOFTMAX_EXP) {
-                e = expf(x);
-                const double total = block_sum_double(cnt ? (double)cnt * (double)e : 0.0, red, lane, wave);
-                p = (float)((double)e / total);
-            } else {
-                e = exp2f(x);
-                const float total = (float)block_sum_double(cnt ? (double)cnt * (double)e : 0.0, red, lane, wave);
-                p = e / total;
+            // each thread owns bins tid, tid + nthreads, ... (4 bins per thread in a one-wavefront group)
+            int dmax = -1;
+            for (uint32_t d = tid; d < 256; d += nthreads) {
+                uint32_t cnt = 0;
+                for (uint32_t i = 0; i < nwaves; i++) cnt += hist[i * 256 + d];
+                hist[d] = cnt;                                  // bins are thread-private from here on
+                if (cnt) dmax = (int)d;
             }
-            if (!cnt) p = 0.0f;
-            ptab[tid] = p;
-            kplut[tid] = (uint8_t)qm_code(p, fa.iwl, fa.frac);
+            dmax = block_max_int(dmax, (int *)red, lane, wave);
+            double part = 0.0;
+            for (uint32_t d = tid; d < 256; d += nthreads) {
+                const float x = (float)((int)d - dmax) / (float)(1 << fm.frac);   // score - max, exact
+                const float e = (a.softmax_base == QMANN_SOFTMAX_EXP) ? expf(x) : exp2f(x);
+                ptab[d] = e;
+                if (hist[d]) part += (double)hist[d] * (double)e;
+            }
+            const double total = block_sum_double(part, red, lane, wave);
+            for (uint32_t d = tid; d < 256; d += nthreads) {
+                float p = 0.0f;
+                if (hist[d])
+                    p = (a.softmax_base == QMANN_SOFTMAX_EXP) ? (float)((double)ptab[d] / total)
+                                                              : ptab[d] / (float)total;
+                ptab[d] = p;
+                kplut[d] = (uint8_t)qm_code(p, fa.iwl, fa.frac);
+            }
             __syncthreads();
 
             if (a.tap_codes || a.tap_scores || a.tap_probs) {
                 const size_t tb = (size_t)h * a.rows_total + r0;
-                for (uint32_t r = tid; r < S; r += kBlock) {
+                for (uint32_t r = tid; r < S; r += nthreads) {
                     const int code = sc[r];
                     if (a.tap_codes) a.tap_codes[tb + r] = code;
                     if (a.tap_scores) a.tap_scores[tb + r] = (float)code / (float)(1 << fm.frac);
@@ -136,7 +147,7 @@ k_hops_fixed(const HopArgs a)
                 }
             }
             // rows whose quantised weight is non-zero
-            for (uint32_t r = tid; r < S; r += kBlock) {
+            for (uint32_t r = tid; r < S; r += nthreads) {
                 const uint8_t kp = kplut[(int)sc[r] + 127];
                 if (kp) {
                     const uint32_t i = atomicAdd(&misc[0], 1u);
@@ -151,7 +162,7 @@ k_hops_fixed(const HopArgs a)
         auto kp_of_row = [&](uint32_t r) { return (int)kplut[(int)sc[r] + 127]; };
         finish_hop<Dp>(a, q, h, r0, S, n_live, live_row, live_kp, kp_of_row, ku, u_f, o_f, tid);
     }
-    if (tid < D) a.u_out[(size_t)q * D + tid] = u_f[tid];
+    for (uint32_t c = tid; c < D; c += nthreads) a.u_out[(size_t)q * D + c] = u_f[c];
 }
 
 __global__ void k_quantize_i8(const float *__restrict__ src, int8_t *__restrict__ dst, size_t rows, uint32_t cols,
@@ -250,7 +261,9 @@ int qmann_hops_i8(const qmann_net *net, const int8_t *keys, const int8_t *vals, 
     a.bin = QFmt{net->bin.iwl, net->bin.frac};
 
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid(n_query), block(kBlock);
+    // short memories (bAbI-sized stories) run one wavefront per query: four times as many queries
+    // resident per CU and no cross-wavefront barriers
+    const dim3 grid(n_query), block(max_slots <= 256 ? kWave : kBlock);
 #define QM_LAUNCH_HOPS(LPR, UN, NT, MINW)                                                               \
     do {                                                                                                \
         static size_t attr_bytes = 0;       /* raise the dynamic-LDS limit only when it grows */        \

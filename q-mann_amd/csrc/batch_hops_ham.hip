@@ -195,8 +195,8 @@ k_hops_ham(const HopArgs a, const uint32_t key_row_bytes, const uint32_t lds_slo
                 }
                 auto row_sum = [&](const i32x4 x) { return appx_lane_sum(x, c); };
                 auto retire_c = [&](uint32_t r, int v) { sc[r] = v > lim ? lim : (v < -lim ? -lim : v); };
-                if (S >= (kWave / LPRK) * 4) scan_rows<LPRK, 4, true>(kb, S, row_sum, retire_c, lane, wave);
-                else scan_rows_short<LPRK>(kb, S, row_sum, retire_c, lane, wave);
+                if (S >= (kWave / LPRK) * 4) scan_rows<LPRK, 4, true, kWaves>(kb, S, row_sum, retire_c, lane, wave);
+                else scan_rows_short<LPRK>(kb, S, row_sum, retire_c, lane, wave, kWaves);
             } else {
                 if (MODE == kModeV1) scale = 1.0f / (float)(1 << NB);
                 PlaneConst c;
@@ -212,8 +212,8 @@ k_hops_ham(const HopArgs a, const uint32_t key_row_bytes, const uint32_t lds_slo
                     c.wgt[t] = pl == 0 ? 0 : (1 << (NB - 1 - pl));
                 }
                 auto row_sum = [&](const i32x4 x) { return plane_lane_sum<MODE, NB>(x, c); };
-                if (S >= (kWave / LPRK) * 4) scan_rows<LPRK, 4, true>(kb, S, row_sum, retire, lane, wave);
-                else scan_rows_short<LPRK>(kb, S, row_sum, retire, lane, wave);
+                if (S >= (kWave / LPRK) * 4) scan_rows<LPRK, 4, true, kWaves>(kb, S, row_sum, retire, lane, wave);
+                else scan_rows_short<LPRK>(kb, S, row_sum, retire, lane, wave, kWaves);
             }
         }
         __syncthreads();

@@ -123,12 +123,12 @@ __device__ __forceinline__ i32x4 load16(const uint8_t *p)
 // four wavefronts.  Not a bandwidth path.
 template <int LPR, typename RowSum, typename Retire>
 __device__ __forceinline__ void scan_rows_short(const uint8_t *__restrict__ kb, uint32_t S, RowSum row_sum,
-                                                Retire retire, uint32_t lane, uint32_t wave)
+                                                Retire retire, uint32_t lane, uint32_t wave, uint32_t nwaves)
 {
     constexpr uint32_t RPW = kWave / LPR;
     constexpr uint32_t Dp = LPR * 16;
     const uint32_t sub = lane / LPR, chunk = lane % LPR;
-    for (uint32_t base = wave * RPW; base < S; base += kWaves * RPW) {
+    for (uint32_t base = wave * RPW; base < S; base += nwaves * RPW) {
         const uint32_t r = base + sub;
         i32x4 x = {0, 0, 0, 0};
         if (r < S) x = *(const i32x4 *)(kb + (size_t)r * Dp + chunk * 16);
@@ -140,10 +140,11 @@ __device__ __forceinline__ void scan_rows_short(const uint8_t *__restrict__ kb, 
 // One wavefront streams tiles of UN x (64 / LPR) rows; loads of the next tile are issued before
 // the current one is reduced (addresses are clamped to the last row instead of being predicated,
 // so the loop body has no divergent control flow and the compiler can count its vmcnt waits).
-template <int LPR, int UN, bool NT, typename RowSum, typename Retire>
+template <int LPR, int UN, bool NT, int NW, typename RowSum, typename Retire>
 __device__ __forceinline__ void scan_rows(const uint8_t *__restrict__ kb, uint32_t S, RowSum row_sum, Retire retire,
                                           uint32_t lane, uint32_t wave)
 {
+    constexpr uint32_t nwaves = NW;                // wavefronts sharing the rows of this query
     constexpr uint32_t RPW = kWave / LPR;          // rows per wavefront instruction
     constexpr uint32_t TILE = RPW * UN;            // rows per wavefront iteration
     constexpr uint32_t Dp = LPR * 16;
@@ -181,12 +182,12 @@ __device__ __forceinline__ void scan_rows(const uint8_t *__restrict__ kb, uint32
     if (wave >= n_tiles) return;
     i32x4 xa[UN], xb[UN];
     uint32_t base = wave * TILE;
-    constexpr uint32_t STEP = kWaves * TILE;
+    constexpr uint32_t STEP = nwaves * TILE;
     issue(xa, base);
-    for (uint32_t t = wave; t < n_tiles; t += 2 * kWaves) {
+    for (uint32_t t = wave; t < n_tiles; t += 2 * nwaves) {
         issue(xb, base + STEP);
         reduce(xa, base);
-        if (t + kWaves >= n_tiles) break;
+        if (t + nwaves >= n_tiles) break;
         issue(xa, base + 2 * STEP);
         reduce(xb, base + STEP);
         base += 2 * STEP;
@@ -200,6 +201,7 @@ __device__ __forceinline__ int sm_decode(uint8_t b)
     return (b & 0x80) ? -m : m;
 }
 
+// block reductions; workgroups are 1 or 4 wavefronts (blockDim.x = 64 or 256)
 __device__ __forceinline__ int block_max_int(int v, int *scratch, uint32_t lane, uint32_t wave)
 {
 #pragma unroll
@@ -207,10 +209,12 @@ __device__ __forceinline__ int block_max_int(int v, int *scratch, uint32_t lane,
         const int t = __shfl_xor(v, o);
         v = t > v ? t : v;
     }
+    const uint32_t nwaves = blockDim.x / kWave;
+    if (nwaves == 1) return v;
     if (lane == 0) scratch[wave] = v;
     __syncthreads();
     int r = scratch[0];
-    for (int i = 1; i < kWaves; i++) r = scratch[i] > r ? scratch[i] : r;
+    for (uint32_t i = 1; i < nwaves; i++) r = scratch[i] > r ? scratch[i] : r;
     __syncthreads();
     return r;
 }
@@ -219,13 +223,15 @@ __device__ __forceinline__ double block_sum_double(double v, double *scratch, ui
 {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const uint32_t nwaves = blockDim.x / kWave;
+    if (nwaves == 1) return v;
     if (lane == 0) scratch[wave] = v;
     __syncthreads();
-    const double r = (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+    double r = scratch[0];
+    for (uint32_t i = 1; i < nwaves; i++) r += scratch[i];
     __syncthreads();
     return r;
 }
-
 
 // Stages after the softmax, shared by every attention mode:
 //   read-out  o[c] = Qa( sum_r Qa( Qa(p[r]) . Qa(C[r][c]) ) )   (lib/layer_cuda.cu:547-635 via :2430/:2512)
@@ -243,8 +249,9 @@ __device__ __forceinline__ void finish_hop(const HopArgs &a, uint32_t q, uint32_
     const int maxa = (1 << (fa.iwl + fa.frac)) - 1;
     const int maxw = (1 << (fw.iwl + fw.frac)) - 1;
     const uint32_t D = a.D;
-    if (tid < Dp) {
-        const uint8_t *vb = (const uint8_t *)a.vals + (size_t)h * a.hop_stride + (size_t)r0 * Dp + tid;
+    const uint32_t nthreads = blockDim.x;
+    for (uint32_t c = tid; c < Dp; c += nthreads) {
+        const uint8_t *vb = (const uint8_t *)a.vals + (size_t)h * a.hop_stride + (size_t)r0 * Dp + c;
         int acc = 0;
         if (n_live <= (uint32_t)kLiveCap) {
             for (uint32_t i = 0; i < n_live; i++)
@@ -256,13 +263,13 @@ __device__ __forceinline__ void finish_hop(const HopArgs &a, uint32_t q, uint32_
             }
         }
         acc = acc > maxa ? maxa : (acc < -maxa ? -maxa : acc);
-        o_f[tid] = (float)acc / (float)(1 << fa.frac);
+        o_f[c] = (float)acc / (float)(1 << fa.frac);
     }
     __syncthreads();
-    if (tid < D) {
-        float lu = u_f[tid];
+    for (uint32_t o_i = tid; o_i < D; o_i += nthreads) {
+        float lu = u_f[o_i];
         if (a.en_lin_map) {
-            const int8_t *hr = a.lin_map[h] + (size_t)tid * Dp;
+            const int8_t *hr = a.lin_map[h] + (size_t)o_i * Dp;
             int acc = 0;
             for (uint32_t i = 0; i < Dp; i += 16) {
                 const i32x4 wv = *(const i32x4 *)(hr + i);
@@ -275,11 +282,11 @@ __device__ __forceinline__ void finish_hop(const HopArgs &a, uint32_t q, uint32_
             acc = acc > maxw ? maxw : (acc < -maxw ? -maxw : acc);
             lu = (float)acc / (float)(1 << fw.frac);
         }
-        const float o = o_f[tid];
+        const float o = o_f[o_i];
         const float un = qm_quant(qm_quant(lu, fa.iwl, fa.frac) + qm_quant(o, fa.iwl, fa.frac), fa.iwl, fa.frac);
-        if (a.tap_o) a.tap_o[((size_t)q * a.n_hop + h) * D + tid] = o;
-        if (a.tap_u) a.tap_u[((size_t)q * a.n_hop + h) * D + tid] = un;
-        u_f[tid] = un;
+        if (a.tap_o) a.tap_o[((size_t)q * a.n_hop + h) * D + o_i] = o;
+        if (a.tap_u) a.tap_u[((size_t)q * a.n_hop + h) * D + o_i] = un;
+        u_f[o_i] = un;
     }
     __syncthreads();
 }
