@@ -54,6 +54,10 @@ WORKLOADS = {
     "synth10k_d128_appx": dict(S=10000, D=128, V=256, B=8192, mode=3, nb=8, ans="f32", sk=30.0, sv=30.0, su=30.0),
     "babi_mem50": dict(S=50, D=60, V=80, B=262144, mode=2, nb=8, ans="f32", sk=8.0, sv=30.0, su=8.0),
     "babi_joint_appx": dict(S=50, D=60, V=256, B=262144, mode=3, nb=8, ans="f32", sk=30.0, sv=30.0, su=30.0),
+    # BASELINE.json configs[1]: real bAbI task-1 stories (the 64-story fixture produced by the reference's
+    # sample.c, replicated), 3 hops, int8, EN_MQ formats, the WHOLE forward from bag-of-words input:
+    # story + question embedding, hops, answer layer
+    "babi_task1_bow": dict(S=10, D=60, V=30, B=262144, mode=2, nb=8, ans="f32", bow=True),
 }
 KERNEL_OF_MODE = {2: "k_hops_fixed", 3: "k_hops_ham", 10: "k_hops_ham", 11: "k_hops_ham"}
 
@@ -108,6 +112,88 @@ def cpu_baseline(cfg, wts, keys, vals, u0, S, D, budget_s=15.0):
     return done / t_used, done, t_used, preds
 
 
+def run_bow(args, wl, net, cfg, wts, dev, rank, world, model):
+    """configs[1]: the full forward from bag-of-words stories (embedding + hops + answer)."""
+    g = np.load(ROOT / "tests" / "golden" / "babi_qa1_test64.npz")
+    n_sen = g["n_sen"].astype(np.int64)
+    B = args.queries or wl["B"]
+    rep = (B + len(n_sen) - 1) // len(n_sen)
+    B = rep * len(n_sen)
+    story = torch.from_numpy(np.tile(g["story"].astype(np.float32), (rep, 1))).to(dev)
+    ques = torch.from_numpy(np.tile(g["question"].astype(np.float32), (rep, 1))).to(dev)
+    ans = torch.from_numpy(np.tile(g["answer"].argmax(1).astype(np.int32), rep)).to(dev)
+    ns_all = np.tile(n_sen, rep)
+    row_off = torch.from_numpy(np.concatenate([[0], np.cumsum(ns_all)]).astype(np.int32)).to(dev)
+    max_slots = int(n_sen.max())
+    torch.cuda.synchronize()
+
+    def step():
+        return net.forward_bow(story, ques, row_off, max_slots, answer=ans)
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    rows = int(row_off[-1])
+    bytes_in = rows * cfg["dim_input"] * 4 + B * cfg["dim_input"] * 4           # BoW floats read by the embedding
+    res = {
+        "metric": "queries/sec", "value": world * B * args.steps / elapsed, "unit": "queries/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int8",
+        "data": "bAbI qa1 test stories (64-story fixture from the reference's sample.c, replicated), seeded random weights",
+        "config": {"workload": args.workload, "slots": "2..10 (mean 5.9)", "dim_emb": 60, "dim_input": cfg["dim_input"],
+                   "hops": 3, "queries_per_gpu": B, "format": "Q5.2 + EN_MQ weight formats", "attention_mode": 2,
+                   "stages": "embed_story + embed_query + hops + answer",
+                   "parallelism": f"replicas x{world}, query-sharded"},
+        "roofline": {"bound": "hbm", "kernel": "whole forward (latency bound at these sizes)",
+                     "achieved": bytes_in * args.steps / elapsed / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": bytes_in * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, "traffic": None},
+        "accuracy_note": "random weights: predictions are compared with the oracle, not with labels",
+    }
+    if rank == 0 and not args.no_cpu_baseline:
+        sys.path.insert(0, str(ROOT / "oracle"))
+        from pyoracle import Oracle
+        ora = Oracle()
+        m = ora.make_model(cfg, wts)
+        st, qu = g["story"].astype(np.float32), g["question"].astype(np.float32)
+        preds, t_used, off, reps = [], 0.0, 0, 0
+        while t_used < 10.0 and reps < 200:
+            off = 0
+            for i in range(len(n_sen)):
+                ns = int(n_sen[i])
+                t1 = time.perf_counter()
+                p_, _ = ora.forward(m, st[off:off + ns], qu[i], taps=())
+                t_used += time.perf_counter() - t1
+                if reps == 0:
+                    preds.append(p_)
+                off += ns
+            reps += 1
+        gp = out["pred"][:len(n_sen)].cpu().numpy().tolist()
+        res["cpu_baseline"] = {"value": reps * len(n_sen) / t_used, "unit": "queries/s", "cores": 1, "kind": "port",
+                               "sample": f"the 64 fixture stories x {reps} passes, {t_used:.1f} s, scalar C oracle -O2",
+                               "pred_agree": int(sum(int(a == b) for a, b in zip(gp, preds))), "pred_total": len(preds)}
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -139,18 +225,27 @@ def main():
     S, D, V, mode, nb = wl["S"], wl["D"], wl["V"], wl["mode"], wl["nb"]
     B = args.queries or wl["B"]
     H = 3
-    cfg = model.babi_cfg(V, attention_mode=mode, softmax_base=0, iwl=5, n_hop=H, D=D, en_mq=False)
+    cfg = model.babi_cfg(V, attention_mode=mode, softmax_base=0, iwl=5, n_hop=H, D=D, en_mq=bool(wl.get("bow")))
     cfg["num_bit"] = nb
 
     # parameters: created on rank 0, broadcast once over RCCL (xGMI) -- the only collective
     wts = make_params(cfg, D, V, seed=0x51A44) if rank == 0 else None
     wts, bcast_ms = broadcast_params(wts, cfg, dev, rank, world)
+    if wl.get("bow"):                            # embedding tables (seeded identically on every rank)
+        rng = np.random.default_rng(0xBAB1)
+        wts["w_q"] = rng.normal(0, 1.0, (D, V)).astype(np.float32)
+        wts["w_a"] = [rng.normal(0, 1.0, (D, V)).astype(np.float32) for _ in range(H)]
+        wts["w_c"] = [rng.normal(0, 1.0, (D, V)).astype(np.float32) for _ in range(H)]
     ans_fmt = (1, 6)
     if wl["ans"] == "i8":                       # answer matrix on an int8 grid -> the MFMA projection is exact
         wts["w_ans"] = (np.clip(np.rint(wts["w_ans"] * 64.0 * 4), -127, 127) / 64.0).astype(np.float32)
     net = model.QNet(cfg, wts, device=str(dev))
     Dp = net.Dp
     w_ans_i8 = net.quantize_i8(net.w_ans, ans_fmt, abi.CODE_TWOS) if wl["ans"] == "i8" else None
+
+    if wl.get("bow"):
+        run_bow(args, wl, net, cfg, wts, dev, rank, world, model)
+        return
 
     # synthetic per-query memories, resident in HBM before the timed region
     gen = torch.Generator(device=dev)
