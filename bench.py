@@ -52,6 +52,7 @@ WORKLOADS = {
     "synth10k_d128": dict(S=10000, D=128, V=256, B=8192, mode=2, nb=8, ans="f32", sk=3.5, sv=30.0, su=3.5),
     "synth10k_d256_ham": dict(S=10000, D=256, V=256, B=8192, mode=10, nb=1, ans="i8", sk=30.0, sv=30.0, su=30.0),
     "synth10k_d128_appx": dict(S=10000, D=128, V=256, B=8192, mode=3, nb=8, ans="f32", sk=30.0, sv=30.0, su=30.0),
+    "synth10k_d128_float": dict(S=10000, D=128, V=256, B=4096, mode=1, nb=8, ans="f32", sk=3.5, sv=30.0, su=3.5),
     "babi_mem50": dict(S=50, D=60, V=80, B=262144, mode=2, nb=8, ans="f32", sk=8.0, sv=30.0, su=8.0),
     "babi_joint_appx": dict(S=50, D=60, V=256, B=262144, mode=3, nb=8, ans="f32", sk=30.0, sv=30.0, su=30.0),
     # BASELINE.json configs[1]: real bAbI task-1 stories (the 64-story fixture produced by the reference's
@@ -59,7 +60,7 @@ WORKLOADS = {
     # story + question embedding, hops, answer layer
     "babi_task1_bow": dict(S=10, D=60, V=30, B=262144, mode=2, nb=8, ans="f32", bow=True),
 }
-KERNEL_OF_MODE = {2: "k_hops_fixed", 3: "k_hops_ham", 10: "k_hops_ham", 11: "k_hops_ham"}
+KERNEL_OF_MODE = {1: "k_hops_float", 2: "k_hops_fixed", 3: "k_hops_ham", 10: "k_hops_ham", 11: "k_hops_ham"}
 
 
 def gauss_i8(shape, sigma, gen, dev, pad_from=None):
@@ -300,6 +301,8 @@ def main():
     hop_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))    # dominant kernel, HIP events
     ans_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
     bytes_per_query = H * S * key_row_bytes                           # key planes: the addressing scan
+    if mode == 1:
+        bytes_per_query += H * S * Dp                                 # float read-out streams every value row too
     achieved = bytes_per_query * B / (hop_ms * 1e-3) / 1e9
     traffic = None
     tj = ROOT / "profiles" / "traffic.json"

@@ -97,8 +97,10 @@ int qmann_quantize_i8(const float *src, int8_t *dst, size_t rows, uint32_t cols,
  *   u_out [n_query][D] float   -- sv[n_hop-1] output, input of the answer layer
  * Replaces, per query and hop, the reference sequence dot_mat_vec_fwd -> softmax_fwd ->
  * dot_mat_vec_fwd(trans) -> dense_fwd(lin_map) -> sum_vec_fwd (MemN2N/MemN2N.c:2644-2666).
- * attention_mode QMANN_ATT_FIXED (define.h mode 2) or QMANN_ATT_APPX (mode 3; needs att formats with
- * iwl + frac = 7 and u grids no finer / wider than the attention grid, else QMANN_EUNSUPPORTED). */
+ * attention_mode QMANN_ATT_FIXED (define.h mode 2), QMANN_ATT_APPX (mode 3; needs att formats with
+ * iwl + frac = 7 and u grids no finer / wider than the attention grid, else QMANN_EUNSUPPORTED) or
+ * QMANN_ATT_FLOAT (mode 1: float scores / softmax / read-out over the same int8 memories, which
+ * then carry Q(w[h]) codes -- the embedding outputs, not re-quantised). */
 int qmann_hops_i8(const qmann_net *net, const int8_t *keys, const int8_t *vals, size_t hop_stride,
                   const uint32_t *row_off, uint32_t max_slots, const float *u0, float *u_out,
                   const qmann_taps *taps, uint32_t n_query, void *stream);

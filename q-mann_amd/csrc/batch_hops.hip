@@ -197,6 +197,8 @@ int qmann_hops_appx_impl(const qmann_net *net, const int8_t *keys, const int8_t 
                          const uint32_t *row_off, uint32_t max_slots, const float *u0, float *u_out,
                          const qmann_taps *taps, uint32_t n_query, void *stream);   // batch_hops_ham.hip
 
+int qmann_hops_float_impl(const HopArgs &a, uint32_t Dp, uint32_t max_slots, uint32_t n_query, void *stream);  // batch_hops_float.hip
+
 // development switch: selects a compiled tuning variant of the D=128 scan (0 = shipped)
 void qmann_debug_set_tune(int v) { g_tune = v; }
 
@@ -230,7 +232,7 @@ int qmann_hops_i8(const qmann_net *net, const int8_t *keys, const int8_t *vals, 
     if (net->dim_emb_pad != 64 && net->dim_emb_pad != 128 && net->dim_emb_pad != 256) return QMANN_EUNSUPPORTED;
     if (net->attention_mode == QMANN_ATT_APPX)
         return qmann_hops_appx_impl(net, keys, vals, hop_stride, row_off, max_slots, u0, u_out, taps, n_query, stream);
-    if (net->attention_mode != QMANN_ATT_FIXED) return QMANN_EUNSUPPORTED;
+    if (net->attention_mode != QMANN_ATT_FIXED && net->attention_mode != QMANN_ATT_FLOAT) return QMANN_EUNSUPPORTED;
     if (net->softmax_base > QMANN_SOFTMAX_POW2) return QMANN_EINVAL;
     if (!fmt8(net->bin)) return QMANN_ERANGE;
     for (uint32_t h = 0; h < net->n_hop; h++) {
@@ -259,6 +261,9 @@ int qmann_hops_i8(const qmann_net *net, const int8_t *keys, const int8_t *vals, 
         a.att[h] = QFmt{net->att[h].iwl, net->att[h].frac};
     }
     a.bin = QFmt{net->bin.iwl, net->bin.frac};
+
+    if (net->attention_mode == QMANN_ATT_FLOAT)
+        return qmann_hops_float_impl(a, net->dim_emb_pad, max_slots, n_query, stream);
 
     hipStream_t st = (hipStream_t)stream;
     // short memories (bAbI-sized stories) run one wavefront per query: four times as many queries

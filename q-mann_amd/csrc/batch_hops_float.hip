@@ -1,0 +1,187 @@
+// batch_hops_float.hip -- fused hop kernel for ATTENTION_MODE 1 ("normal" attention over quantized
+// embeddings): float dot-product scores, float softmax, float read-out (lib/layer.c:177-195 forces
+// f_fixed = false for both dot_mat_vec layers), while the embeddings, the linear map and the hop
+// update stay fixed point.
+//
+// Memories are the same sign-magnitude int8 planes; here they carry the embedding outputs on the
+// WEIGHT grid Q(w[h]) (no attention re-quantisation happens in this mode).  Because both operands
+// sit on grids, a score is an exact integer (|sum| < 2^24) times 2^-(frac_w + frac_u): it is
+// computed as sum |k| . (+-u) with one v_dot4 per 4 bytes (the key's sign selects u or -u through
+// v_perm + v_bfi) and is bit-identical to the reference's float sum in any order.  The read-out
+// o[c] = sum_r p[r] . C[r][c] is a genuine float sum over ALL slots (p is not quantised), so this
+// mode streams the value plane as well; its result carries the float-order tolerance (1e-5).
+#include "hops_common.h"
+
+namespace {
+
+struct DotConst {
+    uint32_t up[4];   // two's-complement bytes of  u for this lane's 16 columns
+    uint32_t un[4];   // two's-complement bytes of -u
+};
+
+__device__ __forceinline__ int dot_lane_sum(const i32x4 x, const DotConst &c)
+{
+    int acc = 0;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const uint32_t w = (uint32_t)x[d];
+        const uint32_t neg = __builtin_amdgcn_perm(0u, 0u, w & 0x80808080u);      // 0xFF where the key is negative
+        const uint32_t uu = (c.un[d] & neg) | (c.up[d] & ~neg);                   // -u there, u elsewhere
+        acc = __builtin_amdgcn_sdot4((int)(w & 0x7F7F7F7Fu), (int)uu, acc, false);
+    }
+    return acc;
+}
+
+template <int LPR>
+__global__ void __launch_bounds__(kBlock)
+k_hops_float(const HopArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *u_f = (float *)(smem + kOffU);
+    float *o_f = (float *)(smem + kOffO);
+    short *ku = (short *)(smem + kOffKu);
+    int8_t *kuq = (int8_t *)(smem + kOffHist);            // integer codes of u on its own grid (reuses hist area)
+    float *part = (float *)(smem + kOffHist + 1024);      // [kWaves * 8][Dp <= 256]... see below (reuses hist/ptab)
+    double *red = (double *)(smem + kOffRed);
+    int32_t *sc = (int32_t *)(smem + kOffScores);         // scores, then p (float, in place)
+
+    constexpr uint32_t Dp = LPR * 16;
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const uint32_t q = blockIdx.x;
+    const uint32_t r0 = a.row_off[q];
+    const uint32_t S = a.row_off[q + 1] - r0;
+    const uint32_t D = a.D;
+
+    u_f[tid] = (tid < D) ? a.u0[(size_t)q * D + tid] : 0.0f;
+    __syncthreads();
+
+    for (uint32_t h = 0; h < a.n_hop; h++) {
+        const QFmt fw = a.w[h], fb = a.bin;
+        const QFmt fsrc = h == 0 ? a.w[0] : a.act[h - 1];              // grid u sits on (emb_q or sv[h-1])
+        const float uv = u_f[tid];
+        ku[tid] = (short)((tid < D) ? qm_code(uv, fb.iwl, fb.frac) : 0);
+        kuq[tid] = (int8_t)((tid < D) ? qm_code(uv, fsrc.iwl, fsrc.frac) : 0);   // exact: u is on that grid
+        __syncthreads();
+
+        const float scale = 1.0f / (float)(1u << (fw.frac + fsrc.frac));
+        if (S > 0) {
+            DotConst c;
+            const uint32_t c0 = (lane % LPR) * 16;
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                uint32_t up = 0, un = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int k = kuq[c0 + 4 * d + i];
+                    up |= ((uint32_t)k & 0xFFu) << (8 * i);
+                    un |= ((uint32_t)(-k) & 0xFFu) << (8 * i);
+                }
+                c.up[d] = up; c.un[d] = un;
+            }
+            const uint8_t *kb = (const uint8_t *)a.keys + (size_t)h * a.hop_stride + (size_t)r0 * Dp;
+            auto row_sum = [&](const i32x4 x) { return dot_lane_sum(x, c); };
+            auto retire = [&](uint32_t r, int v) { sc[r] = v; };
+            if (S >= (kWave / LPR) * 4) scan_rows<LPR, 4, true, kWaves>(kb, S, row_sum, retire, lane, wave);
+            else scan_rows_short<LPR>(kb, S, row_sum, retire, lane, wave, kWaves);
+        }
+        __syncthreads();
+
+        // softmax per slot (lib/layer_cuda.cu:1895-1916, 1969-2060); p replaces the score in place
+        float *pf = (float *)sc;
+        if (S > 0) {
+            int mx = INT32_MIN;
+            for (uint32_t r = tid; r < S; r += kBlock) mx = sc[r] > mx ? sc[r] : mx;
+            mx = block_max_int(mx, (int *)red, lane, wave);
+            const float fmx = (float)mx * scale;
+            double psum = 0.0;
+            for (uint32_t r = tid; r < S; r += kBlock) {
+                const float x = (float)sc[r] * scale - fmx;        // both exact floats; the difference is exact too
+                psum += (double)((a.softmax_base == QMANN_SOFTMAX_EXP) ? expf(x) : exp2f(x));
+            }
+            const double total = block_sum_double(psum, red, lane, wave);
+            const size_t tb = (size_t)h * a.rows_total + r0;
+            for (uint32_t r = tid; r < S; r += kBlock) {
+                const int sv = sc[r];
+                const float x = (float)sv * scale - fmx;
+                float p;
+                if (a.softmax_base == QMANN_SOFTMAX_EXP) p = (float)((double)expf(x) / total);
+                else p = exp2f(x) / (float)total;
+                if (a.tap_codes) a.tap_codes[tb + r] = sv;
+                if (a.tap_scores) a.tap_scores[tb + r] = (float)sv * scale;
+                if (a.tap_probs) a.tap_probs[tb + r] = p;
+                pf[r] = p;
+            }
+        }
+        __syncthreads();
+
+        // dense float read-out: lane (sub, chunk) owns 16 columns of every (64 / LPR)-th row
+        {
+            constexpr uint32_t RPW = kWave / LPR;
+            const uint32_t sub = lane / LPR, chunk = lane % LPR;
+            const float vscale = 1.0f / (float)(1u << fw.frac);
+            float acc[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[i] = 0.0f;
+            const uint8_t *vb = (const uint8_t *)a.vals + (size_t)h * a.hop_stride + (size_t)r0 * Dp + chunk * 16;
+            for (uint32_t r = wave * RPW + sub; r < S; r += kWaves * RPW) {
+                const i32x4 x = __builtin_nontemporal_load((const i32x4 *)(vb + (size_t)r * Dp));
+                const float p = pf[r];
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const uint32_t b = ((uint32_t)x[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+                    const float m = (float)(b & 0x7Fu) * vscale;
+                    const float v = (b & 0x80u) ? -m : m;
+                    acc[i] += p * v;
+                }
+            }
+            // fold the RPW row groups of a wavefront (lanes with equal chunk), then the wavefronts
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                float v = acc[i];
+                for (uint32_t o = LPR; o < kWave; o <<= 1) v += __shfl_xor(v, (int)o);
+                acc[i] = v;
+            }
+            __syncthreads();                                   // the histogram area is free now
+            if (sub == 0) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) part[wave * 256 + chunk * 16 + i] = acc[i];
+            }
+            __syncthreads();
+            if (tid < Dp) {
+                float s = 0.0f;
+                for (int w = 0; w < kWaves; w++) s += part[w * 256 + tid];
+                o_f[tid] = s;
+            }
+            __syncthreads();
+        }
+        linmap_update<Dp>(a, q, h, ku, u_f, o_f, tid);
+    }
+    if (tid < D) a.u_out[(size_t)q * D + tid] = u_f[tid];
+}
+
+template <int LPR>
+void launch_float(const HopArgs &a, size_t lds, uint32_t n_query, hipStream_t st)
+{
+    static size_t attr_bytes = 0;
+    if (lds > attr_bytes) {
+        QM_HIP(hipFuncSetAttribute((const void *)k_hops_float<LPR>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+        attr_bytes = lds;
+    }
+    k_hops_float<LPR><<<n_query, kBlock, lds, st>>>(a);
+}
+
+}  // namespace
+
+extern "C" int qmann_hops_float_impl(const HopArgs &a, uint32_t Dp, uint32_t max_slots, uint32_t n_query, void *stream)
+{
+    static_assert(kOffHist + 1024 + kWaves * 256 * 4 <= kOffU, "partial sums must fit the histogram + p-table area");
+    const size_t lds = (size_t)kOffScores + (((size_t)max_slots * 4 + 15) & ~(size_t)15);
+    if (lds > 160 * 1024 - 1024) return QMANN_ERANGE;
+    hipStream_t st = (hipStream_t)stream;
+    if (Dp == 64) launch_float<4>(a, lds, n_query, st);
+    else if (Dp == 128) launch_float<8>(a, lds, n_query, st);
+    else launch_float<16>(a, lds, n_query, st);
+    QM_LAUNCH_CHECK();
+    return QMANN_OK;
+}

@@ -241,14 +241,12 @@ __device__ __forceinline__ double block_sum_double(double v, double *scratch, ui
 // `ku` holds Q_bin(u) codes, `kp_of_row` gives the weight code of a row (used only if the
 // survivor list overflowed).  Ends with a barrier; u_f holds u' afterwards.
 template <uint32_t Dp, typename KpOfRow>
-__device__ __forceinline__ void finish_hop(const HopArgs &a, uint32_t q, uint32_t h, uint32_t r0, uint32_t S,
-                                           uint32_t n_live, const uint32_t *live_row, const uint8_t *live_kp,
-                                           KpOfRow kp_of_row, const short *ku, float *u_f, float *o_f, uint32_t tid)
+__device__ __forceinline__ void readout_sparse(const HopArgs &a, uint32_t h, uint32_t r0, uint32_t S, uint32_t n_live,
+                                               const uint32_t *live_row, const uint8_t *live_kp, KpOfRow kp_of_row,
+                                               float *o_f, uint32_t tid)
 {
-    const QFmt fa = a.act[h], fw = a.w[h], fb = a.bin;
+    const QFmt fa = a.act[h];
     const int maxa = (1 << (fa.iwl + fa.frac)) - 1;
-    const int maxw = (1 << (fw.iwl + fw.frac)) - 1;
-    const uint32_t D = a.D;
     const uint32_t nthreads = blockDim.x;
     for (uint32_t c = tid; c < Dp; c += nthreads) {
         const uint8_t *vb = (const uint8_t *)a.vals + (size_t)h * a.hop_stride + (size_t)r0 * Dp + c;
@@ -266,6 +264,17 @@ __device__ __forceinline__ void finish_hop(const HopArgs &a, uint32_t q, uint32_
         o_f[c] = (float)acc / (float)(1 << fa.frac);
     }
     __syncthreads();
+}
+
+// lin_map + hop update from o_f (any read-out) and the Q_bin(u) codes in `ku`; ends with a barrier
+template <uint32_t Dp>
+__device__ __forceinline__ void linmap_update(const HopArgs &a, uint32_t q, uint32_t h, const short *ku, float *u_f,
+                                              const float *o_f, uint32_t tid)
+{
+    const QFmt fa = a.act[h], fw = a.w[h], fb = a.bin;
+    const int maxw = (1 << (fw.iwl + fw.frac)) - 1;
+    const uint32_t D = a.D;
+    const uint32_t nthreads = blockDim.x;
     for (uint32_t o_i = tid; o_i < D; o_i += nthreads) {
         float lu = u_f[o_i];
         if (a.en_lin_map) {
@@ -289,6 +298,15 @@ __device__ __forceinline__ void finish_hop(const HopArgs &a, uint32_t q, uint32_
         u_f[o_i] = un;
     }
     __syncthreads();
+}
+
+template <uint32_t Dp, typename KpOfRow>
+__device__ __forceinline__ void finish_hop(const HopArgs &a, uint32_t q, uint32_t h, uint32_t r0, uint32_t S,
+                                           uint32_t n_live, const uint32_t *live_row, const uint8_t *live_kp,
+                                           KpOfRow kp_of_row, const short *ku, float *u_f, float *o_f, uint32_t tid)
+{
+    readout_sparse<Dp>(a, h, r0, S, n_live, live_row, live_kp, kp_of_row, o_f, tid);
+    linmap_update<Dp>(a, q, h, ku, u_f, o_f, tid);
 }
 
 }  // namespace

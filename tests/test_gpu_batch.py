@@ -323,3 +323,55 @@ def test_answer_mfma_i8_bit_identical_to_float_path(env, oracle, D, V, B):
     for q in range(min(B, 8)):
         lo = oracle.dense_fwd(w_float, u[q], False, (8, 7), (8, 7))
         np.testing.assert_array_equal(logits[q].cpu().numpy(), lo)
+
+
+# ---------------------------------------------------------------------------------------------
+# ATTENTION_MODE 1: float attention over quantized embeddings
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("D,S_list,B", [(60, [1, 2, 10, 50, 64], 10), (128, [33, 300], 6), (256, [7, 129], 4),
+                                        (128, [10000, 4097], 3)])
+def test_hops_float_attention(env, oracle, D, S_list, B):
+    torch, model = env.torch, env.model
+    H, V, iwl = 3, 40, 5
+    frac = 7 - iwl
+    fmt = [(iwl, frac)] * H
+    fmt_w = [(6, 1), (5, 2), (4, 3)]
+    cfg = dict(n_hop=H, dim_emb=D, dim_input=V, attention_mode=1, softmax_variant=0, f_fixed=True, en_lin_map=True,
+               fmt=fmt, fmt_w=fmt_w, fmt_att=list(fmt), fmt_bin=(iwl, frac))
+    rng = np.random.default_rng(D + B)
+    wts = weights(D, H, D, V, 1.0, with_emb=False)
+    net = model.QNet(cfg, wts)
+    Dp = net.Dp
+    n_slots = np.array([S_list[i % len(S_list)] for i in range(B)], np.int64)
+    row_off = np.concatenate([[0], np.cumsum(n_slots)]).astype(np.int32)
+    R = int(row_off[-1])
+    keys = np.zeros((H, R, Dp), np.int8); vals = np.zeros((H, R, Dp), np.int8)
+    keys[:, :, :D] = np.clip(np.rint(rng.normal(0, 12, (H, R, D))), -127, 127)
+    vals[:, :, :D] = np.clip(np.rint(rng.normal(0, 40, (H, R, D))), -127, 127)
+    u0 = (np.clip(np.rint(rng.normal(0, 6, (B, D))), -127, 127) / (1 << fmt_w[0][1])).astype(np.float32)
+    dk = torch.from_numpy(model.to_signmag(keys)).to(env.dev); dv = torch.from_numpy(model.to_signmag(vals)).to(env.dev)
+    u_out, taps = net.hops(dk, dv, torch.from_numpy(row_off).to(env.dev), int(n_slots.max()),
+                           torch.from_numpy(u0).to(env.dev), taps=True)
+    torch.cuda.synchronize()
+    g_scores = taps.scores.cpu().numpy(); g_probs = taps.probs.cpu().numpy()
+    g_o = taps.o.cpu().numpy(); g_u = taps.u.cpu().numpy()
+    m = oracle.make_model(cfg, wts)
+    excused = 0
+    for q in range(B):
+        a, b = int(row_off[q]), int(row_off[q + 1])
+        kf = np.stack([keys[h, a:b, :D].astype(np.float32) / (1 << fmt_w[h][1]) for h in range(H)])
+        vf = np.stack([vals[h, a:b, :D].astype(np.float32) / (1 << fmt_w[h][1]) for h in range(H)])
+        _, t = oracle.forward_mem(m, kf, vf, u0[q])
+        for h in range(H):
+            np.testing.assert_array_equal(g_scores[h, a:b], t["scores"][h])          # exact integers
+            np.testing.assert_allclose(g_probs[h, a:b], t["probs"][h], rtol=1e-5, atol=1e-7)
+            # float read-out: sum order differs from the reference's serial loop
+            np.testing.assert_allclose(g_o[q, h], t["o"][h], rtol=1e-5, atol=2e-5)
+            if not np.array_equal(g_u[q, h], t["u"][h]):
+                # only where lu + o sits within the float tolerance of a quantisation step
+                x = (t["lu"][h].astype(np.float64) + t["o"][h]) * (1 << frac)
+                bad = g_u[q, h] != t["u"][h]
+                assert np.all(np.abs(x[bad] - np.rint(x[bad])) < 1e-3), f"u differs away from a step q{q} h{h}"
+                excused += 1
+                break
+    assert excused <= max(1, B // 4)
