@@ -82,6 +82,21 @@ class Oracle:
         L.qo_argmax_hi.restype = u; L.qo_argmax_hi.argtypes = [_f32p, u]
         L.qo_cross_entropy_run.restype = u
         L.qo_cross_entropy_run.argtypes = [_f32p, _f32p, u, _f32p, C.POINTER(u), _f32p]
+        b = C.c_bool
+        L.qo_dot_mat_vec_bwd.restype = None
+        L.qo_dot_mat_vec_bwd.argtypes = [_f32p] * 5 + [u, u, b, b, u, u]
+        L.qo_dot_mat_vec_bwd_appx.restype = None
+        L.qo_dot_mat_vec_bwd_appx.argtypes = [_f32p] * 5 + [u, u, b, u, u, u, b]
+        L.qo_softmax_bwd.restype = None
+        L.qo_softmax_bwd.argtypes = [_f32p] * 3 + [u, b]
+        L.qo_dense_bwd.restype = None
+        L.qo_dense_bwd.argtypes = [_f32p] * 6 + [u, u, C.c_char_p, b, u, u]
+        L.qo_dense_mat_bwd.restype = None
+        L.qo_dense_mat_bwd.argtypes = [_f32p] * 5 + [u, u, u, b, u, u]
+        L.qo_mat_w_up.restype = f
+        L.qo_mat_w_up.argtypes = [_f32p, _f32p, u, u, u, f, f, f, b, u, u]
+        L.qo_dup_grad_bwd.restype = None
+        L.qo_dup_grad_bwd.argtypes = [_f32p] * 3 + [u, b, u, u]
         L.qo_memn2n_forward.restype = u
         L.qo_memn2n_forward.argtypes = [C.POINTER(QoModel), _f32p, u, _f32p, C.POINTER(QoTaps)]
         L.qo_memn2n_forward_mem.restype = u
@@ -167,6 +182,53 @@ class Oracle:
         cost = np.zeros(1, np.float32); cnt = C.c_uint(0); grad = np.empty_like(h)
         pred = self.L.qo_cross_entropy_run(_fp(h), _fp(y), h.size, _fp(cost), C.byref(cnt), _fp(grad))
         return int(pred), float(cost[0]), int(cnt.value), grad
+
+    # ---- training verbs ----
+    def dot_mat_vec_bwd(self, mat, vec, grad_in, f_trans, f_fixed, fmt_m, appx_bits=None):
+        mat = np.ascontiguousarray(mat, np.float32); vec = np.ascontiguousarray(vec, np.float32)
+        grad_in = np.ascontiguousarray(grad_in, np.float32)
+        r, c = mat.shape
+        gm = np.zeros((r, c), np.float32); gv = np.zeros(r if f_trans else c, np.float32)
+        if appx_bits is None:
+            self.L.qo_dot_mat_vec_bwd(_fp(mat), _fp(vec), _fp(grad_in), _fp(gm), _fp(gv), r, c, f_trans, f_fixed,
+                                      fmt_m[0], fmt_m[1])
+        else:
+            self.L.qo_dot_mat_vec_bwd_appx(_fp(mat), _fp(vec), _fp(grad_in), _fp(gm), _fp(gv), r, c, f_fixed,
+                                           fmt_m[0], fmt_m[1], appx_bits, f_trans)
+        return gm, gv
+
+    def softmax_bwd(self, out_vec, grad_in, shift_based=False):
+        out_vec = np.ascontiguousarray(out_vec, np.float32); grad_in = np.ascontiguousarray(grad_in, np.float32)
+        g = np.empty_like(out_vec)
+        self.L.qo_softmax_bwd(_fp(out_vec), _fp(grad_in), _fp(g), out_vec.size, shift_based)
+        return g
+
+    def dense_bwd(self, w, w_del, x, out, grad_in, f_fixed, fmt_w, act=b"NULL"):
+        w = np.ascontiguousarray(w, np.float32); w_del = np.array(w_del, np.float32, copy=True)
+        x = np.ascontiguousarray(x, np.float32); out = np.ascontiguousarray(out, np.float32)
+        gi = np.array(grad_in, np.float32, copy=True); go = np.zeros(w.shape[1], np.float32)
+        self.L.qo_dense_bwd(_fp(w), _fp(w_del), _fp(x), _fp(out), _fp(gi), _fp(go), w.shape[1], w.shape[0], act,
+                            f_fixed, fmt_w[0], fmt_w[1])
+        return w_del, go, gi
+
+    def dense_mat_bwd(self, in_mat, w, w_del, grad_in, f_fixed, fmt):
+        in_mat = np.ascontiguousarray(in_mat, np.float32); w = np.ascontiguousarray(w, np.float32)
+        w_del = np.array(w_del, np.float32, copy=True); grad_in = np.ascontiguousarray(grad_in, np.float32)
+        go = np.zeros_like(in_mat)
+        self.L.qo_dense_mat_bwd(_fp(in_mat), _fp(w), _fp(w_del), _fp(grad_in), _fp(go), w.shape[1], w.shape[0],
+                                in_mat.shape[0], f_fixed, fmt[0], fmt[1])
+        return w_del, go
+
+    def mat_w_up(self, w, w_del, batch, lr, lam, max_norm, f_fixed, fmt):
+        w = np.array(w, np.float32, copy=True); w_del = np.array(w_del, np.float32, copy=True)
+        norm = self.L.qo_mat_w_up(_fp(w), _fp(w_del), w.shape[1], w.shape[0], batch, lr, lam, max_norm, f_fixed,
+                                  fmt[0], fmt[1])
+        return w, w_del, float(norm)
+
+    def dup_grad_bwd(self, a, b, f_fixed, fmt):
+        a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32); out = np.empty_like(a)
+        self.L.qo_dup_grad_bwd(_fp(a), _fp(b), _fp(out), a.size, f_fixed, fmt[0], fmt[1])
+        return out
 
     # ---- composite ----
     def make_model(self, cfg: dict, weights: dict):

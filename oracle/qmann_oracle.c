@@ -396,6 +396,188 @@ unsigned qo_cross_entropy_run(const float *h, const float *y, unsigned dim,
 }
 
 /* ------------------------------------------------------------------------ */
+/* training verbs (restated from CUDA text only)                             */
+/* ------------------------------------------------------------------------ */
+
+/* lib/layer_cuda.cu:695-738 (_cuda_mat_mat_product): out[R][C] = Qo(sum_t mul(a[R][t], b[t][C])) */
+static void mat_mat(const float *a, const float *b, float *out, unsigned R, unsigned C, unsigned K, bool fixed,
+                    unsigned iwl, unsigned frac, unsigned iwl_o, unsigned frac_o, bool accum)
+{
+    for (unsigned r = 0; r < R; r++)
+        for (unsigned c = 0; c < C; c++) {
+            float sum = 0;
+            for (unsigned t = 0; t < K; t++) {
+                float p = fixed ? qo_fixed_mul(a[r * K + t], b[c + C * t], iwl, frac, iwl, frac)
+                                : a[r * K + t] * b[c + C * t];
+                sum += p;
+            }
+            float v = fixed ? qo_quant(sum, iwl_o, frac_o) : sum;
+            if (accum) out[r * C + c] += v; else out[r * C + c] = v;
+        }
+}
+
+/* lib/layer_cuda.cu:547-690 (_cuda_mat_trans_mat_product[_accum]): out[R][C] = sum_t a[t][R] . b[t][C] */
+static void mat_trans_mat(const float *a, const float *b, float *out, unsigned R, unsigned C, unsigned K, bool fixed,
+                          unsigned iwl, unsigned frac, unsigned iwl_o, unsigned frac_o, bool accum)
+{
+    for (unsigned r = 0; r < R; r++)
+        for (unsigned c = 0; c < C; c++) {
+            float sum = 0;
+            for (unsigned t = 0; t < K; t++) {
+                float p = fixed ? qo_fixed_mul(a[r + R * t], b[c + C * t], iwl, frac, iwl, frac)
+                                : a[r + R * t] * b[c + C * t];
+                sum += p;
+            }
+            float v = fixed ? qo_quant(sum, iwl_o, frac_o) : sum;
+            if (accum) out[r * C + c] += v; else out[r * C + c] = v;
+        }
+}
+
+void qo_dot_mat_vec_bwd(const float *mat, const float *vec, const float *grad_in, float *grad_out_mat,
+                        float *grad_out_vec, unsigned r, unsigned c, bool f_trans, bool f_fixed,
+                        unsigned iwl_m, unsigned frac_m)
+{
+    const unsigned io = 1, fo = iwl_m + frac_m - 1;           /* gradients leave in Q(1.wl-2) */
+    if (f_trans) {
+        mat_mat(vec, grad_in, grad_out_mat, r, c, 1, f_fixed, iwl_m, frac_m, io, fo, false);      /* :2586 */
+        for (unsigned i = 0; i < r; i++) {                                                        /* :2587 */
+            float sum = 0;
+            for (unsigned j = 0; j < c; j++) {
+                float p = f_fixed ? qo_fixed_mul(mat[i * c + j], grad_in[j], iwl_m, frac_m, iwl_m, frac_m)
+                                  : mat[i * c + j] * grad_in[j];
+                sum += p;
+            }
+            grad_out_vec[i] = f_fixed ? qo_quant(sum, io, fo) : sum;
+        }
+    } else {
+        mat_mat(grad_in, vec, grad_out_mat, r, c, 1, f_fixed, iwl_m, frac_m, io, fo, false);      /* :2595 */
+        mat_trans_mat(grad_in, mat, grad_out_vec, 1, c, r, f_fixed, iwl_m, frac_m, io, fo, false); /* :2596 */
+    }
+}
+
+/* the operand transform shared by forward and backward of the approximate attention (:383-420, :777-817) */
+static void appx_transform(float m, float v, unsigned iwl, uint32_t *fm, uint32_t *fv, float *sm, float *sv)
+{
+    const unsigned frac = 31 - iwl;
+    uint32_t a = (uint32_t)qo_float2fixed(m, iwl, frac), b = (uint32_t)qo_float2fixed(v, iwl, frac);
+    *sm = ((int32_t)a >= 0) ? 1.0f : -1.0f;
+    *sv = ((int32_t)b >= 0) ? 1.0f : -1.0f;
+    uint32_t sa = a & 0x80000000u, sb = b & 0x80000000u, ma = a & 0x7FFFFFFFu, mb = b & 0x7FFFFFFFu;
+    uint32_t mn = ma >= mb ? mb : ma;
+    if (*sm == *sv) { a = sa | (ma - mn); b = sb | (mb - mn); }
+    else if (ma >= mb) { a = sa | (ma + mn); b = sb; }
+    else { a = sa; b = sb | (mb + mn); }
+    *fm = a; *fv = b;
+}
+
+void qo_dot_mat_vec_bwd_appx(const float *mat, const float *vec, const float *grad_in, float *grad_out_mat,
+                             float *grad_out_vec, unsigned r, unsigned c, bool f_fixed, unsigned iwl,
+                             unsigned frac, unsigned num_bit, bool f_trans)
+{
+    if (f_trans) {
+        qo_dot_mat_vec_bwd(mat, vec, grad_in, grad_out_mat, grad_out_vec, r, c, true, f_fixed, iwl, frac);
+        return;
+    }
+    const float k = powf(2, (int)QO_ATTENTION_CONST_SCALE);
+    for (unsigned i = 0; i < r; i++)                               /* _cuda_backprop_grad_out_mat */
+        for (unsigned j = 0; j < c; j++) {
+            uint32_t fm, fv; float sm, sv;
+            appx_transform(mat[i * c + j], vec[j], iwl, &fm, &fv, &sm, &sv);
+            float ta = 0.0f;
+            for (unsigned b = 0; b < num_bit; b++) {
+                int bm = (int)((fm >> (31 - b)) & 1u), bv = (int)((fv >> (31 - b)) & 1u);
+                if (bm != bv) {
+                    if (b == 0) ta += (bm - bv) * sm * k;
+                    else ta += -1.0 * sv * k * (bm - bv);
+                }
+            }
+            grad_out_mat[i * c + j] = ta * grad_in[i];
+        }
+    for (unsigned j = 0; j < c; j++) {                             /* _cuda_backprop_grad_out_vec */
+        float sum = 0.0f;
+        for (unsigned i = 0; i < r; i++) {
+            uint32_t fm, fv; float sm, sv;
+            appx_transform(mat[i * c + j], vec[j], iwl, &fm, &fv, &sm, &sv);
+            float ta = 0.0f, ga = 0.0f;                            /* ta is NOT reset inside the bit loop */
+            for (unsigned b = 0; b < num_bit; b++) {
+                int bm = (int)((fm >> (31 - b)) & 1u), bv = (int)((fv >> (31 - b)) & 1u);
+                if (bm != bv) {
+                    if (b == 0) ta = -1.0 * (bm - bv) * sv * k;
+                    else ta = 1.0 * sm * k * (bm - bv);
+                }
+                ga += ta;
+            }
+            float t = ga * grad_in[i];
+            sum += t;
+        }
+        grad_out_vec[j] = sum;
+    }
+}
+
+void qo_softmax_bwd(const float *out_vec, const float *grad_in, float *grad_out, unsigned dim, bool f_shift_based)
+{
+    float sum = 0.0f;
+    for (unsigned i = 0; i < dim; i++) { float t = out_vec[i] * grad_in[i]; sum += t; }
+    for (unsigned i = 0; i < dim; i++) {
+        if (f_shift_based) grad_out[i] = 0.7 * out_vec[i] * (grad_in[i] - sum);
+        else grad_out[i] = out_vec[i] * (grad_in[i] - sum);
+    }
+}
+
+void qo_dense_bwd(const float *w, float *w_del, const float *in, const float *out, float *grad_in, float *grad_out,
+                  unsigned dim_in, unsigned dim_out, const char *act, bool f_fixed, unsigned iwl_w, unsigned frac_w)
+{
+    if (act && !strcmp(act, "SIGMOID"))
+        for (unsigned i = 0; i < dim_out; i++) {
+            double g = grad_in[i] * out[i] * (1.0 - out[i]);
+            grad_in[i] = f_fixed ? qo_quant((float)g, iwl_w, frac_w) : (float)g;
+        }
+    else if (act && !strcmp(act, "RELU"))
+        for (unsigned i = 0; i < dim_out; i++) {
+            float g = out[i] > 0.0f ? grad_in[i] : 0.0f;
+            grad_in[i] = f_fixed ? qo_quant(g, iwl_w, frac_w) : g;
+        }
+    mat_mat(grad_in, in, w_del, dim_out, dim_in, 1, false, 0, 0, 0, 0, true);                  /* :3276 */
+    mat_trans_mat(w, grad_in, grad_out, dim_in, 1, dim_out, false, 0, 0, 0, 0, false);         /* :3284 */
+}
+
+void qo_dense_mat_bwd(const float *in_mat, const float *w, float *w_del, const float *grad_in, float *grad_out,
+                      unsigned dim_in, unsigned dim_out, unsigned dim_len, bool f_fixed, unsigned iwl, unsigned frac)
+{
+    mat_trans_mat(grad_in, in_mat, w_del, dim_out, dim_in, dim_len, false, 0, 0, 0, 0, true);  /* :3592 */
+    mat_mat(grad_in, w, grad_out, dim_len, dim_in, dim_out, f_fixed, iwl, frac, 1, iwl + frac - 1, false); /* :3600 */
+}
+
+float qo_mat_w_up(float *w, float *w_del, unsigned dim_in, unsigned dim_out, unsigned batch_size, float lr,
+                  float lambda, float max_grad_l2_norm, bool f_fixed, unsigned iwl, unsigned frac)
+{
+    float norm = 0.0f;                                           /* sum over rows of the row 2-norms (:1596-1622) */
+    for (unsigned o = 0; o < dim_out; o++) {
+        float sum = 0.0f;
+        for (unsigned i = 0; i < dim_in; i++) { float t = w_del[o * dim_in + i] * w_del[o * dim_in + i]; sum += t; }
+        norm += sqrtf(sum);
+    }
+    for (unsigned k = 0; k < dim_in * dim_out; k++) {
+        float step = (norm > max_grad_l2_norm) ? lr / batch_size * w_del[k] * max_grad_l2_norm / norm
+                                               : lr / batch_size * w_del[k];
+        float decay = lr * lambda * w[k];
+        if (f_fixed) {
+            w[k] += qo_quant(step, iwl, frac) + qo_quant(decay, iwl, frac);
+            w[k] = qo_quant(w[k], iwl, frac);
+        } else {
+            w[k] += step + decay;
+        }
+        w_del[k] = 0.0f;
+    }
+    return norm;
+}
+
+void qo_dup_grad_bwd(const float *a, const float *b, float *out, unsigned dim, bool f_fixed, unsigned iwl, unsigned frac)
+{
+    qo_sum_vec_fwd(a, b, out, dim, f_fixed, 1, iwl + frac - 1);
+}
+
+/* ------------------------------------------------------------------------ */
 /* composite forward                                                         */
 /* ------------------------------------------------------------------------ */
 

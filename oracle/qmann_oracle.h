@@ -88,6 +88,29 @@ unsigned qo_argmax_hi(const float *in, unsigned dim);
 unsigned qo_cross_entropy_run(const float *h, const float *y, unsigned dim,
                               float *cost_acc, unsigned *m_cnt_acc, float *grad_out);
 
+/* ---- training verbs; restated from CUDA text, parity unpinned ---- */
+/* lib/layer_cuda.cu:2560-2665 */
+void qo_dot_mat_vec_bwd(const float *mat, const float *vec, const float *grad_in, float *grad_out_mat,
+                        float *grad_out_vec, unsigned r, unsigned c, bool f_trans, bool f_fixed,
+                        unsigned iwl_m, unsigned frac_m);
+/* lib/layer_cuda.cu:2666-2767 with the surrogate-gradient kernels :742-1463 */
+void qo_dot_mat_vec_bwd_appx(const float *mat, const float *vec, const float *grad_in, float *grad_out_mat,
+                             float *grad_out_vec, unsigned r, unsigned c, bool f_fixed, unsigned iwl,
+                             unsigned frac, unsigned num_bit, bool f_trans);
+/* lib/layer_cuda.cu:2062-2135 */
+void qo_softmax_bwd(const float *out_vec, const float *grad_in, float *grad_out, unsigned dim, bool f_shift_based);
+/* lib/layer_cuda.cu:3232-3315: w_del accumulates, grad_out is overwritten */
+void qo_dense_bwd(const float *w, float *w_del, const float *in, const float *out, float *grad_in, float *grad_out,
+                  unsigned dim_in, unsigned dim_out, const char *act, bool f_fixed, unsigned iwl_w, unsigned frac_w);
+/* lib/layer_cuda.cu:3570-3610 */
+void qo_dense_mat_bwd(const float *in_mat, const float *w, float *w_del, const float *grad_in, float *grad_out,
+                      unsigned dim_in, unsigned dim_out, unsigned dim_len, bool f_fixed, unsigned iwl, unsigned frac);
+/* lib/layer_cuda.cu:3317-3363 / :3612-3651 with :1596-1622, :1783-1830; returns the norm it used */
+float qo_mat_w_up(float *w, float *w_del, unsigned dim_in, unsigned dim_out, unsigned batch_size, float lr,
+                  float lambda, float max_grad_l2_norm, bool f_fixed, unsigned iwl, unsigned frac);
+/* lib/layer_cuda.cu:3908-3946 */
+void qo_dup_grad_bwd(const float *a, const float *b, float *out, unsigned dim, bool f_fixed, unsigned iwl, unsigned frac);
+
 /* ---- composite: one query through the test-phase forward, MemN2N/MemN2N.c:2626-2697 ---- */
 #define QO_MAX_HOP 8
 typedef struct {

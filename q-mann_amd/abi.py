@@ -94,6 +94,17 @@ _proto("cuda_copy_mat", None, [_vp, _vp, _u, _u, _b])
 _proto("cuda_accum_mat", None, [_vp, _vp, _u, _u, _b])
 _proto("cuda_set_value", None, [_vp, C.c_float, _u, _u, _u])
 _proto("cuda_copy_dev2host", None, [_vp, _vp, _u])
+_f = C.c_float
+_proto("cuda_dot_mat_vec_bwd", None, [_vp] * 6 + [_u, _u, _b, _b, _u, _u, _u, _u, _u, _b])
+_proto("cuda_dot_mat_vec_bwd_appx", None, [_vp] * 7 + [_u, _u, _b, _u, _u, _u, _u, _b, _b, _u])
+_proto("cuda_softmax_bwd", None, [_vp] * 4 + [_u, _b, _b])
+_proto("cuda_sum_vec_bwd", None, [_vp] * 4 + [_u])
+_proto("cuda_dense_bwd", None, [_vp] * 9 + [_u, _u, C.c_char_p, _b, _u, _u, _u, _u, _u, _b])
+_proto("cuda_dense_w_up", None, [_vp] * 6 + [_u, _u, _u, C.POINTER(_f), C.POINTER(_f), C.POINTER(_f), _b, _u, _u, _u, _b])
+_proto("cuda_dense_mat_bwd", None, [_vp] * 8 + [_u, _u, _u, _b, _u, _u, _u, _b])
+_proto("cuda_dense_mat_w_up", None, [_vp] * 8 + [_u, _u, _u, C.POINTER(_f), C.POINTER(_f), C.POINTER(_f), _b, _u, _u, _u, _b])
+_proto("cuda_dup_grad_bwd", None, [_vp] * 4 + [_u, _b, _u, _u, _u])
+_proto("cuda_activation_bwd", None, [_vp, _vp, _vp, C.c_char_p, _u, _b, _u, _u, _u])
 _proto("qmann_abi_set_softmax_base", None, [C.c_int])
 _proto("qmann_abi_symbol_count", _u, [])
 

@@ -84,3 +84,35 @@ def test_reference_layer_api_drives_our_library(oracle, gold, tmp_path, att_mode
         want_cost -= float(t["out_probs"][y])
     assert match == n_match
     assert cost == pytest.approx(want_cost, rel=1e-4)
+
+
+@pytest.mark.parametrize("binary,mode_name", [("MemN2N_ref", "quantized"), ("MemN2N_ref_mode3", "approximate")])
+def test_unmodified_reference_program_trains_and_tests(gold, tmp_path, binary, mode_name):
+    """oracle/_ref/MemN2N_ref is the reference's whole host program -- MemN2N.c, sample.c, layer.c, common.c
+    compiled where they lie with its own define.h -- linked against libqmann_hip.so in place of the CUDA
+    object.  `./MemN2N 1 1 1 5` (run.sh's command line for task 1, one loop): 100 epochs of SGD, then the
+    test phase.  Every forward, backward and update verb runs on the MI355X through boundary B."""
+    exe = ROOT / "oracle" / "_ref" / binary
+    if not exe.exists():
+        pytest.skip(f"oracle/_ref/{binary} not built (needs /root/reference at build time)")
+    g = gold("babi_qa1_en1k_sets.npz")
+    d = tmp_path / "dataset" / "en_10k_parsed"            # PATH_DATA_SET of the stock define.h
+    d.mkdir(parents=True)
+    (d / "qa1_single-supporting-fact_train_set").write_bytes(g["train_set"].tobytes())
+    (d / "qa1_single-supporting-fact_test_set").write_bytes(g["test_set"].tobytes())
+    with open(tmp_path / "stdout.log", "w") as out:
+        r = subprocess.run([str(exe), "1", "1", "1", "5"], cwd=tmp_path, stdout=out, stderr=subprocess.STDOUT,
+                           timeout=900)
+    text = (tmp_path / "stdout.log").read_text(errors="replace")
+    assert r.returncode == 0, text[-3000:]
+    assert f"ATTENTION MODE : {mode_name}" in text
+    itr = [l for l in text.splitlines() if l.startswith("< ITR")]
+    assert len(itr) == 100
+    err = [float(l.split("error:")[1].split(",")[0]) for l in itr]
+    # training reduces the training error (a functional check of the whole loop, not an accuracy claim: 1 000
+    # stories, 8-bit Q5.2; the Hamming-attention build learns more slowly at this setting)
+    drop, cap = (0.2, 0.75) if mode_name == "quantized" else (0.1, 0.95)
+    assert err[-1] < err[0] - drop, (err[0], err[-1])
+    res = (tmp_path / "result.csv").read_text().strip().split(",")
+    err_test = float(res[10])
+    assert 0.0 <= err_test < cap, err_test                      # chance is 5 of 6 wrong
