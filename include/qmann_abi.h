@@ -26,9 +26,10 @@
  *
  * Status of each group is given in its comment: FORWARD = real HIP kernels
  * (hot path, parity-tested); UTIL = allocation / copy helpers, real;
- * TRAIN = backward / weight-update verbs, outside the hot-path scope of this
- * library: the symbols exist so that the host links,
- * and calling one aborts with a message instead of silently doing nothing.
+ * TRAIN = backward / weight-update verbs: functional
+ * HIP, one thread per output element with the reference's serial reduction
+ * order (bit-identical gradients, parity-tested), not tuned -- enough for the
+ * unmodified MemN2N.c to train and test end to end on the GPU.
  */
 #ifndef QMANN_ABI_H
 #define QMANN_ABI_H
