@@ -59,6 +59,8 @@ WORKLOADS = {
     # sample.c, replicated), 3 hops, int8, EN_MQ formats, the WHOLE forward from bag-of-words input:
     # story + question embedding, hops, answer layer
     "babi_task1_bow": dict(S=10, D=60, V=30, B=262144, mode=2, nb=8, ans="f32", bow=True),
+    # the same forward fed with the compact wire format: uint16 word indices instead of float bag-of-words rows
+    "babi_task1_idx": dict(S=10, D=60, V=30, B=262144, mode=2, nb=8, ans="f32", bow=True, idx=True),
 }
 KERNEL_OF_MODE = {1: "k_hops_float", 2: "k_hops_fixed", 3: "k_hops_ham", 10: "k_hops_ham", 11: "k_hops_ham"}
 
@@ -126,10 +128,30 @@ def run_bow(args, wl, net, cfg, wts, dev, rank, world, model):
     ns_all = np.tile(n_sen, rep)
     row_off = torch.from_numpy(np.concatenate([[0], np.cumsum(ns_all)]).astype(np.int32)).to(dev)
     max_slots = int(n_sen.max())
+    use_idx = bool(wl.get("idx"))
+    if use_idx:
+        dd = int(g["dim_dict"])
+
+        def to_words(bow, nd, width, with_time):
+            out = np.full((bow.shape[0], width), 0xFFFF, np.uint16)
+            for r, row in enumerate(bow):
+                ent = [k for k in np.flatnonzero(row[:nd]) for _ in range(int(row[k]))]
+                if with_time:
+                    ent.append(nd + int(np.flatnonzero(row[nd:])[0]))
+                out[r, :len(ent)] = ent
+            return out
+        sw = torch.from_numpy(np.tile(to_words(g["story"], dd, 8, True), (rep, 1)).view(np.int16)).to(dev)
+        qw = torch.from_numpy(np.tile(to_words(g["question"], cfg["dim_input"], 8, False), (rep, 1)).view(np.int16)).to(dev)
+        net.make_tables()
     torch.cuda.synchronize()
 
     def step():
-        return net.forward_bow(story, ques, row_off, max_slots, answer=ans)
+        if not use_idx:
+            return net.forward_bow(story, ques, row_off, max_slots, answer=ans)
+        keys, vals, u0 = net.embed_idx(sw, qw)
+        u = net.hops(keys, vals, row_off, max_slots, u0)
+        pred, _, cost, match = net.answer(u, ans)
+        return dict(pred=pred, cost=cost, match=match)
 
     for _ in range(args.warmup):
         out = step()
@@ -152,6 +174,8 @@ def run_bow(args, wl, net, cfg, wts, dev, rank, world, model):
         elapsed = float(t.item())
     rows = int(row_off[-1])
     bytes_in = rows * cfg["dim_input"] * 4 + B * cfg["dim_input"] * 4           # BoW floats read by the embedding
+    if use_idx:
+        bytes_in = rows * 8 * 2 + B * 8 * 2                                      # uint16 word lists
     res = {
         "metric": "queries/sec", "value": world * B * args.steps / elapsed, "unit": "queries/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -160,6 +184,7 @@ def run_bow(args, wl, net, cfg, wts, dev, rank, world, model):
         "config": {"workload": args.workload, "slots": "2..10 (mean 5.9)", "dim_emb": 60, "dim_input": cfg["dim_input"],
                    "hops": 3, "queries_per_gpu": B, "format": "Q5.2 + EN_MQ weight formats", "attention_mode": 2,
                    "stages": "embed_story + embed_query + hops + answer",
+                   "input": "uint16 word indices" if use_idx else "float bag-of-words",
                    "parallelism": f"replicas x{world}, query-sharded"},
         "roofline": {"bound": "hbm", "kernel": "whole forward (latency bound at these sizes)",
                      "achieved": bytes_in * args.steps / elapsed / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -147,6 +147,20 @@ int qmann_embed_story(const qmann_net *net, const float *story, uint32_t rows_to
 int qmann_embed_query(const qmann_net *net, const float *question, const float *w_q, float *u0,
                       uint32_t n_query, void *stream);
 
+/* Compact wire format for stories: word indices instead of float bag-of-words
+ * rows.  words: uint16 [rows][max_words] (max_words <= 16, unused entries 0xFFFF); with time_last the
+ * last valid entry of a row is its time-encoding index (bag-of-words entry SET to 1; word entries
+ * COUNT occurrences -- MemN2N/sample.c:466-475, 544-548).  Tables: int8 [V][Dp] two's-complement
+ * codes of Q(w[h]) made by qmann_quantize_table_i8 from the float [D][V] matrices.  Results are
+ * bit-identical to qmann_embed_story / qmann_embed_query on the equivalent bag-of-words input. */
+int qmann_quantize_table_i8(const float *w, int8_t *table, uint32_t dim_emb, uint32_t dim_emb_pad,
+                            uint32_t dim_input, qmann_fmt fmt, void *stream);
+int qmann_embed_story_idx(const qmann_net *net, const uint16_t *words, uint32_t rows_total, uint32_t max_words,
+                          int time_last, const int8_t *const *t_a, const int8_t *const *t_c, int8_t *keys,
+                          int8_t *vals, size_t hop_stride, void *stream);
+int qmann_embed_query_idx(const qmann_net *net, const uint16_t *words, uint32_t max_words, const int8_t *t_q,
+                          float *u0, uint32_t n_query, void *stream);
+
 /* bytes of LDS one workgroup of qmann_hops_i8 needs for `max_slots` slots (for sizing checks) */
 size_t qmann_hops_lds_bytes(uint32_t max_slots);
 

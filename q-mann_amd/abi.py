@@ -111,7 +111,6 @@ _proto("qmann_abi_symbol_count", _u, [])
 # ---- batched int8 API (include/qmann_batch.h) ----
 _proto("qmann_hops_lds_bytes", C.c_size_t, [C.c_uint32])
 _proto("qmann_quantize_i8", C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, C.c_uint32, Fmt, C.c_int, _vp])
-_proto("qmann_debug_set_tune", None, [C.c_int])
 _proto("qmann_hops_i8", C.c_int, [C.POINTER(Net), _vp, _vp, C.c_size_t, _vp, C.c_uint32, _vp, _vp,
                                   C.POINTER(Taps), C.c_uint32, _vp])
 _proto("qmann_pack_bitplanes", C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, C.c_uint32, _vp])
@@ -121,6 +120,10 @@ _proto("qmann_answer_f32", C.c_int, [C.POINTER(Net), _vp, _vp, _vp, _vp, _vp, _v
 _proto("qmann_answer_i8", C.c_int, [C.POINTER(Net), _vp, Fmt, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_uint32, _vp])
 _proto("qmann_embed_story", C.c_int, [C.POINTER(Net), _vp, C.c_uint32, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp,
                                       C.c_size_t, _vp])
+_proto("qmann_quantize_table_i8", C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, Fmt, _vp])
+_proto("qmann_embed_story_idx", C.c_int, [C.POINTER(Net), _vp, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(_vp),
+                                          C.POINTER(_vp), _vp, _vp, C.c_size_t, _vp])
+_proto("qmann_embed_query_idx", C.c_int, [C.POINTER(Net), _vp, C.c_uint32, _vp, _vp, C.c_uint32, _vp])
 _proto("qmann_embed_query", C.c_int, [C.POINTER(Net), _vp, _vp, _vp, C.c_uint32, _vp])
 
 

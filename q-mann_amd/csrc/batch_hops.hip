@@ -187,8 +187,6 @@ __global__ void k_quantize_i8(const float *__restrict__ src, int8_t *__restrict_
 
 inline bool fmt8(qmann_fmt f) { return f.iwl + f.frac >= 1 && f.iwl + f.frac <= 7; }
 
-int g_tune = 0;
-
 }  // namespace
 
 extern "C" {
@@ -198,9 +196,6 @@ int qmann_hops_appx_impl(const qmann_net *net, const int8_t *keys, const int8_t 
                          const qmann_taps *taps, uint32_t n_query, void *stream);   // batch_hops_ham.hip
 
 int qmann_hops_float_impl(const HopArgs &a, uint32_t Dp, uint32_t max_slots, uint32_t n_query, void *stream);  // batch_hops_float.hip
-
-// development switch: selects a compiled tuning variant of the D=128 scan (0 = shipped)
-void qmann_debug_set_tune(int v) { g_tune = v; }
 
 size_t qmann_hops_lds_bytes(uint32_t max_slots)
 {
@@ -281,20 +276,7 @@ int qmann_hops_i8(const qmann_net *net, const int8_t *keys, const int8_t *vals, 
     } while (0)
     if (net->dim_emb_pad == 64) QM_LAUNCH_HOPS(4, kUnrollDefault, true, 1);
     else if (net->dim_emb_pad == 256) QM_LAUNCH_HOPS(16, kUnrollDefault, true, 1);
-    else {
-        switch (g_tune) {                 // tuning variants (bench_variants.py); 0 is the shipped one
-        case 1: QM_LAUNCH_HOPS(8, 4, false, 1); break;
-        case 2: QM_LAUNCH_HOPS(8, 8, false, 1); break;
-        case 3: QM_LAUNCH_HOPS(8, 8, true, 1); break;
-        case 4: QM_LAUNCH_HOPS(8, 8, false, 1); break;
-        case 5: QM_LAUNCH_HOPS(8, 4, true, 8); break;
-        case 6: QM_LAUNCH_HOPS(8, 8, true, 4); break;
-        case 7: QM_LAUNCH_HOPS(8, 6, true, 1); break;
-        case 8: QM_LAUNCH_HOPS(8, 12, true, 1); break;
-        case 9: QM_LAUNCH_HOPS(8, 2, true, 8); break;
-        default: QM_LAUNCH_HOPS(8, kUnrollDefault, true, 1); break;
-        }
-    }
+    else QM_LAUNCH_HOPS(8, kUnrollDefault, true, 1);
 #undef QM_LAUNCH_HOPS
     QM_LAUNCH_CHECK();
     return QMANN_OK;

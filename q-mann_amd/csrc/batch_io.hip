@@ -290,6 +290,115 @@ k_embed_query(const float *__restrict__ question, const float *__restrict__ w_q,
     }
 }
 
+// ---------------------------------------------------------------------------
+// Story embedding from WORD INDICES.  A bag-of-words row has at most a
+// handful of non-zeros, so the dense X . W^T of dense_mat_fwd is a gather-sum over table rows.
+// Wire format: uint16 [rows][max_words], unused entries 0xFFFF; with `time_last` the last valid
+// entry of a row is its time-encoding index, whose bag-of-words entry is SET to 1 while word
+// entries COUNT occurrences (MemN2N/sample.c:466-475, 544-548).  Tables are int8 [V][Dp]
+// two's-complement codes of Q(w[h]) (transposed, so a word's row is contiguous).  For an integer
+// count c the reference term Qw(Qw(c) . Qw(W)) is clamp(c' . kw, +-max) with c' = the count
+// saturated to the format (a code needs no truncation when one factor is an integer), so the
+// result is bit-identical to the float path.  One wavefront per story row, lane = column.
+// ---------------------------------------------------------------------------
+constexpr int kMaxWords = 16;
+
+struct EmbedIdxArgs {
+    const uint16_t *words;
+    const int8_t *t_a[QMANN_MAX_HOP];
+    const int8_t *t_c[QMANN_MAX_HOP];
+    int8_t *keys;
+    int8_t *vals;
+    size_t hop_stride;
+    uint32_t n_hop, D, Dp, V, rows, max_words, time_last;
+    QFmt act[QMANN_MAX_HOP], w[QMANN_MAX_HOP], att[QMANN_MAX_HOP];
+};
+
+// integer count -> value the format can hold: Qw(c) for c >= 0 (saturates at max / 2^frac, truncated)
+__device__ __forceinline__ float count_value(uint32_t c, QFmt f) { return qm_quant((float)c, f.iwl, f.frac); }
+
+__global__ void __launch_bounds__(kBlock)
+k_embed_story_idx(const EmbedIdxArgs a)
+{
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const size_t stride = (size_t)gridDim.x * kWaves;
+    for (size_t s = (size_t)blockIdx.x * kWaves + threadIdx.x / kWave; s < a.rows; s += stride) {
+        // distinct entries and their bag-of-words values (wave-uniform, <= 16 entries)
+        const uint16_t *wr = a.words + s * a.max_words;
+        uint32_t idx[kMaxWords], cnt[kMaxWords], n = 0, n_valid = 0;
+        for (uint32_t i = 0; i < a.max_words && i < (uint32_t)kMaxWords; i++)
+            if (wr[i] != 0xFFFFu) n_valid = i + 1;
+        for (uint32_t i = 0; i < n_valid; i++) {
+            const uint32_t wdx = wr[i];
+            if (wdx == 0xFFFFu || wdx >= a.V) continue;
+            const bool is_time = a.time_last && (i + 1 == n_valid);
+            uint32_t j = 0;
+            for (; j < n; j++)
+                if (idx[j] == wdx) break;
+            if (j == n) { idx[n] = wdx; cnt[n] = 0; n++; }
+            cnt[j] = is_time ? 1u : cnt[j] + 1u;         // "= 1.0" for the time entry, "+= 1.0" for words
+        }
+        for (uint32_t col = lane; col < a.Dp; col += kWave) {
+            for (uint32_t h = 0; h < a.n_hop; h++) {
+                const QFmt fw = a.w[h];
+                int8_t kcode = 0, vcode = 0;
+                if (col < a.D) {
+                    float sa = 0.0f, sc = 0.0f;
+                    for (uint32_t e = 0; e < n; e++) {
+                        const float x = count_value(cnt[e], fw);
+                        const float wa = qm_decode(a.t_a[h][(size_t)idx[e] * a.Dp + col], fw.frac);
+                        const float wc = qm_decode(a.t_c[h][(size_t)idx[e] * a.Dp + col], fw.frac);
+                        sa += qm_quant(x * wa, fw.iwl, fw.frac);
+                        sc += qm_quant(x * wc, fw.iwl, fw.frac);
+                    }
+                    kcode = sm_byte(qm_quant(sa, fw.iwl, fw.frac), a.att[h]);
+                    vcode = sm_byte(qm_quant(sc, fw.iwl, fw.frac), a.act[h]);
+                }
+                a.keys[(size_t)h * a.hop_stride + s * a.Dp + col] = kcode;
+                a.vals[(size_t)h * a.hop_stride + s * a.Dp + col] = vcode;
+            }
+        }
+    }
+}
+
+// question: word entries only (no time entry, sample.c:557-565); u0[j] = Qw0(sum_k Qw0(Qw0(W[j][k]) . Qw0(c_k)))
+__global__ void __launch_bounds__(kBlock)
+k_embed_query_idx(const uint16_t *__restrict__ words, const int8_t *__restrict__ t_q, float *__restrict__ u0,
+                  uint32_t n_query, uint32_t max_words, uint32_t D, uint32_t Dp, uint32_t V, QFmt fw)
+{
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const size_t stride = (size_t)gridDim.x * kWaves;
+    for (size_t q = (size_t)blockIdx.x * kWaves + threadIdx.x / kWave; q < n_query; q += stride) {
+        const uint16_t *wr = words + q * max_words;
+        uint32_t idx[kMaxWords], cnt[kMaxWords], n = 0;
+        for (uint32_t i = 0; i < max_words && i < (uint32_t)kMaxWords; i++) {
+            const uint32_t wdx = wr[i];
+            if (wdx == 0xFFFFu || wdx >= V) continue;
+            uint32_t j = 0;
+            for (; j < n; j++)
+                if (idx[j] == wdx) break;
+            if (j == n) { idx[n] = wdx; cnt[n] = 0; n++; }
+            cnt[j]++;
+        }
+        for (uint32_t col = lane; col < D; col += kWave) {
+            float s = 0.0f;
+            for (uint32_t e = 0; e < n; e++)
+                s += qm_quant(qm_decode(t_q[(size_t)idx[e] * Dp + col], fw.frac) * count_value(cnt[e], fw), fw.iwl, fw.frac);
+            u0[q * D + col] = qm_quant(s, fw.iwl, fw.frac);
+        }
+    }
+}
+
+// float [D][V] -> int8 two's-complement codes, transposed to [V][Dp] (padding columns zero)
+__global__ void k_quantize_transpose(const float *__restrict__ src, int8_t *__restrict__ dst, uint32_t D, uint32_t V,
+                                     uint32_t Dp, QFmt f)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= V * Dp) return;
+    const uint32_t v = i / Dp, c = i % Dp;
+    dst[i] = (c < D) ? (int8_t)qm_code(src[(size_t)c * V + v], f.iwl, f.frac) : (int8_t)0;
+}
+
 inline bool fmt8(qmann_fmt f) { return f.iwl + f.frac >= 1 && f.iwl + f.frac <= 7; }
 
 }  // namespace
@@ -375,6 +484,61 @@ int qmann_embed_query(const qmann_net *net, const float *question, const float *
     if (n_query >= (1u << 24)) return QMANN_ERANGE;      // one workgroup per query: a launch holds < 2^32 threads
     k_embed_query<<<n_query, kBlock, 0, (hipStream_t)stream>>>(question, w_q, u0, net->dim_emb, net->dim_input,
                                                              QFmt{net->w[0].iwl, net->w[0].frac});
+    QM_LAUNCH_CHECK();
+    return QMANN_OK;
+}
+
+int qmann_quantize_table_i8(const float *w, int8_t *table, uint32_t dim_emb, uint32_t dim_emb_pad, uint32_t dim_input,
+                            qmann_fmt fmt, void *stream)
+{
+    if (!w || !table || dim_emb > dim_emb_pad) return QMANN_EINVAL;
+    if (!fmt8(fmt)) return QMANN_ERANGE;
+    const uint32_t n = dim_input * dim_emb_pad;
+    if (n == 0) return QMANN_OK;
+    k_quantize_transpose<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(w, table, dim_emb, dim_input, dim_emb_pad,
+                                                                         QFmt{fmt.iwl, fmt.frac});
+    QM_LAUNCH_CHECK();
+    return QMANN_OK;
+}
+
+int qmann_embed_story_idx(const qmann_net *net, const uint16_t *words, uint32_t rows_total, uint32_t max_words,
+                          int time_last, const int8_t *const *t_a, const int8_t *const *t_c, int8_t *keys, int8_t *vals,
+                          size_t hop_stride, void *stream)
+{
+    if (!net || !words || !t_a || !t_c || !keys || !vals) return QMANN_EINVAL;
+    if (net->n_hop == 0 || net->n_hop > QMANN_MAX_HOP || net->dim_emb > net->dim_emb_pad) return QMANN_EINVAL;
+    if (max_words == 0 || max_words > (uint32_t)kMaxWords) return QMANN_ERANGE;
+    if (hop_stride < (size_t)rows_total * net->dim_emb_pad) return QMANN_EINVAL;
+    EmbedIdxArgs a{};
+    a.words = words; a.keys = keys; a.vals = vals; a.hop_stride = hop_stride;
+    a.n_hop = net->n_hop; a.D = net->dim_emb; a.Dp = net->dim_emb_pad; a.V = net->dim_input; a.rows = rows_total;
+    a.max_words = max_words; a.time_last = time_last ? 1u : 0u;
+    for (uint32_t h = 0; h < net->n_hop; h++) {
+        if (!t_a[h] || !t_c[h]) return QMANN_EINVAL;
+        if (!fmt8(net->act[h]) || !fmt8(net->w[h]) || !fmt8(net->att[h])) return QMANN_ERANGE;
+        a.t_a[h] = t_a[h]; a.t_c[h] = t_c[h];
+        a.act[h] = QFmt{net->act[h].iwl, net->act[h].frac};
+        a.w[h] = QFmt{net->w[h].iwl, net->w[h].frac};
+        a.att[h] = QFmt{net->att[h].iwl, net->att[h].frac};
+    }
+    if (rows_total == 0) return QMANN_OK;
+    const uint32_t blocks = (rows_total + kWaves - 1) / kWaves;
+    k_embed_story_idx<<<blocks < (1u << 20) ? blocks : (1u << 20), kBlock, 0, (hipStream_t)stream>>>(a);
+    QM_LAUNCH_CHECK();
+    return QMANN_OK;
+}
+
+int qmann_embed_query_idx(const qmann_net *net, const uint16_t *words, uint32_t max_words, const int8_t *t_q, float *u0,
+                          uint32_t n_query, void *stream)
+{
+    if (!net || !words || !t_q || !u0) return QMANN_EINVAL;
+    if (max_words == 0 || max_words > (uint32_t)kMaxWords) return QMANN_ERANGE;
+    if (!fmt8(net->w[0])) return QMANN_ERANGE;
+    if (n_query == 0) return QMANN_OK;
+    const uint32_t blocks = (n_query + kWaves - 1) / kWaves;
+    k_embed_query_idx<<<blocks < (1u << 20) ? blocks : (1u << 20), kBlock, 0, (hipStream_t)stream>>>(
+        words, t_q, u0, n_query, max_words, net->dim_emb, net->dim_emb_pad, net->dim_input,
+        QFmt{net->w[0].iwl, net->w[0].frac});
     QM_LAUNCH_CHECK();
     return QMANN_OK;
 }

@@ -7,6 +7,29 @@
 #include "rt.h"
 #include "../../include/qmann_batch.h"
 
+// launch arguments of every fused hop kernel (a named type: it crosses translation units)
+namespace qmann {
+struct HopArgs {
+    const int8_t *keys;
+    const int8_t *vals;
+    size_t hop_stride;       // bytes between hop planes of the value memory (and of int8 keys)
+    size_t key_hop_stride;   // bytes between hop planes of the key memory (packed-code modes)
+    const uint32_t *row_off;
+    const float *u0;
+    float *u_out;
+    int32_t *tap_codes;
+    float *tap_scores;
+    float *tap_probs;
+    float *tap_o;
+    float *tap_u;
+    const int8_t *lin_map[QMANN_MAX_HOP];
+    uint32_t rows_total;
+    uint32_t n_hop, D, Dp, softmax_base, en_lin_map;
+    QFmt act[QMANN_MAX_HOP], w[QMANN_MAX_HOP], att[QMANN_MAX_HOP], bin;
+};
+}  // namespace qmann
+using qmann::HopArgs;
+
 namespace {
 
 
@@ -33,24 +56,6 @@ constexpr uint32_t kOffRed = kOffMisc + 64;                        // double[8]
 constexpr uint32_t kOffScores = kOffRed + 64;                      // i8    [slots]
 static_assert(kOffScores % 16 == 0, "score bytes must start 16-byte aligned");
 
-struct HopArgs {
-    const int8_t *keys;
-    const int8_t *vals;
-    size_t hop_stride;       // bytes between hop planes of the value memory (and of int8 keys)
-    size_t key_hop_stride;   // bytes between hop planes of the key memory (packed-code modes)
-    const uint32_t *row_off;
-    const float *u0;
-    float *u_out;
-    int32_t *tap_codes;
-    float *tap_scores;
-    float *tap_probs;
-    float *tap_o;
-    float *tap_u;
-    const int8_t *lin_map[QMANN_MAX_HOP];
-    uint32_t rows_total;
-    uint32_t n_hop, D, Dp, softmax_base, en_lin_map;
-    QFmt act[QMANN_MAX_HOP], w[QMANN_MAX_HOP], att[QMANN_MAX_HOP], bin;
-};
 
 template <int CTRL>
 __device__ __forceinline__ int dpp_add(int v)

@@ -132,6 +132,33 @@ class QNet:
                                             question.shape[0], self._s()), "qmann_embed_query")
         return keys, vals, u0
 
+    def make_tables(self):
+        """int8 [V][Dp] gather tables of the embedding matrices (word-index input path)."""
+        def tab(w, fmt):
+            out = torch.empty((self.V, self.Dp), dtype=torch.int8, device=self.dev)
+            abi.check(abi.lib.qmann_quantize_table_i8(_ptr(w), _ptr(out), self.D, self.Dp, self.V, abi.Fmt(*fmt),
+                                                      self._s()), "qmann_quantize_table_i8")
+            return out
+        self.t_q = tab(self.w_q, self.cfg["fmt_w"][0])
+        self.t_a = [tab(self.w_a[h], self.cfg["fmt_w"][h]) for h in range(self.H)]
+        self.t_c = [tab(self.w_c[h], self.cfg["fmt_w"][h]) for h in range(self.H)]
+
+    def embed_idx(self, story_words: torch.Tensor, question_words: torch.Tensor, time_last=True):
+        """story_words int16/uint16-as-int16 [rows][W], question_words [B][Wq] (0xFFFF = unused)."""
+        rows, W = story_words.shape
+        keys = torch.empty((self.H, rows, self.Dp), dtype=torch.int8, device=self.dev)
+        vals = torch.empty_like(keys)
+        ta = (C.c_void_p * self.H)(*[t.data_ptr() for t in self.t_a])
+        tc = (C.c_void_p * self.H)(*[t.data_ptr() for t in self.t_c])
+        abi.check(abi.lib.qmann_embed_story_idx(C.byref(self.net), _ptr(story_words), rows, W, int(time_last), ta, tc,
+                                                _ptr(keys), _ptr(vals), rows * self.Dp, self._s()),
+                  "qmann_embed_story_idx")
+        B, Wq = question_words.shape
+        u0 = torch.empty((B, self.D), dtype=torch.float32, device=self.dev)
+        abi.check(abi.lib.qmann_embed_query_idx(C.byref(self.net), _ptr(question_words), Wq, _ptr(self.t_q), _ptr(u0), B,
+                                                self._s()), "qmann_embed_query_idx")
+        return keys, vals, u0
+
     def hops(self, keys, vals, row_off, max_slots, u0, taps=False, u_out=None):
         """keys/vals int8 [H][rows][Dp]; row_off uint32 (as int32 tensor) [B+1]; u0 [B][D] float."""
         B = u0.shape[0]

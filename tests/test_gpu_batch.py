@@ -375,3 +375,41 @@ def test_hops_float_attention(env, oracle, D, S_list, B):
                 excused += 1
                 break
     assert excused <= max(1, B // 4)
+
+
+# ---------------------------------------------------------------------------------------------
+# word-index wire format
+# ---------------------------------------------------------------------------------------------
+def bow_to_words(bow, dim_dict, max_words, with_time):
+    """float bag-of-words rows -> uint16 word lists (words repeated by count, then the time index)."""
+    out = np.full((bow.shape[0], max_words), 0xFFFF, np.uint16)
+    for r, row in enumerate(bow):
+        ent = []
+        for k in np.flatnonzero(row[:dim_dict]):
+            ent += [k] * int(row[k])
+        if with_time:
+            t = np.flatnonzero(row[dim_dict:])
+            assert len(t) == 1 and row[dim_dict + t[0]] == 1.0
+            ent.append(dim_dict + int(t[0]))
+        assert len(ent) <= max_words
+        out[r, :len(ent)] = ent
+    return out
+
+
+@pytest.mark.parametrize("name", ["babi_qa1_test64.npz", "babi_qa3_test16.npz"])
+def test_embedding_from_word_indices_equals_bag_of_words_path(env, gold, name):
+    torch, model = env.torch, env.model
+    b = gold(name)
+    V, dd = int(b["dim_input"]), int(b["dim_dict"])
+    story = b["story"].astype(np.float32); ques = b["question"].astype(np.float32)
+    # a row with a repeated word, to exercise the counting
+    story[0, 3] += 1.0; ques[0, 4] += 2.0
+    cfg = model.babi_cfg(V, 2, 0)
+    net = model.QNet(cfg, weights(77, 3, 60, V, 1.5))
+    net.make_tables()
+    sw = bow_to_words(story, dd, 12, True); qw = bow_to_words(ques, V, 8, False)
+    k1, v1, u1 = net.embed(torch.from_numpy(story).to(env.dev), torch.from_numpy(ques).to(env.dev))
+    k2, v2, u2 = net.embed_idx(torch.from_numpy(sw.view(np.int16)).to(env.dev), torch.from_numpy(qw.view(np.int16)).to(env.dev))
+    torch.cuda.synchronize()
+    assert torch.equal(k1, k2) and torch.equal(v1, v2) and torch.equal(u1, u2)
+    assert k1.abs().sum().item() > 0
