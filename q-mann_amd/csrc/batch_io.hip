@@ -25,7 +25,7 @@ template <bool PRECOMPUTED>
 __global__ void __launch_bounds__(kBlock)
 k_answer(const float *__restrict__ w_ans, const float *__restrict__ u, const uint32_t *__restrict__ answer,
          uint32_t *__restrict__ pred, float *__restrict__ probs, float *cost, uint32_t *match, uint32_t D,
-         uint32_t V, uint32_t softmax_base)
+         uint32_t V, uint32_t softmax_base, uint32_t n_query)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *us = (float *)smem;            // [D]
@@ -34,7 +34,10 @@ k_answer(const float *__restrict__ w_ans, const float *__restrict__ u, const uin
     __shared__ float red_f[kWaves];
     __shared__ uint32_t red_i[kWaves];
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-    const uint32_t q = blockIdx.x;
+    float cost_acc = 0.0f;              // thread 0 only; added once per workgroup (see k_answer_small)
+    uint32_t match_acc = 0;
+    for (uint32_t q = blockIdx.x; q < n_query; q += gridDim.x) {
+    __syncthreads();                    // the previous query's LDS rows are free again
     if (!PRECOMPUTED) {
         for (uint32_t c = tid; c < D; c += kBlock) us[c] = u[(size_t)q * D + c];
         __syncthreads();
@@ -102,10 +105,74 @@ k_answer(const float *__restrict__ w_ans, const float *__restrict__ u, const uin
         if (answer) {
             const uint32_t y = answer[q];
             if (y < V) {
-                if (cost) atomicAdd(cost, -lg[y]);
-                if (match && y == bi) atomicAdd(match, 1u);
+                cost_acc += -lg[y];
+                match_acc += (y == bi) ? 1u : 0u;
             }
         }
+    }
+    }
+    if (tid == 0 && answer) {
+        if (cost) atomicAdd(cost, cost_acc);
+        if (match && match_acc) atomicAdd(match, match_acc);
+    }
+}
+
+// Answer layer for small dictionaries (V <= 64, bAbI single-task sizes): one WAVEFRONT per query,
+// lane v owns logit v -- the same arithmetic as k_answer without idle threads and block barriers.
+__global__ void __launch_bounds__(kBlock)
+k_answer_small(const float *__restrict__ w_ans, const float *__restrict__ u, const uint32_t *__restrict__ answer,
+               uint32_t *__restrict__ pred, float *__restrict__ probs, float *cost, uint32_t *match, uint32_t D,
+               uint32_t V, uint32_t softmax_base, uint32_t n_query)
+{
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const size_t stride = (size_t)gridDim.x * kWaves;
+    const bool live = lane < V;
+    // cost / match are summed per wavefront and added once: one device-scope atomic per query on a
+    // single word would serialise the whole batch (~12 ns each)
+    float cost_acc = 0.0f;
+    uint32_t match_acc = 0;
+    for (size_t q = (size_t)blockIdx.x * kWaves + threadIdx.x / kWave; q < n_query; q += stride) {
+        float sum = 0.0f;
+        if (live) {
+            const float *wr = w_ans + (size_t)lane * D;
+            const float *uq = u + q * D;
+            for (uint32_t c = 0; c < D; c++) {
+                const float t = wr[c] * uq[c];
+                sum += t;
+            }
+        }
+        float mx = live ? sum : -INFINITY;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float t = __shfl_xor(mx, o);
+            mx = t > mx ? t : mx;
+        }
+        const float e = live ? ((softmax_base == QMANN_SOFTMAX_EXP) ? expf(sum - mx) : exp2f(sum - mx)) : 0.0f;
+        double total = (double)e;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+        const float p = (softmax_base == QMANN_SOFTMAX_EXP) ? (float)((double)e / total) : e / (float)total;
+        if (probs && live) probs[q * V + lane] = p;
+        float bv = live ? p : -INFINITY;
+        uint32_t bi = live ? lane : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float tv = __shfl_xor(bv, o);
+            const uint32_t ti = __shfl_xor(bi, o);
+            if (tv > bv || (tv == bv && ti > bi)) { bv = tv; bi = ti; }   // ties go to the highest index
+        }
+        if (lane == 0) pred[q] = bi;
+        if (answer) {
+            const uint32_t y = answer[q];
+            if (y < V) {
+                cost_acc += -__shfl(p, (int)y);
+                match_acc += (y == bi) ? 1u : 0u;
+            }
+        }
+    }
+    if (answer && lane == 0) {
+        if (cost) atomicAdd(cost, cost_acc);
+        if (match && match_acc) atomicAdd(match, match_acc);
     }
 }
 
@@ -316,6 +383,22 @@ struct EmbedIdxArgs {
 
 // integer count -> value the format can hold: Qw(c) for c >= 0 (saturates at max / 2^frac, truncated)
 __device__ __forceinline__ float count_value(uint32_t c, QFmt f) { return qm_quant((float)c, f.iwl, f.frac); }
+// the same as an integer code in units of 2^-frac
+__device__ __forceinline__ int count_code(uint32_t c, uint32_t frac, int maxw)
+{
+    const uint64_t k = (uint64_t)c << frac;
+    return k > (uint64_t)maxw ? maxw : (int)k;
+}
+// code k in units of 2^-frac_src -> sign-magnitude byte of Q(dst): shift (truncating toward zero) and clamp.
+// The sign of the byte follows the VALUE (a negative value that truncates to zero is "minus zero").
+__device__ __forceinline__ int8_t sm_requant(int k, uint32_t frac_src, QFmt dst)
+{
+    const int maxd = (1 << (dst.iwl + dst.frac)) - 1;
+    const uint32_t mag = (uint32_t)(k < 0 ? -k : k);
+    uint32_t m = dst.frac >= frac_src ? mag << (dst.frac - frac_src) : mag >> (frac_src - dst.frac);
+    if (m > (uint32_t)maxd) m = (uint32_t)maxd;
+    return (int8_t)(m | (k < 0 ? 0x80u : 0u));
+}
 
 __global__ void __launch_bounds__(kBlock)
 k_embed_story_idx(const EmbedIdxArgs a)
@@ -341,18 +424,19 @@ k_embed_story_idx(const EmbedIdxArgs a)
         for (uint32_t col = lane; col < a.Dp; col += kWave) {
             for (uint32_t h = 0; h < a.n_hop; h++) {
                 const QFmt fw = a.w[h];
+                const int maxw = (1 << (fw.iwl + fw.frac)) - 1;
                 int8_t kcode = 0, vcode = 0;
                 if (col < a.D) {
-                    float sa = 0.0f, sc = 0.0f;
+                    int sa = 0, sc = 0;                  // integer codes in units of 2^-frac_w
                     for (uint32_t e = 0; e < n; e++) {
-                        const float x = count_value(cnt[e], fw);
-                        const float wa = qm_decode(a.t_a[h][(size_t)idx[e] * a.Dp + col], fw.frac);
-                        const float wc = qm_decode(a.t_c[h][(size_t)idx[e] * a.Dp + col], fw.frac);
-                        sa += qm_quant(x * wa, fw.iwl, fw.frac);
-                        sc += qm_quant(x * wc, fw.iwl, fw.frac);
+                        const int cc = count_code(cnt[e], fw.frac, maxw);
+                        sa += qm_mul_code(cc, (int)a.t_a[h][(size_t)idx[e] * a.Dp + col], fw.frac, maxw);
+                        sc += qm_mul_code(cc, (int)a.t_c[h][(size_t)idx[e] * a.Dp + col], fw.frac, maxw);
                     }
-                    kcode = sm_byte(qm_quant(sa, fw.iwl, fw.frac), a.att[h]);
-                    vcode = sm_byte(qm_quant(sc, fw.iwl, fw.frac), a.act[h]);
+                    sa = sa > maxw ? maxw : (sa < -maxw ? -maxw : sa);
+                    sc = sc > maxw ? maxw : (sc < -maxw ? -maxw : sc);
+                    kcode = sm_requant(sa, fw.frac, a.att[h]);
+                    vcode = sm_requant(sc, fw.frac, a.act[h]);
                 }
                 a.keys[(size_t)h * a.hop_stride + s * a.Dp + col] = kcode;
                 a.vals[(size_t)h * a.hop_stride + s * a.Dp + col] = vcode;
@@ -417,8 +501,15 @@ int qmann_answer_f32(const qmann_net *net, const float *w_ans, const float *u, c
     if (n_query >= (1u << 24)) return QMANN_ERANGE;      // one workgroup per query: a launch holds < 2^32 threads
     if (lds > 48 * 1024)
         QM_HIP(hipFuncSetAttribute((const void *)k_answer<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    k_answer<false><<<n_query, kBlock, lds, (hipStream_t)stream>>>(w_ans, u, answer, pred, probs, cost, match, D, V,
-                                                                 net->softmax_base);
+    if (V <= (uint32_t)kWave) {
+        const uint32_t blocks = (n_query + kWaves - 1) / kWaves;
+        k_answer_small<<<blocks < 4096u ? blocks : 4096u, kBlock, 0, (hipStream_t)stream>>>(
+            w_ans, u, answer, pred, probs, cost, match, D, V, net->softmax_base, n_query);
+        QM_LAUNCH_CHECK();
+        return QMANN_OK;
+    }
+    k_answer<false><<<n_query < 8192u ? n_query : 8192u, kBlock, lds, (hipStream_t)stream>>>(
+        w_ans, u, answer, pred, probs, cost, match, D, V, net->softmax_base, n_query);
     QM_LAUNCH_CHECK();
     return QMANN_OK;
 }
@@ -446,8 +537,8 @@ int qmann_answer_i8(const qmann_net *net, const int8_t *w_ans_i8, qmann_fmt w_fm
     else return QMANN_EUNSUPPORTED;
     if (lds > 48 * 1024)
         QM_HIP(hipFuncSetAttribute((const void *)k_answer<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    k_answer<true><<<n_query, kBlock, lds, (hipStream_t)stream>>>(logits_ws, nullptr, answer, pred, probs, cost, match,
-                                                                D, V, net->softmax_base);
+    k_answer<true><<<n_query < 8192u ? n_query : 8192u, kBlock, lds, (hipStream_t)stream>>>(
+        logits_ws, nullptr, answer, pred, probs, cost, match, D, V, net->softmax_base, n_query);
     QM_LAUNCH_CHECK();
     return QMANN_OK;
 }
