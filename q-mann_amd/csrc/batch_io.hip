@@ -400,46 +400,99 @@ __device__ __forceinline__ int8_t sm_requant(int k, uint32_t frac_src, QFmt dst)
     return (int8_t)(m | (k < 0 ? 0x80u : 0u));
 }
 
+// 16 lanes per story row (a lane owns 4 adjacent columns = one dword of a table row), 4 rows per
+// wavefront, persistent workgroups.  Duplicate words are found lane-parallel: lane i holds entry i,
+// compares with the row's other entries by shuffles, and the first occurrence carries the count.
+// TAB_LDS: all 2.n_hop tables staged in LDS once per workgroup (bAbI: 11.5 KB).
+template <bool TAB_LDS>
 __global__ void __launch_bounds__(kBlock)
 k_embed_story_idx(const EmbedIdxArgs a)
 {
-    const uint32_t lane = threadIdx.x & (kWave - 1);
-    const size_t stride = (size_t)gridDim.x * kWaves;
-    for (size_t s = (size_t)blockIdx.x * kWaves + threadIdx.x / kWave; s < a.rows; s += stride) {
-        // distinct entries and their bag-of-words values (wave-uniform, <= 16 entries)
-        const uint16_t *wr = a.words + s * a.max_words;
-        uint32_t idx[kMaxWords], cnt[kMaxWords], n = 0, n_valid = 0;
-        for (uint32_t i = 0; i < a.max_words && i < (uint32_t)kMaxWords; i++)
-            if (wr[i] != 0xFFFFu) n_valid = i + 1;
-        for (uint32_t i = 0; i < n_valid; i++) {
-            const uint32_t wdx = wr[i];
-            if (wdx == 0xFFFFu || wdx >= a.V) continue;
-            const bool is_time = a.time_last && (i + 1 == n_valid);
-            uint32_t j = 0;
-            for (; j < n; j++)
-                if (idx[j] == wdx) break;
-            if (j == n) { idx[n] = wdx; cnt[n] = 0; n++; }
-            cnt[j] = is_time ? 1u : cnt[j] + 1u;         // "= 1.0" for the time entry, "+= 1.0" for words
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), sub = lane & 15u, grp = lane >> 4;
+    const uint32_t dw = a.Dp / 4;                        // dwords per table row
+    const uint32_t tab_dw = a.V * dw;
+    uint32_t *tabs = (uint32_t *)smem;                   // [n_hop][2][V][dw]
+    if (TAB_LDS) {
+        for (uint32_t h = 0; h < a.n_hop; h++)
+            for (uint32_t i = tid; i < tab_dw; i += kBlock) {
+                tabs[(2 * h) * tab_dw + i] = ((const uint32_t *)a.t_a[h])[i];
+                tabs[(2 * h + 1) * tab_dw + i] = ((const uint32_t *)a.t_c[h])[i];
+            }
+        __syncthreads();
+    }
+    const size_t rows_per_pass = (size_t)gridDim.x * kWaves * 4;
+    for (size_t s0 = ((size_t)blockIdx.x * kWaves + tid / kWave) * 4; s0 < a.rows; s0 += rows_per_pass) {
+        const size_t s = s0 + grp;
+        const bool row_ok = s < a.rows;
+        uint32_t w = 0xFFFFu;
+        if (row_ok && sub < a.max_words) w = a.words[s * a.max_words + sub];
+        const uint32_t m16 = (uint32_t)(__ballot(w != 0xFFFFu) >> (16 * grp)) & 0xFFFFu;
+        const uint32_t n_valid = 32u - (uint32_t)__clz(m16);
+        const bool valid = w != 0xFFFFu && w < a.V;
+        const bool is_time = a.time_last && valid && (sub + 1 == n_valid);
+        const uint32_t me = w | (valid ? 1u << 16 : 0u) | (is_time ? 1u << 17 : 0u);
+        uint32_t cnt = 0;
+        bool dup = false, timed = false;
+        for (uint32_t j = 0; j < a.max_words; j++) {
+            const uint32_t o = (uint32_t)__shfl((int)me, (int)j, 16);
+            const bool same = (((o ^ me) & 0xFFFFu) == 0u) && ((o >> 16) & 1u);
+            const bool o_time = (o >> 17) & 1u;
+            cnt += (same && !o_time) ? 1u : 0u;          // word entries COUNT occurrences ...
+            timed |= same && o_time;                     // ... the time entry SETS its slot to 1
+            dup |= same && j < sub;
         }
-        for (uint32_t col = lane; col < a.Dp; col += kWave) {
+        if (timed) cnt = 1;
+        const uint32_t pack = (w & 0xFFFFu) | (cnt << 16) | ((valid && !dup) ? 1u << 24 : 0u);
+
+        for (uint32_t c0 = 0; c0 < dw; c0 += 16) {
+            const uint32_t c4 = c0 + sub;
+            const bool col_ok = c4 < dw;
             for (uint32_t h = 0; h < a.n_hop; h++) {
                 const QFmt fw = a.w[h];
                 const int maxw = (1 << (fw.iwl + fw.frac)) - 1;
-                int8_t kcode = 0, vcode = 0;
-                if (col < a.D) {
-                    int sa = 0, sc = 0;                  // integer codes in units of 2^-frac_w
-                    for (uint32_t e = 0; e < n; e++) {
-                        const int cc = count_code(cnt[e], fw.frac, maxw);
-                        sa += qm_mul_code(cc, (int)a.t_a[h][(size_t)idx[e] * a.Dp + col], fw.frac, maxw);
-                        sc += qm_mul_code(cc, (int)a.t_c[h][(size_t)idx[e] * a.Dp + col], fw.frac, maxw);
+                int sa[4] = {0, 0, 0, 0}, sc[4] = {0, 0, 0, 0};      // codes in units of 2^-frac_w
+                for (uint32_t e = 0; e < a.max_words; e++) {
+                    const uint32_t pe = (uint32_t)__shfl((int)pack, (int)e, 16);
+                    if (!((pe >> 24) & 1u) || !col_ok) continue;
+                    const uint32_t we = pe & 0xFFFFu, ce = (pe >> 16) & 0xFFu;
+                    uint32_t ta, tc;
+                    if (TAB_LDS) {
+                        ta = tabs[(2 * h) * tab_dw + we * dw + c4];
+                        tc = tabs[(2 * h + 1) * tab_dw + we * dw + c4];
+                    } else {
+                        ta = ((const uint32_t *)a.t_a[h])[(size_t)we * dw + c4];
+                        tc = ((const uint32_t *)a.t_c[h])[(size_t)we * dw + c4];
                     }
-                    sa = sa > maxw ? maxw : (sa < -maxw ? -maxw : sa);
-                    sc = sc > maxw ? maxw : (sc < -maxw ? -maxw : sc);
-                    kcode = sm_requant(sa, fw.frac, a.att[h]);
-                    vcode = sm_requant(sc, fw.frac, a.act[h]);
+                    if (ce == 1u) {                      // Qw(1 . kw) = kw
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            sa[k] += (int)(int8_t)(ta >> (8 * k));
+                            sc[k] += (int)(int8_t)(tc >> (8 * k));
+                        }
+                    } else {
+                        const int cc = count_code(ce, fw.frac, maxw);
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            sa[k] += qm_mul_code(cc, (int)(int8_t)(ta >> (8 * k)), fw.frac, maxw);
+                            sc[k] += qm_mul_code(cc, (int)(int8_t)(tc >> (8 * k)), fw.frac, maxw);
+                        }
+                    }
                 }
-                a.keys[(size_t)h * a.hop_stride + s * a.Dp + col] = kcode;
-                a.vals[(size_t)h * a.hop_stride + s * a.Dp + col] = vcode;
+                uint32_t kw = 0, vw = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int ka = sa[k] > maxw ? maxw : (sa[k] < -maxw ? -maxw : sa[k]);
+                    const int kc = sc[k] > maxw ? maxw : (sc[k] < -maxw ? -maxw : sc[k]);
+                    if (4 * c4 + (uint32_t)k < a.D) {
+                        kw |= (uint32_t)(uint8_t)sm_requant(ka, fw.frac, a.att[h]) << (8 * k);
+                        vw |= (uint32_t)(uint8_t)sm_requant(kc, fw.frac, a.act[h]) << (8 * k);
+                    }
+                }
+                if (row_ok && col_ok) {
+                    *(uint32_t *)(a.keys + (size_t)h * a.hop_stride + s * a.Dp + 4 * c4) = kw;
+                    *(uint32_t *)(a.vals + (size_t)h * a.hop_stride + s * a.Dp + 4 * c4) = vw;
+                }
             }
         }
     }
@@ -613,8 +666,14 @@ int qmann_embed_story_idx(const qmann_net *net, const uint16_t *words, uint32_t 
         a.att[h] = QFmt{net->att[h].iwl, net->att[h].frac};
     }
     if (rows_total == 0) return QMANN_OK;
-    const uint32_t blocks = (rows_total + kWaves - 1) / kWaves;
-    k_embed_story_idx<<<blocks < (1u << 20) ? blocks : (1u << 20), kBlock, 0, (hipStream_t)stream>>>(a);
+    if ((net->dim_emb_pad & 3u) || (hop_stride & 3u) || ((uintptr_t)keys & 3u) || ((uintptr_t)vals & 3u)) return QMANN_EINVAL;
+    const uint32_t need = (rows_total + kWaves * 4 - 1) / (kWaves * 4);
+    const uint32_t blocks = need < 2048u ? need : 2048u;
+    const size_t tab_lds = (size_t)net->n_hop * 2 * net->dim_input * net->dim_emb_pad;
+    if (tab_lds <= 48 * 1024)
+        k_embed_story_idx<true><<<blocks, kBlock, tab_lds, (hipStream_t)stream>>>(a);
+    else
+        k_embed_story_idx<false><<<blocks, kBlock, 0, (hipStream_t)stream>>>(a);
     QM_LAUNCH_CHECK();
     return QMANN_OK;
 }

@@ -413,3 +413,45 @@ def test_embedding_from_word_indices_equals_bag_of_words_path(env, gold, name):
     torch.cuda.synchronize()
     assert torch.equal(k1, k2) and torch.equal(v1, v2) and torch.equal(u1, u2)
     assert k1.abs().sum().item() > 0
+
+
+@pytest.mark.parametrize("V,D,rows", [(500, 70, 203), (40, 60, 57), (120, 128, 33)])
+def test_word_index_embedding_duplicates_large_tables_ragged(env, V, D, rows):
+    """Shuffled repeated words (counts up to 5), empty rows, out-of-range indices, a row count that is
+    not a multiple of 4, D that does not fill 16 dwords, tables too large for LDS: all equal the
+    bag-of-words path (itself pinned to the oracle above)."""
+    torch, model = env.torch, env.model
+    rng = np.random.default_rng(V + D)
+    dd = V - 10                                     # last 10 indices play the time encoding
+    max_words = 16
+    sw = np.full((rows, max_words), 0xFFFF, np.uint16)
+    story = np.zeros((rows, V), np.float32)
+    for r in range(rows):
+        if r % 17 == 5:
+            continue                                # empty row
+        n = int(rng.integers(1, max_words))
+        ws = rng.integers(0, min(dd, 6 if r % 3 == 0 else dd), n)      # small range -> many repeats
+        for k in ws:
+            story[r, k] += 1.0
+        t = dd + int(rng.integers(0, 10))
+        story[r, t] = 1.0
+        ent = list(ws) + [t]
+        if r % 5 == 0 and len(ent) < max_words:
+            ent.insert(0, V + 3)                    # out-of-range index: ignored
+        sw[r, :len(ent)] = ent
+    nq = 19
+    qw = np.full((nq, 8), 0xFFFF, np.uint16)
+    ques = np.zeros((nq, V), np.float32)
+    for q in range(nq):
+        ws = rng.integers(0, dd if q % 2 else 3, int(rng.integers(1, 8)))
+        for k in ws:
+            ques[q, k] += 1.0
+        qw[q, :len(ws)] = ws
+    cfg = model.babi_cfg(V, 2, 0, D=D)
+    net = model.QNet(cfg, weights(V * 3 + D, 3, D, V, 1.5))
+    net.make_tables()
+    k1, v1, u1 = net.embed(torch.from_numpy(story).to(env.dev), torch.from_numpy(ques).to(env.dev))
+    k2, v2, u2 = net.embed_idx(torch.from_numpy(sw.view(np.int16)).to(env.dev), torch.from_numpy(qw.view(np.int16)).to(env.dev))
+    torch.cuda.synchronize()
+    assert torch.equal(k1, k2) and torch.equal(v1, v2) and torch.equal(u1, u2)
+    assert k1.abs().sum().item() > 0
