@@ -75,7 +75,7 @@ typedef struct qmann_net {
     qmann_fmt w[QMANN_MAX_HOP];     /* (iwl_w[h], frac_w[h])      :718-719, 748-754       */
     qmann_fmt att[QMANN_MAX_HOP];   /* (iwl_att[h], frac_att[h])  :721-722                */
     qmann_fmt bin;                  /* (iwl_bin, frac_bin)        :769-775                */
-    const int8_t *lin_map[QMANN_MAX_HOP]; /* device, [D][Dp] two's-complement codes in format w[h]; NULL when !en_lin_map */
+    const int8_t *lin_map[QMANN_MAX_HOP]; /* device, [D][Dp] sign-magnitude codes (QMANN_CODE_SIGNMAG) in format w[h]; NULL when !en_lin_map */
 } qmann_net;
 
 /* optional per-query taps for parity tests; any pointer may be NULL */

@@ -50,7 +50,8 @@ k_answer(const float *__restrict__ w_ans, const float *__restrict__ u, const uin
             sum = w_ans[(size_t)q * V + v];          // w_ans aliases the logits buffer [n_query][V]
         } else {
             const float *wr = w_ans + (size_t)v * D;
-            for (uint32_t c = 0; c < D; c++) {
+#pragma unroll 8
+            for (uint32_t c = 0; c < D; c++) {       // unrolled: loads of a row run ahead of the serial adds
                 const float t = wr[c] * us[c];
                 sum += t;
             }
@@ -124,23 +125,31 @@ k_answer_small(const float *__restrict__ w_ans, const float *__restrict__ u, con
                uint32_t *__restrict__ pred, float *__restrict__ probs, float *cost, uint32_t *match, uint32_t D,
                uint32_t V, uint32_t softmax_base, uint32_t n_query)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *wt = (float *)smem;                          // [D][V]: W transposed, lane v reads consecutive words
+    float *us = wt + (size_t)D * V + (threadIdx.x / kWave) * D;      // [kWaves][D]: this wavefront's query
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const size_t stride = (size_t)gridDim.x * kWaves;
     const bool live = lane < V;
+    for (uint32_t i = threadIdx.x; i < D * V; i += kBlock) wt[(i % D) * V + i / D] = w_ans[i];
+    __syncthreads();
     // cost / match are summed per wavefront and added once: one device-scope atomic per query on a
     // single word would serialise the whole batch (~12 ns each)
     float cost_acc = 0.0f;
     uint32_t match_acc = 0;
     for (size_t q = (size_t)blockIdx.x * kWaves + threadIdx.x / kWave; q < n_query; q += stride) {
+        for (uint32_t c = lane; c < D; c += kWave) us[c] = u[q * D + c];
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         float sum = 0.0f;
         if (live) {
-            const float *wr = w_ans + (size_t)lane * D;
-            const float *uq = u + q * D;
+#pragma unroll 8
             for (uint32_t c = 0; c < D; c++) {
-                const float t = wr[c] * uq[c];
+                const float t = wt[c * V + lane] * us[c];
                 sum += t;
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // reads of us[] done before the next query overwrites it
         float mx = live ? sum : -INFINITY;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -554,9 +563,10 @@ int qmann_answer_f32(const qmann_net *net, const float *w_ans, const float *u, c
     if (n_query >= (1u << 24)) return QMANN_ERANGE;      // one workgroup per query: a launch holds < 2^32 threads
     if (lds > 48 * 1024)
         QM_HIP(hipFuncSetAttribute((const void *)k_answer<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (V <= (uint32_t)kWave) {
+    if (V <= (uint32_t)kWave && (size_t)D * V <= 8192) {
         const uint32_t blocks = (n_query + kWaves - 1) / kWaves;
-        k_answer_small<<<blocks < 4096u ? blocks : 4096u, kBlock, 0, (hipStream_t)stream>>>(
+        const size_t lds_small = ((size_t)D * V + (size_t)kWaves * D) * sizeof(float);
+        k_answer_small<<<blocks < 2048u ? blocks : 2048u, kBlock, lds_small, (hipStream_t)stream>>>(
             w_ans, u, answer, pred, probs, cost, match, D, V, net->softmax_base, n_query);
         QM_LAUNCH_CHECK();
         return QMANN_OK;

@@ -117,6 +117,29 @@ __device__ __forceinline__ int lane_row_sum(const i32x4 x, const ScanConst &c, u
     return acc;
 }
 
+// ScanConst of the 16 columns starting at c0 from the Q(v) codes `ku` of the vector; wl = word
+// length (iwl + frac) of the product format, fv = frac of the vector format.  Returns the result shift.
+__device__ __forceinline__ uint32_t make_scan_const(ScanConst &c, const short *ku, uint32_t c0, uint32_t wl, int fv)
+{
+    const uint32_t sh = 16u - wl;                       // result shift
+    const int pre = (int)sh - fv;                       // |u| << pre (>= 0 since wl + fv <= 14)
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        uint32_t m[4], sg = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int k = ku[c0 + 4 * d + i];
+            const uint32_t a = (uint32_t)(k < 0 ? -k : k) << pre;
+            m[i] = a > 0xFFFFu ? 0xFFFFu : a;
+            sg |= (k < 0 ? 0x80u : 0u) << (8 * i);
+        }
+        c.ue[d] = m[0] | (m[2] << 16);
+        c.uo[d] = m[1] | (m[3] << 16);
+        c.s7[d] = sg;
+    }
+    return sh;
+}
+
 template <bool NT>
 __device__ __forceinline__ i32x4 load16(const uint8_t *p)
 {
@@ -271,36 +294,43 @@ __device__ __forceinline__ void readout_sparse(const HopArgs &a, uint32_t h, uin
     __syncthreads();
 }
 
-// lin_map + hop update from o_f (any read-out) and the Q_bin(u) codes in `ku`; ends with a barrier
+// lin_map + hop update from o_f (any read-out) and the Q_bin(u) codes in `ku`; ends with a barrier.
+// H is sign-magnitude int8 [D][Dp]: the matrix-vector product is the key scan's arithmetic (same
+// per-product form Qw(Qw(H).Qbin(u)), lib/layer_cuda.cu:71), Dp/16 lanes per output row.
 template <uint32_t Dp>
 __device__ __forceinline__ void linmap_update(const HopArgs &a, uint32_t q, uint32_t h, const short *ku, float *u_f,
                                               const float *o_f, uint32_t tid)
 {
+    constexpr uint32_t LPR = Dp / 16, RPW = kWave / LPR;
     const QFmt fa = a.act[h], fw = a.w[h], fb = a.bin;
     const int maxw = (1 << (fw.iwl + fw.frac)) - 1;
     const uint32_t D = a.D;
-    const uint32_t nthreads = blockDim.x;
-    for (uint32_t o_i = tid; o_i < D; o_i += nthreads) {
-        float lu = u_f[o_i];
-        if (a.en_lin_map) {
-            const int8_t *hr = a.lin_map[h] + (size_t)o_i * Dp;
-            int acc = 0;
-            for (uint32_t i = 0; i < Dp; i += 16) {
-                const i32x4 wv = *(const i32x4 *)(hr + i);
-#pragma unroll
-                for (int b = 0; b < 16; b++) {
-                    const int kh = (int)(int8_t)((uint32_t)wv[b >> 2] >> (8 * (b & 3)));
-                    acc += qm_mul_code(kh, (int)ku[i + b], fb.frac, maxw);
-                }
-            }
-            acc = acc > maxw ? maxw : (acc < -maxw ? -maxw : acc);
-            lu = (float)acc / (float)(1 << fw.frac);
-        }
+    const uint32_t nthreads = blockDim.x, nwaves = nthreads / kWave;
+    const uint32_t lane = tid & (kWave - 1), wave = tid / kWave;
+    const uint32_t sub = lane / LPR, chunk = lane % LPR;
+    auto update = [&](uint32_t o_i, float lu) {
         const float o = o_f[o_i];
         const float un = qm_quant(qm_quant(lu, fa.iwl, fa.frac) + qm_quant(o, fa.iwl, fa.frac), fa.iwl, fa.frac);
         if (a.tap_o) a.tap_o[((size_t)q * a.n_hop + h) * D + o_i] = o;
         if (a.tap_u) a.tap_u[((size_t)q * a.n_hop + h) * D + o_i] = un;
         u_f[o_i] = un;
+    };
+    if (a.en_lin_map) {
+        ScanConst c;
+        const uint32_t sh = make_scan_const(c, ku, chunk * 16, fw.iwl + fw.frac, (int)fb.frac);
+        const uint8_t *hb = (const uint8_t *)a.lin_map[h] + chunk * 16;
+        for (uint32_t base = wave * RPW; base < D; base += nwaves * RPW) {
+            const uint32_t r = base + sub;
+            i32x4 x = {0, 0, 0, 0};
+            if (r < D) x = *(const i32x4 *)(hb + (size_t)r * Dp);
+            int acc = row_lanes_sum<LPR>(lane_row_sum(x, c, sh));
+            if (chunk == 0 && r < D) {
+                acc = acc > maxw ? maxw : (acc < -maxw ? -maxw : acc);
+                update(r, (float)acc / (float)(1 << fw.frac));
+            }
+        }
+    } else {
+        for (uint32_t o_i = tid; o_i < D; o_i += nthreads) update(o_i, u_f[o_i]);
     }
     __syncthreads();
 }

@@ -99,7 +99,7 @@ class QNet:
         if n.en_lin_map:
             for h in range(self.H):
                 wf = up(weights["w_h"][h])
-                self.lin_map_i8.append(self.quantize_i8(wf, cfg["fmt_w"][h]))
+                self.lin_map_i8.append(self.quantize_i8(wf, cfg["fmt_w"][h], abi.CODE_SIGNMAG))
                 n.lin_map[h] = self.lin_map_i8[h].data_ptr()
 
     # ---- helpers -------------------------------------------------------------------------

@@ -124,6 +124,17 @@ def test_hops_small_ragged(env, oracle, D, iwl):
     run_case(env, oracle, cfg, B=24, S_list=[1, 2, 3, 7, 10, 31, 32, 33, 50, 64, 65, 129], seed=100 + D + iwl)
 
 
+@pytest.mark.parametrize("D", [60, 64, 100, 128, 200, 256])
+@pytest.mark.parametrize("iwl,base", [(5, 0), (2, 0), (3, 1)])
+def test_hops_one_wavefront_path(env, oracle, D, iwl, base):
+    """Every story <= 64 slots: the one-wavefront kernel (slot r in lane r), incl. empty stories and
+    mixed per-hop weight formats."""
+    frac = 7 - iwl
+    fmt_w = [(iwl + 1, frac - 1), (iwl, frac), (iwl - 1, frac + 1)]
+    cfg = cfg_synth(D, 40, iwl, base=base, fmt_w=fmt_w)
+    run_case(env, oracle, cfg, B=26, S_list=[1, 2, 3, 0, 7, 10, 16, 17, 31, 32, 33, 50, 63, 64], seed=300 + D + iwl)
+
+
 @pytest.mark.parametrize("base", [0, 1])
 def test_hops_softmax_bases(env, oracle, base):
     run_case(env, oracle, cfg_synth(128, 64, 5, base=base), B=8, S_list=[50, 257], seed=7 + base)
