@@ -19,11 +19,10 @@
 //                         [Dp/64 groups][num_bit planes]; agreement is ~(K ^ U), counted with
 //                         popcount (v_bcnt), split by sign agreement for V1.
 //
-// Scores are not on an 8-bit grid here, so they are kept as int32 in LDS and the softmax is
-// evaluated per slot (max, sum of exp in double, quotient), as lib/layer_cuda.cu:1969-2060 does.
+// Scores are not on an 8-bit grid here; every mode's row score is bounded by 127.D <= 32512 units,
+// so they are kept as int16 in LDS.  V0 evaluates the softmax once per distinct count (histogram),
+// the other modes per slot (max, sum of exp in double, quotient), as lib/layer_cuda.cu:1969-2060 does.
 #include "hops_common.h"
-
-#include <type_traits>
 
 namespace {
 
@@ -33,46 +32,46 @@ static_assert(kOffUpl % 8 == 0 && kOffUpl + 4 * 8 * 8 <= kOffPtab, "u planes mus
 
 enum { kModeAppx = 0, kModeV0 = 1, kModeV1 = 2 };
 
-// V0 scores are small counts (0 .. num_bit . D <= 2048): they are kept as int16 and the softmax is
-// evaluated once per distinct count through a histogram (as the fixed-point kernel does per code);
-// the other modes keep int32 scores and evaluate the softmax per slot.
-constexpr uint32_t kV0MaxBins = 2049;
-constexpr uint32_t kV0HistBytes = ((kV0MaxBins * 4 + 15) / 16) * 16;
-constexpr uint32_t kV0KpBytes = ((kV0MaxBins + 15) / 16) * 16;
-constexpr uint32_t kV0TableBytes = 2 * kV0HistBytes + kV0KpBytes;     // hist u32, p float, Q(p) u8
+// V0 scores are small counts (0 .. num_bit . D <= 2048): the softmax is evaluated once per distinct
+// count through a histogram (as the fixed-point kernel does per code).  The tables (hist u32, p float,
+// Q(p) u8, each nbins = num_bit . D + 1 entries) sit behind the score array.
+__host__ __device__ inline uint32_t v0_hist_bytes(uint32_t nbins) { return ((nbins * 4 + 15) / 16) * 16; }
+__host__ __device__ inline uint32_t v0_table_bytes(uint32_t nbins) { return 2 * v0_hist_bytes(nbins) + ((nbins + 15) / 16) * 16; }
 
 // ---- APPX: 4 key bytes against 4 query bytes -------------------------------------------------
 struct AppxConst {
     uint32_t um[4];   // |u| bytes
     uint32_t us[4];   // 0x80 where u < 0
-    uint32_t vm[4];   // 0xFF for real columns, 0x00 for padding
+    uint32_t m7[4];   // 0x7F in real columns, 0 in padding
+    uint32_t m8[4];   // 0x80 in real columns, 0 in padding
+    int bias;         // 127 . (16 - padding columns of this lane): the same-sign terms' constant part
 };
 
+// 19 VALU operations per 4 columns.  Padding columns are forced to "same sign, both magnitudes 0"
+// by the masks (a term of exactly 127), which `bias` leaves out.
 __device__ __forceinline__ int appx_lane_sum(const i32x4 x, const AppxConst &c)
 {
-    int acc = 0;
+    int dot = 0;
+    uint32_t sad = 0, ndiff = 0;
 #pragma unroll
     for (int d = 0; d < 4; d++) {
         const uint32_t w = (uint32_t)x[d];
-        const uint32_t km = w & 0x7F7F7F7Fu;
-        const uint32_t sd = (w ^ c.us[d]) & 0x80808080u;                    // signs differ
-        const uint32_t dmask = __builtin_amdgcn_perm(0u, 0u, sd) & c.vm[d]; // 0xFF in those bytes
-        const uint32_t smask = c.vm[d] & ~dmask;                            // same sign, real column
-        // same sign: 127 - |ka - kb|
-        const int n_same = __builtin_popcount(smask & 0x01010101u);
-        const uint32_t sad = __builtin_amdgcn_sad_u8(km & smask, c.um[d] & smask, 0u);
-        acc += 127 * n_same - (int)sad;
-        // opposite sign: +-(127 - ((ka + kb) & 127))
-        const uint32_t s4 = (km & dmask) + (c.um[d] & dmask);               // per byte <= 254: no carry across
-        const uint32_t carry = s4 & 0x80808080u;
-        const uint32_t val = (0x7F7F7F7Fu - (s4 & 0x7F7F7F7Fu)) & dmask;
-        const uint32_t ge = ((km | 0x80808080u) - c.um[d]) & 0x80808080u;   // |k| >= |u|
-        const uint32_t lneg = (w & ge) | (c.us[d] & ~ge);                   // sign bit of the larger operand
-        const uint32_t neg = (~(carry & ~lneg)) & 0x80808080u;              // term is negative
+        const uint32_t km = w & c.m7[d];
+        const uint32_t sd = (w ^ c.us[d]) & c.m8[d];                        // signs differ
+        const uint32_t dmask = __builtin_amdgcn_perm(0u, 0u, sd);           // 0xFF in those bytes
+        ndiff += (uint32_t)__builtin_popcount(sd);
+        // same sign: 127 - |ka - kb|  (the 127s are counted through ndiff)
+        sad = __builtin_amdgcn_sad_u8(km & ~dmask, c.um[d] & ~dmask, sad);
+        // opposite sign: +-(127 - ((ka + kb) & 127)); per byte ka + kb <= 254, no carry across bytes
+        const uint32_t s4 = km + c.um[d];                                   // bit 7 of a byte = carry out of 7 bits
+        const uint32_t val = ~s4 & (dmask & 0x7F7F7F7Fu);
+        const uint32_t ge = (km | 0x80808080u) - c.um[d];                   // bit 7: |k| >= |u|
+        const uint32_t lneg = (w & ge) | (c.us[d] & ~ge);                   // bit 7: sign of the larger operand
+        const uint32_t neg = ((s4 & lneg) | ~s4) & 0x80808080u;             // negative unless carry and larger > 0
         const uint32_t sg = __builtin_amdgcn_perm(0x01010101u, 0x01010101u, neg);
-        acc = __builtin_amdgcn_sdot4((int)val, (int)sg, acc, false);
+        dot = __builtin_amdgcn_sdot4((int)val, (int)sg, dot, false);
     }
-    return acc;
+    return dot + c.bias - 127 * (int)ndiff - (int)sad;
 }
 
 // ---- V0 / V1: two 64-bit plane words per lane -------------------------------------------------
@@ -133,7 +132,7 @@ k_hops_ham(const HopArgs a, const uint32_t key_row_bytes, const uint32_t lds_slo
     uint8_t *live_kp = (uint8_t *)(smem + kOffLiveKp);
     uint32_t *misc = (uint32_t *)(smem + kOffMisc);
     double *red = (double *)(smem + kOffRed);
-    using score_t = typename std::conditional<MODE == kModeV0, int16_t, int32_t>::type;
+    using score_t = int16_t;
     score_t *sc = (score_t *)(smem + kOffScores);
 
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
@@ -144,9 +143,9 @@ k_hops_ham(const HopArgs a, const uint32_t key_row_bytes, const uint32_t lds_slo
     // V0 tables sit behind the score array (lds_slots is the launch's slot capacity)
     unsigned char *tab = smem + kOffScores + (((size_t)lds_slots * sizeof(score_t) + 15) & ~(size_t)15);
     uint32_t *v0_hist = (uint32_t *)tab;
-    float *v0_p = (float *)(tab + kV0HistBytes);
-    uint8_t *v0_kp = (uint8_t *)(tab + 2 * kV0HistBytes);
     const uint32_t nbins = NB * D + 1;
+    float *v0_p = (float *)(tab + v0_hist_bytes(nbins));
+    uint8_t *v0_kp = (uint8_t *)(tab + 2 * v0_hist_bytes(nbins));
 
     u_f[tid] = (tid < D) ? a.u0[(size_t)q * D + tid] : 0.0f;
     __syncthreads();
@@ -191,8 +190,10 @@ k_hops_ham(const HopArgs a, const uint32_t key_row_bytes, const uint32_t lds_slo
                     uint32_t vm = 0;
 #pragma unroll
                     for (int i = 0; i < 4; i++) vm |= (c0 + 4 * d + i < D ? 0xFFu : 0u) << (8 * i);
-                    c.vm[d] = vm;
+                    c.m7[d] = vm & 0x7F7F7F7Fu;
+                    c.m8[d] = vm & 0x80808080u;
                 }
+                c.bias = 127 * (int)(D >= c0 + 16 ? 16u : (D > c0 ? D - c0 : 0u));
                 auto row_sum = [&](const i32x4 x) { return appx_lane_sum(x, c); };
                 auto retire_c = [&](uint32_t r, int v) { sc[r] = v > lim ? lim : (v < -lim ? -lim : v); };
                 if (S >= (kWave / LPRK) * 4) scan_rows<LPRK, 4, true, kWaves>(kb, S, row_sum, retire_c, lane, wave);
@@ -375,10 +376,9 @@ void launch(const HopArgs &a, uint32_t key_row_bytes, size_t lds, uint32_t lds_s
     k_hops_ham<LPRK, DP, MODE, NB><<<n_query, kBlock, lds, st>>>(a, key_row_bytes, lds_slots);
 }
 
-size_t ham_lds_bytes(uint32_t max_slots, bool v0)
+size_t ham_lds_bytes(uint32_t max_slots, uint32_t v0_bins)
 {
-    if (v0) return (size_t)kOffScores + (((size_t)max_slots * 2 + 15) & ~(size_t)15) + kV0TableBytes;
-    return (size_t)kOffScores + (((size_t)max_slots * 4 + 15) & ~(size_t)15);
+    return (size_t)kOffScores + (((size_t)max_slots * 2 + 15) & ~(size_t)15) + (v0_bins ? v0_table_bytes(v0_bins) : 0);
 }
 
 }  // namespace
@@ -407,7 +407,7 @@ int qmann_hops_appx_impl(const qmann_net *net, const int8_t *keys, const int8_t 
     HopArgs a;
     const int rc = fill_args(a, net, keys, vals, hop_stride, hop_stride, row_off, u0, u_out, taps);
     if (rc) return rc;
-    const size_t lds = ham_lds_bytes(max_slots, false);
+    const size_t lds = ham_lds_bytes(max_slots, 0);
     if (lds > 160 * 1024 - 1024) return QMANN_ERANGE;
     if (n_query == 0) return QMANN_OK;
     if (n_query >= (1u << 24)) return QMANN_ERANGE;      // one workgroup per query: a launch holds < 2^32 threads
@@ -433,7 +433,7 @@ int qmann_hops_packed(const qmann_net *net, const uint64_t *key_planes, size_t k
     const int rc = fill_args(a, net, key_planes, vals, key_hop_stride, val_hop_stride, row_off, u0, u_out, taps);
     if (rc) return rc;
     const bool v1 = net->attention_mode == QMANN_ATT_HAMMING_V1;
-    const size_t lds = ham_lds_bytes(max_slots, !v1);
+    const size_t lds = ham_lds_bytes(max_slots, v1 ? 0u : nb * net->dim_emb + 1u);
     if (lds > 160 * 1024 - 1024) return QMANN_ERANGE;
     const uint32_t row_bytes = Dp / 64 * nb * 8;
     if (row_bytes < 16) return QMANN_EUNSUPPORTED;      // Dp = 64 with a single plane
