@@ -99,13 +99,15 @@ k_hops_float(const HopArgs a)
                 psum += (double)((a.softmax_base == QMANN_SOFTMAX_EXP) ? expf(x) : exp2f(x));
             }
             const double total = block_sum_double(psum, red, lane, wave);
+            const double inv_total = 1.0 / total;               // e . (1/total): within an ulp of e / total, and p is
+            const float inv_total_f = 1.0f / (float)total;      // not quantised in this mode (tolerance 1e-5)
             const size_t tb = (size_t)h * a.rows_total + r0;
             for (uint32_t r = tid; r < S; r += kBlock) {
                 const int sv = sc[r];
                 const float x = (float)sv * scale - fmx;
                 float p;
-                if (a.softmax_base == QMANN_SOFTMAX_EXP) p = (float)((double)expf(x) / total);
-                else p = exp2f(x) / (float)total;
+                if (a.softmax_base == QMANN_SOFTMAX_EXP) p = (float)((double)expf(x) * inv_total);
+                else p = exp2f(x) * inv_total_f;
                 if (a.tap_codes) a.tap_codes[tb + r] = sv;
                 if (a.tap_scores) a.tap_scores[tb + r] = (float)sv * scale;
                 if (a.tap_probs) a.tap_probs[tb + r] = p;
@@ -114,25 +116,66 @@ k_hops_float(const HopArgs a)
         }
         __syncthreads();
 
-        // dense float read-out: lane (sub, chunk) owns 16 columns of every (64 / LPR)-th row
+        // dense float read-out: lane (sub, chunk) owns 16 columns of every (64 / LPR)-th row; tiles of
+        // UN loads per lane, the next tile in flight while the current one is accumulated (as the key scan)
         {
             constexpr uint32_t RPW = kWave / LPR;
+            constexpr int UN = 4;
+            constexpr uint32_t TILE = RPW * UN, STEP = kWaves * TILE;
             const uint32_t sub = lane / LPR, chunk = lane % LPR;
             const float vscale = 1.0f / (float)(1u << fw.frac);
             float acc[16];
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[i] = 0.0f;
             const uint8_t *vb = (const uint8_t *)a.vals + (size_t)h * a.hop_stride + (size_t)r0 * Dp + chunk * 16;
-            for (uint32_t r = wave * RPW + sub; r < S; r += kWaves * RPW) {
-                const i32x4 x = __builtin_nontemporal_load((const i32x4 *)(vb + (size_t)r * Dp));
-                const float p = pf[r];
+            // acc[i] += (p . 2^-frac) . (+-|code|): the magnitude byte converts with one v_cvt_f32_ubyte, the
+            // sign bit is moved onto the float's sign, one FMA accumulates (inside the mode's 1e-5 tolerance)
+            auto accumulate = [&](const i32x4 x, float ps) {
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const uint32_t b = ((uint32_t)x[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-                    const float m = (float)(b & 0x7Fu) * vscale;
-                    const float v = (b & 0x80u) ? -m : m;
-                    acc[i] += p * v;
+                for (int d = 0; d < 4; d++) {
+                    const uint32_t w = (uint32_t)x[d];
+                    const uint32_t mag = w & 0x7F7F7F7Fu;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const float m = (float)((mag >> (8 * i)) & 0xFFu);
+                        const uint32_t sgn = (w << (24 - 8 * i)) & 0x80000000u;
+                        const float v = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, m) | sgn);
+                        acc[4 * d + i] = __builtin_fmaf(ps, v, acc[4 * d + i]);
+                    }
                 }
+            };
+            if (S >= TILE) {
+                const uint32_t n_tiles = (S + TILE - 1) / TILE;
+                auto tile_start = [&](uint32_t base) { return base + TILE <= S ? base : S - TILE; };
+                auto issue = [&](i32x4 (&x)[UN], uint32_t base) {
+                    const uint8_t *pp = vb + (size_t)(tile_start(base) + sub) * Dp;
+#pragma unroll
+                    for (int j = 0; j < UN; j++) x[j] = __builtin_nontemporal_load((const i32x4 *)(pp + (size_t)j * RPW * Dp));
+                };
+                auto consume = [&](const i32x4 (&x)[UN], uint32_t base) {
+                    const uint32_t start = tile_start(base);
+#pragma unroll
+                    for (int j = 0; j < UN; j++) {
+                        const uint32_t r = start + j * RPW + sub;
+                        accumulate(x[j], r >= base ? pf[r] * vscale : 0.0f);     // rows a moved-back tile repeats add zero
+                    }
+                };
+                if (wave < n_tiles) {
+                    i32x4 xa[UN], xb[UN];
+                    uint32_t base = wave * TILE;
+                    issue(xa, base);
+                    for (uint32_t t = wave; t < n_tiles; t += 2 * kWaves) {
+                        issue(xb, base + STEP);
+                        consume(xa, base);
+                        if (t + kWaves >= n_tiles) break;
+                        issue(xa, base + 2 * STEP);
+                        consume(xb, base + STEP);
+                        base += 2 * STEP;
+                    }
+                }
+            } else {
+                for (uint32_t r = wave * RPW + sub; r < S; r += kWaves * RPW)
+                    accumulate(*(const i32x4 *)(vb + (size_t)r * Dp), pf[r] * vscale);
             }
             // fold the RPW row groups of a wavefront (lanes with equal chunk), then the wavefronts
 #pragma unroll
