@@ -87,32 +87,80 @@ def make_params(cfg, D, V, seed):
             "w_ans": rng.normal(0, 0.1, (V, D)).astype(np.float32)}
 
 
-def cpu_baseline(cfg, wts, keys, vals, u0, S, D, budget_s=15.0):
-    """The CPU oracle (our scalar restatement of the reference arithmetic, 1 thread) on a bounded
-    sample of the SAME queries.  Checker infrastructure used as a reported baseline only."""
+def usable_cores():
+    """Threads for the CPU baseline: the cgroup CPU quota when one is set, else the affinity mask capped at
+    16 (the GPU pool's documented host share per GPU; the affinity mask there shows the whole host)."""
+    import math
+    n = max(1, len(os.sched_getaffinity(0)))
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: [t.strip(), None])):
+        try:
+            q, per = parse(open(path).read())
+            if q != "max" and int(q) > 0:
+                per = int(per) if per else int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                return max(1, min(n, math.ceil(int(q) / per)))
+        except (OSError, ValueError):
+            pass
+    return min(n, 16)
+
+
+def cpu_baseline(cfg, wts, keys, vals, u0, S, D, budget_s=8.0):
+    """The CPU oracle (our scalar restatement of the reference arithmetic) on a bounded sample of the
+    SAME queries: first one thread (the reference is single-threaded), then one thread per host core
+    the process may use, queries spread over threads (ctypes releases the GIL).  Checker
+    infrastructure used as a reported baseline only."""
+    import os
+    import threading
     sys.path.insert(0, str(ROOT / "oracle"))
     from pyoracle import Oracle
     from qmann_amd.model import from_signmag
     ora = Oracle()
     m = ora.make_model(cfg, wts)
     H = cfg["n_hop"]
-    done, t_used, preds = 0, 0.0, []
     B = u0.shape[0]
-    while done < B and (t_used < budget_s or done < 2):
-        q = done
+
+    def inputs(q):
         kf = np.stack([from_signmag(keys[h, q * S:(q + 1) * S, :D].cpu().numpy()).astype(np.float32)
                        / np.float32(1 << cfg["fmt_att"][h][1]) for h in range(H)])
         vf = np.stack([from_signmag(vals[h, q * S:(q + 1) * S, :D].cpu().numpy()).astype(np.float32)
                        / np.float32(1 << cfg["fmt"][h][1]) for h in range(H)])
-        uq = u0[q].cpu().numpy()
+        return kf, vf, u0[q].cpu().numpy()
+
+    # one thread
+    done, t_used, preds = 0, 0.0, []
+    while done < B and (t_used < budget_s or done < 2) and done < 4096:
+        kf, vf, uq = inputs(done)
         t0 = time.perf_counter()
         pred, _ = ora.forward_mem(m, kf, vf, uq, taps=())
         t_used += time.perf_counter() - t0
         preds.append(pred)
         done += 1
-        if done >= 4096:
-            break
-    return done / t_used, done, t_used, preds
+    one = {"qps": done / t_used, "n": done, "secs": t_used}
+
+    # every core: a pool of converted queries (bounded memory), threads walk it until the deadline
+    cores = usable_cores()
+    per_query_bytes = 2 * H * S * D * 4
+    pool = [inputs(q) for q in range(min(B, max(cores, min(64, int(4e9 // max(per_query_bytes, 1))))))]
+    counts = [0] * cores
+    deadline = [0.0]
+
+    def worker(t):
+        i = t
+        while time.perf_counter() < deadline[0]:
+            kf, vf, uq = pool[i % len(pool)]
+            ora.forward_mem(m, kf, vf, uq, taps=())
+            counts[t] += 1
+            i += cores
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(cores)]
+    t0 = time.perf_counter()
+    deadline[0] = t0 + budget_s
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    wall = time.perf_counter() - t0
+    many = {"qps": sum(counts) / wall, "n": sum(counts), "secs": wall, "cores": cores}
+    return one, many, preds
 
 
 def run_bow(args, wl, net, cfg, wts, dev, rank, world, model):
@@ -210,8 +258,32 @@ def run_bow(args, wl, net, cfg, wts, dev, rank, world, model):
                 off += ns
             reps += 1
         gp = out["pred"][:len(n_sen)].cpu().numpy().tolist()
-        res["cpu_baseline"] = {"value": reps * len(n_sen) / t_used, "unit": "queries/s", "cores": 1, "kind": "port",
-                               "sample": f"the 64 fixture stories x {reps} passes, {t_used:.1f} s, scalar C oracle -O2",
+        # the same on one thread per usable host core (the reference itself is single-threaded)
+        import threading
+        cores = usable_cores()
+        offs = np.concatenate([[0], np.cumsum(n_sen)]).astype(np.int64)
+        counts = [0] * cores
+        t_end = time.perf_counter() + 8.0
+
+        def worker(t):
+            i = t
+            while time.perf_counter() < t_end:
+                k = i % len(n_sen)
+                ora.forward(m, st[offs[k]:offs[k + 1]], qu[k], taps=())
+                counts[t] += 1
+                i += cores
+        t1 = time.perf_counter()
+        ths = [threading.Thread(target=worker, args=(t,)) for t in range(cores)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        wall = time.perf_counter() - t1
+        res["cpu_baseline"] = {"value": sum(counts) / wall, "unit": "queries/s", "cores": cores, "kind": "port",
+                               "sample": f"the 64 fixture stories, {sum(counts)} forwards in {wall:.1f} s on {cores} threads "
+                                         "(one per usable host core; the Python call overhead is part of it), scalar C oracle -O2",
+                               "one_thread": {"value": reps * len(n_sen) / t_used,
+                                              "sample": f"the 64 fixture stories x {reps} passes, {t_used:.1f} s"},
                                "pred_agree": int(sum(int(a == b) for a, b in zip(gp, preds))), "pred_total": len(preds)}
     if rank == 0:
         print(json.dumps(res), flush=True)
@@ -356,10 +428,13 @@ def main():
     if bcast_ms is not None:
         out["param_broadcast_ms"] = bcast_ms
     if rank == 0 and not args.no_cpu_baseline:
-        qps, n, secs, preds = cpu_baseline(cfg, wts, keys, vals, u0, S, D)
+        one, many, preds = cpu_baseline(cfg, wts, keys, vals, u0, S, D)
+        n = one["n"]
         gp = pred[:n].cpu().numpy().tolist()
-        out["cpu_baseline"] = {"value": qps, "unit": "queries/s", "cores": 1, "kind": "port",
-                               "sample": f"first {n} queries of the same batch, {secs:.1f} s, scalar C oracle -O2",
+        out["cpu_baseline"] = {"value": many["qps"], "unit": "queries/s", "cores": many["cores"], "kind": "port",
+                               "sample": f"queries of the same batch: {many['n']} in {many['secs']:.1f} s on "
+                                         f"{many['cores']} threads (one per usable host core), scalar C oracle -O2",
+                               "one_thread": {"value": one["qps"], "sample": f"first {n} queries, {one['secs']:.1f} s"},
                                "pred_agree": int(sum(int(a == b) for a, b in zip(gp, preds))), "pred_total": n}
     if rank == 0:
         print(json.dumps(out), flush=True)
