@@ -283,7 +283,7 @@ void cuda_copy_dev2host(float *host, float *dev, unsigned int size);
 
 /* ---- library-level switches that have no reference counterpart ------------ */
 /* Exponential used by cuda_softmax_fwd: 0 = e^x as _cuda_softmax_fwd (lib/layer_cuda.cu:2006, default),
- * 1 = 2^x as the live CPU branch (lib/layer.c:1225). */
+ * 1 = 2^x as the live CPU branch (lib/layer.c:1225), 2 = its piece-wise linear exp_plan (lib/layer.c:1196-1199). */
 void qmann_abi_set_softmax_base(int base);
 /* Number of `cuda_*` symbols of boundary B this build exports (66). */
 unsigned int qmann_abi_symbol_count(void);

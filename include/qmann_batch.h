@@ -55,7 +55,8 @@ enum {
 /* byte layout of an int8 code */
 enum { QMANN_CODE_TWOS = 0 /* two's complement (weights) */, QMANN_CODE_SIGNMAG = 1 /* memories */ };
 
-enum { QMANN_SOFTMAX_EXP = 0 /* lib/layer_cuda.cu:2006 */, QMANN_SOFTMAX_POW2 = 1 /* lib/layer.c:1225 */ };
+enum { QMANN_SOFTMAX_EXP = 0 /* lib/layer_cuda.cu:2006 */, QMANN_SOFTMAX_POW2 = 1 /* lib/layer.c:1225 */,
+       QMANN_SOFTMAX_EXP_PLAN = 2 /* piece-wise linear exp, lib/layer.c:1196-1199 + lib/common.c:51-73 */ };
 
 typedef struct qmann_fmt {
     uint32_t iwl;
@@ -76,6 +77,10 @@ typedef struct qmann_net {
     qmann_fmt att[QMANN_MAX_HOP];   /* (iwl_att[h], frac_att[h])  :721-722                */
     qmann_fmt bin;                  /* (iwl_bin, frac_bin)        :769-775                */
     const int8_t *lin_map[QMANN_MAX_HOP]; /* device, [D][Dp] sign-magnitude codes (QMANN_CODE_SIGNMAG) in format w[h]; NULL when !en_lin_map */
+    /* in-hop softmax variants; all zero = the stock configuration */
+    uint32_t softmax_shift_based;   /* EN_SHIFT_BASED_SM (define.h:54-55): power-of-two style normaliser, sf_in only (MemN2N.c:856) */
+    uint32_t en_att_scale;          /* EN_SC_ATT (define.h:58-59): scores times one learnt scalar before the softmax (MemN2N.c:2647-2649) */
+    float att_scale[QMANN_MAX_HOP]; /* that scalar per hop (scale.w, lib/layer.h:786-810) */
 } qmann_net;
 
 /* optional per-query taps for parity tests; any pointer may be NULL */

@@ -39,6 +39,7 @@ class QoModel(C.Structure):
         ("w_q", _f32p),
         ("w_a", _f32p * QO_MAX_HOP), ("w_c", _f32p * QO_MAX_HOP), ("w_h", _f32p * QO_MAX_HOP),
         ("w_ans", _f32p),
+        ("f_shift_based", C.c_bool), ("en_sc_att", C.c_bool), ("sc_att", C.c_float * QO_MAX_HOP),
     ]
 
 
@@ -247,6 +248,11 @@ class Oracle:
             m.iwl_w[h], m.frac_w[h] = cfg["fmt_w"][h]
             m.iwl_att[h], m.frac_att[h] = cfg["fmt_att"][h]
         m.iwl_bin, m.frac_bin = cfg["fmt_bin"]
+        m.f_shift_based = bool(cfg.get("softmax_shift_based", False))
+        if cfg.get("att_scale") is not None:
+            m.en_sc_att = True
+            for h in range(cfg["n_hop"]):
+                m.sc_att[h] = float(np.float32(cfg["att_scale"][h]))
         keep = []
 
         def hold(a):

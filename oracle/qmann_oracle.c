@@ -603,8 +603,12 @@ static void hop_forward(const qo_model *m, unsigned h, const float *keys, const 
     else /* 10 / 11: the CPU hamming functions on the CUDA word alignment (frac = 31 - iwl) */
         qo_attention_hamming(keys, u, s, n_sen, D, m->iwl_att[h], 31 - m->iwl_att[h], m->num_bit,
                              m->attention_mode == 10 ? 0 : 1);
-    /* softmax over slots: sf_in[h] (MemN2N.c:2651) */
-    qo_softmax_fwd(s, p, n_sen, m->softmax_variant, false);
+    if (taps && taps->scores) memcpy(taps->scores + (size_t)h * n_sen, s, n_sen * sizeof(float));
+    /* optional scale layer sc_sf_in[h] (MemN2N.c:2647-2649): plain float product with one scalar */
+    if (m->en_sc_att)
+        for (unsigned i = 0; i < n_sen; i++) s[i] = s[i] * m->sc_att[h];
+    /* softmax over slots: sf_in[h] (MemN2N.c:2651; constructor :856 carries f_shift_based) */
+    qo_softmax_fwd(s, p, n_sen, m->softmax_variant, m->f_shift_based);
     /* weighted read-out: w_sum[h] (constructor MemN2N.c:863, formats (iwl[h],frac[h])) */
     if (m->attention_mode == 1)
         qo_dot_mat_vec_fwd(vals, p, o, n_sen, D, true, false, 0, 0, 0, 0);
@@ -621,7 +625,6 @@ static void hop_forward(const qo_model *m, unsigned h, const float *keys, const 
     else
         memcpy(lu, u, D * sizeof(float));
     if (taps) {
-        if (taps->scores) memcpy(taps->scores + (size_t)h * n_sen, s, n_sen * sizeof(float));
         if (taps->probs) memcpy(taps->probs + (size_t)h * n_sen, p, n_sen * sizeof(float));
         if (taps->o) memcpy(taps->o + (size_t)h * D, o, D * sizeof(float));
         if (taps->lu) memcpy(taps->lu + (size_t)h * D, lu, D * sizeof(float));

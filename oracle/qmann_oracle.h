@@ -130,6 +130,10 @@ typedef struct {
     const float *w_c[QO_MAX_HOP];     /* [D][dim_input]          emb_c   :838 */
     const float *w_h[QO_MAX_HOP];     /* [D][D]                  lin_map :873 */
     const float *w_ans;               /* [dim_input][D], float   ds_ans  :902-906 */
+    /* optional in-hop softmax variants (all zero = off) */
+    bool     f_shift_based;           /* EN_SHIFT_BASED_SM: sf_in only, MemN2N.c:856 (sf_out never, :910) */
+    bool     en_sc_att;               /* EN_SC_ATT: scale layer between dotmv and sf_in, MemN2N.c:2647-2651 */
+    float    sc_att[QO_MAX_HOP];      /* its scalar weight per hop (out = in * w, lib/layer_cuda.cu:1551-1558) */
 } qo_model;
 
 typedef struct {                 /* optional taps; any pointer may be NULL */

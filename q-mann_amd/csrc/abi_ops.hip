@@ -180,7 +180,14 @@ k_softmax(const float *__restrict__ in, float *__restrict__ out, float *__restri
     } else {
         float part = 0.0f;
         for (unsigned i = threadIdx.x; i < dim; i += kBlock) {
-            const float e = shift_based ? exp2f(in[i] - mx + 1.0f) : exp2f(in[i] - mx);
+            float e;
+            if (base == 2) {                          // piece-wise linear exp (lib/common.c:51-73)
+                const float x = in[i] - mx;
+                e = fmaxf(fmaxf(0.597226f * x + 0.933989f, 0.141642f * x + 0.43981f),
+                          fmaxf(0.070265f * x + 0.10888f, 0.0f * x + 0.0f));
+            } else {
+                e = shift_based ? exp2f(in[i] - mx + 1.0f) : exp2f(in[i] - mx);
+            }
             out[i] = e;
             part += e;
         }
@@ -300,7 +307,7 @@ inline void free_dev(void *p)
 
 extern "C" {
 
-void qmann_abi_set_softmax_base(int base) { g_softmax_base = base ? 1 : 0; }
+void qmann_abi_set_softmax_base(int base) { g_softmax_base = (base == 1 || base == 2) ? base : 0; }
 unsigned int qmann_abi_symbol_count(void) { return 66u; }
 
 // ---------------------------------------------------------------- dot_mat_vec

@@ -94,27 +94,25 @@ k_hops_fixed(const HopArgs a)
         uint32_t n_live = 0;
         if (S > 0) {
             // each thread owns bins tid, tid + nthreads, ... (4 bins per thread in a one-wavefront group)
-            int dmax = -1;
+            const SmCfg smc = sm_cfg(a, h);
+            auto bin_x = [&](uint32_t d) { return sm_scaled((float)((int)d - 127) / (float)(1 << fm.frac), smc); };
+            float xmax = -INFINITY;
             for (uint32_t d = tid; d < 256; d += nthreads) {
                 uint32_t cnt = 0;
                 for (uint32_t i = 0; i < nwaves; i++) cnt += hist[i * 256 + d];
                 hist[d] = cnt;                                  // bins are thread-private from here on
-                if (cnt) dmax = (int)d;
+                if (cnt) xmax = fmaxf(xmax, bin_x(d));
             }
-            dmax = block_max_int(dmax, (int *)red, lane, wave);
+            xmax = block_max<float>(xmax, (float *)red, lane, wave);
             double part = 0.0;
             for (uint32_t d = tid; d < 256; d += nthreads) {
-                const float x = (float)((int)d - dmax) / (float)(1 << fm.frac);   // score - max, exact
-                const float e = (a.softmax_base == QMANN_SOFTMAX_EXP) ? expf(x) : exp2f(x);
+                const float e = sm_exp(bin_x(d) - xmax, smc);  // score - max: exact on the score grid
                 ptab[d] = e;
                 if (hist[d]) part += (double)hist[d] * (double)e;
             }
             const double total = block_sum_double(part, red, lane, wave);
             for (uint32_t d = tid; d < 256; d += nthreads) {
-                float p = 0.0f;
-                if (hist[d])
-                    p = (a.softmax_base == QMANN_SOFTMAX_EXP) ? (float)((double)ptab[d] / total)
-                                                              : ptab[d] / (float)total;
+                const float p = hist[d] ? sm_quot(ptab[d], total, smc) : 0.0f;
                 ptab[d] = p;
                 kplut[d] = (uint8_t)qm_code(p, fa.iwl, fa.frac);
             }
@@ -196,19 +194,16 @@ k_hops_small(const HopArgs a)
         // softmax over slots, slot r in lane r
         const bool live = lane < S;
         const int code = live ? (int)sc[lane] : -128;
-        int mx = code;
+        const SmCfg smc = sm_cfg(a, h);
+        const float xs = live ? sm_scaled((float)code / (float)(1 << fm.frac), smc) : -INFINITY;
+        float mx = xs;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const int t = __shfl_xor(mx, o);
-            mx = t > mx ? t : mx;
-        }
-        const float x = (float)(code - mx) / (float)(1 << fm.frac);      // score - max, exact
-        const float e = live ? ((a.softmax_base == QMANN_SOFTMAX_EXP) ? expf(x) : exp2f(x)) : 0.0f;
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        const float e = live ? sm_exp(xs - mx, smc) : 0.0f;              // score - max, exact on the score grid
         double total = (double)e;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
-        float p = 0.0f;
-        if (live) p = (a.softmax_base == QMANN_SOFTMAX_EXP) ? (float)((double)e / total) : e / (float)total;
+        const float p = live ? sm_quot(e, total, smc) : 0.0f;
         const int kp = live ? qm_code(p, fa.iwl, fa.frac) : 0;
         if (live) {
             const size_t tb = (size_t)h * a.rows_total + r0 + lane;
@@ -298,7 +293,7 @@ int qmann_hops_i8(const qmann_net *net, const int8_t *keys, const int8_t *vals, 
     if (net->attention_mode == QMANN_ATT_APPX)
         return qmann_hops_appx_impl(net, keys, vals, hop_stride, row_off, max_slots, u0, u_out, taps, n_query, stream);
     if (net->attention_mode != QMANN_ATT_FIXED && net->attention_mode != QMANN_ATT_FLOAT) return QMANN_EUNSUPPORTED;
-    if (net->softmax_base > QMANN_SOFTMAX_POW2) return QMANN_EINVAL;
+    if (net->softmax_base > QMANN_SOFTMAX_EXP_PLAN) return QMANN_EINVAL;
     if (!fmt8(net->bin)) return QMANN_ERANGE;
     for (uint32_t h = 0; h < net->n_hop; h++) {
         if (!fmt8(net->act[h]) || !fmt8(net->w[h]) || !fmt8(net->att[h])) return QMANN_ERANGE;
@@ -319,7 +314,9 @@ int qmann_hops_i8(const qmann_net *net, const int8_t *keys, const int8_t *vals, 
     a.rows_total = (uint32_t)(hop_stride / net->dim_emb_pad);
     a.n_hop = net->n_hop; a.D = net->dim_emb; a.Dp = net->dim_emb_pad;
     a.softmax_base = net->softmax_base; a.en_lin_map = net->en_lin_map;
+    a.softmax_shift = net->softmax_shift_based; a.en_att_scale = net->en_att_scale;
     for (uint32_t h = 0; h < net->n_hop; h++) {
+        a.att_scale[h] = net->att_scale[h];
         a.lin_map[h] = net->lin_map[h];
         a.act[h] = QFmt{net->act[h].iwl, net->act[h].frac};
         a.w[h] = QFmt{net->w[h].iwl, net->w[h].frac};

@@ -89,25 +89,23 @@ k_hops_float(const HopArgs a)
         // softmax per slot (lib/layer_cuda.cu:1895-1916, 1969-2060); p replaces the score in place
         float *pf = (float *)sc;
         if (S > 0) {
-            int mx = INT32_MIN;
-            for (uint32_t r = tid; r < S; r += kBlock) mx = sc[r] > mx ? sc[r] : mx;
-            mx = block_max_int(mx, (int *)red, lane, wave);
-            const float fmx = (float)mx * scale;
+            const SmCfg smc = sm_cfg(a, h);
+            auto slot_x = [&](int sv) { return sm_scaled((float)sv * scale, smc); };   // (float)sv . scale is exact
+            float xmax = -INFINITY;
+            for (uint32_t r = tid; r < S; r += kBlock) xmax = fmaxf(xmax, slot_x(sc[r]));
+            xmax = block_max<float>(xmax, (float *)red, lane, wave);
             double psum = 0.0;
-            for (uint32_t r = tid; r < S; r += kBlock) {
-                const float x = (float)sc[r] * scale - fmx;        // both exact floats; the difference is exact too
-                psum += (double)((a.softmax_base == QMANN_SOFTMAX_EXP) ? expf(x) : exp2f(x));
-            }
+            for (uint32_t r = tid; r < S; r += kBlock) psum += (double)sm_exp(slot_x(sc[r]) - xmax, smc);
             const double total = block_sum_double(psum, red, lane, wave);
-            const double inv_total = 1.0 / total;               // e . (1/total): within an ulp of e / total, and p is
-            const float inv_total_f = 1.0f / (float)total;      // not quantised in this mode (tolerance 1e-5)
+            // stock e^x softmax: e . (1/total) is within an ulp of e / total, and p is not quantised in this
+            // mode (tolerance 1e-5); the variants go through the general quotient
+            const bool stock = smc.base == QMANN_SOFTMAX_EXP && !smc.shift;
+            const double inv_total = 1.0 / total;
             const size_t tb = (size_t)h * a.rows_total + r0;
             for (uint32_t r = tid; r < S; r += kBlock) {
                 const int sv = sc[r];
-                const float x = (float)sv * scale - fmx;
-                float p;
-                if (a.softmax_base == QMANN_SOFTMAX_EXP) p = (float)((double)expf(x) * inv_total);
-                else p = exp2f(x) * inv_total_f;
+                const float e = sm_exp(slot_x(sv) - xmax, smc);
+                const float p = stock ? (float)((double)e * inv_total) : sm_quot(e, total, smc);
                 if (a.tap_codes) a.tap_codes[tb + r] = sv;
                 if (a.tap_scores) a.tap_scores[tb + r] = (float)sv * scale;
                 if (a.tap_probs) a.tap_probs[tb + r] = p;

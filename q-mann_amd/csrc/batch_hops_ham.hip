@@ -223,21 +223,20 @@ k_hops_ham(const HopArgs a, const uint32_t key_row_bytes, const uint32_t lds_slo
         uint32_t n_live = 0;
         if (MODE == kModeV0 && S > 0) {
             // one exp per distinct count; normaliser sum_d count[d] . e[d] in double (lib/layer_cuda.cu:2024-2042)
-            int dmax = -1;
-            for (uint32_t d = tid; d < nbins; d += kBlock) dmax = v0_hist[d] ? (int)d : dmax;
-            dmax = block_max_int(dmax, (int *)red, lane, wave);
+            const SmCfg smc = sm_cfg(a, h);
+            float xmax = -INFINITY;
+            for (uint32_t d = tid; d < nbins; d += kBlock)
+                if (v0_hist[d]) xmax = fmaxf(xmax, sm_scaled((float)d, smc));
+            xmax = block_max<float>(xmax, (float *)red, lane, wave);
             double part = 0.0;
             for (uint32_t d = tid; d < nbins; d += kBlock) {
-                const float x = (float)((int)d - dmax);
-                const float e = (a.softmax_base == QMANN_SOFTMAX_EXP) ? expf(x) : exp2f(x);
+                const float e = sm_exp(sm_scaled((float)d, smc) - xmax, smc);
                 v0_p[d] = e;
                 if (v0_hist[d]) part += (double)v0_hist[d] * (double)e;
             }
             const double total = block_sum_double(part, red, lane, wave);
             for (uint32_t d = tid; d < nbins; d += kBlock) {
-                float p = 0.0f;
-                if (v0_hist[d])
-                    p = (a.softmax_base == QMANN_SOFTMAX_EXP) ? (float)((double)v0_p[d] / total) : v0_p[d] / (float)total;
+                const float p = v0_hist[d] ? sm_quot(v0_p[d], total, smc) : 0.0f;
                 v0_p[d] = p;
                 v0_kp[d] = (uint8_t)qm_code(p, fa.iwl, fa.frac);
             }
@@ -257,21 +256,18 @@ k_hops_ham(const HopArgs a, const uint32_t key_row_bytes, const uint32_t lds_slo
             __syncthreads();
             n_live = misc[0];
         } else if (S > 0) {
-            int mx = INT32_MIN;
-            for (uint32_t r = tid; r < S; r += kBlock) mx = sc[r] > mx ? sc[r] : mx;
-            mx = block_max_int(mx, (int *)red, lane, wave);
+            const SmCfg smc = sm_cfg(a, h);
+            // (float)score . scale is exact (integers below 2^24 times a power of two)
+            auto slot_x = [&](uint32_t r) { return sm_scaled((float)sc[r] * scale, smc); };
+            float xmax = -INFINITY;
+            for (uint32_t r = tid; r < S; r += kBlock) xmax = fmaxf(xmax, slot_x(r));
+            xmax = block_max<float>(xmax, (float *)red, lane, wave);
             double part = 0.0;
-            for (uint32_t r = tid; r < S; r += kBlock) {
-                const float x = (float)(sc[r] - mx) * scale;           // exact: score - max on the score grid
-                part += (double)((a.softmax_base == QMANN_SOFTMAX_EXP) ? expf(x) : exp2f(x));
-            }
+            for (uint32_t r = tid; r < S; r += kBlock) part += (double)sm_exp(slot_x(r) - xmax, smc);
             const double total = block_sum_double(part, red, lane, wave);
             const size_t tb = (size_t)h * a.rows_total + r0;
             for (uint32_t r = tid; r < S; r += kBlock) {
-                const float x = (float)(sc[r] - mx) * scale;
-                float p;
-                if (a.softmax_base == QMANN_SOFTMAX_EXP) p = (float)((double)expf(x) / total);
-                else p = exp2f(x) / (float)total;
+                const float p = sm_quot(sm_exp(slot_x(r) - xmax, smc), total, smc);
                 if (a.tap_codes) a.tap_codes[tb + r] = sc[r];
                 if (a.tap_scores) a.tap_scores[tb + r] = (float)sc[r] * scale;
                 if (a.tap_probs) a.tap_probs[tb + r] = p;
@@ -285,9 +281,7 @@ k_hops_ham(const HopArgs a, const uint32_t key_row_bytes, const uint32_t lds_slo
             n_live = misc[0];
             if (n_live > (uint32_t)kLiveCap) {                  // keep the overflow path exact: park Q(p) in sc
                 for (uint32_t r = tid; r < S; r += kBlock) {
-                    const float x = (float)(sc[r] - mx) * scale;
-                    const float p = (a.softmax_base == QMANN_SOFTMAX_EXP) ? (float)((double)expf(x) / total)
-                                                                          : exp2f(x) / (float)total;
+                    const float p = sm_quot(sm_exp(slot_x(r) - xmax, smc), total, smc);
                     sc[r] = (score_t)qm_code(p, fa.iwl, fa.frac);
                 }
                 __syncthreads();
@@ -333,7 +327,7 @@ int fill_args(HopArgs &a, const qmann_net *net, const void *keys, const int8_t *
     if (net->n_hop == 0 || net->n_hop > QMANN_MAX_HOP) return QMANN_EINVAL;
     if (net->dim_emb == 0 || net->dim_emb > net->dim_emb_pad) return QMANN_EINVAL;
     if (net->dim_emb_pad != 64 && net->dim_emb_pad != 128 && net->dim_emb_pad != 256) return QMANN_EUNSUPPORTED;
-    if (net->softmax_base > QMANN_SOFTMAX_POW2) return QMANN_EINVAL;
+    if (net->softmax_base > QMANN_SOFTMAX_EXP_PLAN) return QMANN_EINVAL;
     if (!fmt8(net->bin)) return QMANN_ERANGE;
     for (uint32_t h = 0; h < net->n_hop; h++) {
         if (!fmt8(net->act[h]) || !fmt8(net->w[h]) || !fmt8(net->att[h])) return QMANN_ERANGE;
@@ -354,7 +348,9 @@ int fill_args(HopArgs &a, const qmann_net *net, const void *keys, const int8_t *
     a.rows_total = (uint32_t)(val_hop_stride / net->dim_emb_pad);
     a.n_hop = net->n_hop; a.D = net->dim_emb; a.Dp = net->dim_emb_pad;
     a.softmax_base = net->softmax_base; a.en_lin_map = net->en_lin_map;
+    a.softmax_shift = net->softmax_shift_based; a.en_att_scale = net->en_att_scale;
     for (uint32_t h = 0; h < net->n_hop; h++) {
+        a.att_scale[h] = net->att_scale[h];
         a.lin_map[h] = net->lin_map[h];
         a.act[h] = QFmt{net->act[h].iwl, net->act[h].frac};
         a.w[h] = QFmt{net->w[h].iwl, net->w[h].frac};

@@ -1,15 +1,9 @@
 // batch_io.hip -- the stages either side of the hop loop, batched over queries:
 // story / question embedding into int8 memories, and the answer layer
 // (projection, softmax, arg-max, test-phase bookkeeping).
-#include "qfmt.h"
-#include "rt.h"
-#include "../../include/qmann_batch.h"
+#include "hops_common.h"
 
 namespace {
-
-constexpr int kWave = 64;
-constexpr int kBlock = 256;
-constexpr int kWaves = kBlock / kWave;
 
 // ---------------------------------------------------------------------------
 // Answer layer.  One workgroup per query.  Thread v owns logit v and sums over
@@ -71,7 +65,7 @@ k_answer(const float *__restrict__ w_ans, const float *__restrict__ u, const uin
 
     double part = 0.0;
     for (uint32_t v = tid; v < V; v += kBlock) {
-        const float e = (softmax_base == QMANN_SOFTMAX_EXP) ? expf(lg[v] - mx) : exp2f(lg[v] - mx);
+        const float e = sm_exp(lg[v] - mx, SmCfg{softmax_base, false, false, 1.0f});    // sf_out is never shift-based
         lg[v] = e;
         part += (double)e;
     }
@@ -156,7 +150,7 @@ k_answer_small(const float *__restrict__ w_ans, const float *__restrict__ u, con
             const float t = __shfl_xor(mx, o);
             mx = t > mx ? t : mx;
         }
-        const float e = live ? ((softmax_base == QMANN_SOFTMAX_EXP) ? expf(sum - mx) : exp2f(sum - mx)) : 0.0f;
+        const float e = live ? sm_exp(sum - mx, SmCfg{softmax_base, false, false, 1.0f}) : 0.0f;
         double total = (double)e;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);

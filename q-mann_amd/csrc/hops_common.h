@@ -26,6 +26,8 @@ struct HopArgs {
     uint32_t rows_total;
     uint32_t n_hop, D, Dp, softmax_base, en_lin_map;
     QFmt act[QMANN_MAX_HOP], w[QMANN_MAX_HOP], att[QMANN_MAX_HOP], bin;
+    uint32_t softmax_shift, en_att_scale;     // in-hop softmax variants (qmann_net)
+    float att_scale[QMANN_MAX_HOP];
 };
 }  // namespace qmann
 using qmann::HopArgs;
@@ -230,21 +232,26 @@ __device__ __forceinline__ int sm_decode(uint8_t b)
 }
 
 // block reductions; workgroups are 1 or 4 wavefronts (blockDim.x = 64 or 256)
-__device__ __forceinline__ int block_max_int(int v, int *scratch, uint32_t lane, uint32_t wave)
+template <typename T>
+__device__ __forceinline__ T block_max(T v, T *scratch, uint32_t lane, uint32_t wave)
 {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-        const int t = __shfl_xor(v, o);
+        const T t = __shfl_xor(v, o);
         v = t > v ? t : v;
     }
     const uint32_t nwaves = blockDim.x / kWave;
     if (nwaves == 1) return v;
     if (lane == 0) scratch[wave] = v;
     __syncthreads();
-    int r = scratch[0];
+    T r = scratch[0];
     for (uint32_t i = 1; i < nwaves; i++) r = scratch[i] > r ? scratch[i] : r;
     __syncthreads();
     return r;
+}
+__device__ __forceinline__ int block_max_int(int v, int *scratch, uint32_t lane, uint32_t wave)
+{
+    return block_max<int>(v, scratch, lane, wave);
 }
 
 __device__ __forceinline__ double block_sum_double(double v, double *scratch, uint32_t lane, uint32_t wave)
@@ -259,6 +266,43 @@ __device__ __forceinline__ double block_sum_double(double v, double *scratch, ui
     for (uint32_t i = 1; i < nwaves; i++) r += scratch[i];
     __syncthreads();
     return r;
+}
+
+// ---- softmax variants over slots ----------------------------------------------------------------
+// base EXP : e^(x-max), double normaliser, float quotient of the double division (lib/layer_cuda.cu:2006-2042);
+//            shift-based: divided by the integer llrint(log2(total)) instead (:2038)
+// base POW2: 2^(x-max), float quotient (lib/layer.c:1225-1243); shift-based: 2^(x-max+1) (:1217)
+// base PLAN: four-segment piece-wise linear exp (lib/common.c:51-73, table lib/common.h:270-286)
+// optional scale layer in front: x = score . w, one float product (lib/layer_cuda.cu:1551-1558, 4822)
+struct SmCfg {
+    uint32_t base;
+    bool shift, en_scale;
+    float scale;
+};
+__device__ __forceinline__ SmCfg sm_cfg(const HopArgs &a, uint32_t h)
+{
+    return SmCfg{a.softmax_base, a.softmax_shift != 0, a.en_att_scale != 0, a.att_scale[h]};
+}
+__device__ __forceinline__ float sm_scaled(float score, const SmCfg &c) { return c.en_scale ? score * c.scale : score; }
+__device__ __forceinline__ float sm_exp_plan(float x)
+{
+    float o = 0.597226f * x + 0.933989f;
+    o = fmaxf(o, 0.141642f * x + 0.43981f);
+    o = fmaxf(o, 0.070265f * x + 0.10888f);
+    return fmaxf(o, 0.0f * x + 0.0f);
+}
+// x = (scaled) score - max
+__device__ __forceinline__ float sm_exp(float x, const SmCfg &c)
+{
+    if (c.base == QMANN_SOFTMAX_EXP) return expf(x);
+    if (c.base == QMANN_SOFTMAX_EXP_PLAN) return sm_exp_plan(x);
+    return exp2f(c.shift ? x + 1.0f : x);
+}
+__device__ __forceinline__ float sm_quot(float e, double total, const SmCfg &c)
+{
+    if (c.base == QMANN_SOFTMAX_EXP)
+        return c.shift ? e / (float)llrintf(log2f((float)total)) : (float)((double)e / total);
+    return e / (float)total;
 }
 
 // Stages after the softmax, shared by every attention mode:

@@ -80,7 +80,12 @@ class QNet:
         n = self.net = abi.Net()
         n.n_hop, n.dim_emb, n.dim_emb_pad, n.dim_input = self.H, self.D, self.Dp, self.V
         n.attention_mode = cfg["attention_mode"]
-        n.softmax_base = cfg.get("softmax_variant", 0)
+        n.softmax_base = cfg.get("softmax_variant", 0)      # 0 e^x, 1 2^x, 2 exp_plan
+        n.softmax_shift_based = 1 if cfg.get("softmax_shift_based") else 0
+        if cfg.get("att_scale") is not None:                # EN_SC_ATT: one learnt scalar per hop
+            n.en_att_scale = 1
+            for h in range(cfg["n_hop"]):
+                n.att_scale[h] = float(np.float32(cfg["att_scale"][h]))
         n.en_lin_map = 1 if cfg.get("en_lin_map", True) else 0
         n.num_bit = cfg.get("num_bit", 8)
         for h in range(self.H):

@@ -53,9 +53,10 @@ def near_step(p, frac, rel=1e-5):
     return (np.abs(x - k) <= rel * np.maximum(1.0, np.abs(x))) & (k > 0)
 
 
-def run_case(env, oracle, cfg, B, S_list, seed, sigma_u=20.0, sigma_k=30.0, sigma_h=1.0):
+def run_case(env, oracle, cfg, B, S_list, seed, sigma_u=20.0, sigma_k=30.0, sigma_h=1.0, extra=None):
     """Random memories (ragged slot counts) -> hops + answer on the GPU vs the oracle per query."""
     torch, model = env.torch, env.model
+    cfg = dict(cfg, **(extra or {}))
     H, D, V = cfg["n_hop"], cfg["dim_emb"], cfg["dim_input"]
     rng = np.random.default_rng(seed)
     wts = weights(seed, H, D, V, sigma_h, with_emb=False)
@@ -218,7 +219,7 @@ def test_babi_end_to_end_from_bag_of_words(env, oracle, gold):
 # ---------------------------------------------------------------------------------------------
 # Hamming family
 # ---------------------------------------------------------------------------------------------
-def run_hamming_case(env, oracle, mode, D, S_list, B, seed, iwl=5, num_bit=8, sigma=40.0):
+def run_hamming_case(env, oracle, mode, D, S_list, B, seed, iwl=5, num_bit=8, sigma=40.0, extra=None):
     """mode 3 (CUDA approximate attention, int8 keys) or 10 / 11 (packed bit planes + popcount)."""
     torch, model = env.torch, env.model
     H, V = 3, 40
@@ -226,6 +227,7 @@ def run_hamming_case(env, oracle, mode, D, S_list, B, seed, iwl=5, num_bit=8, si
     fmt = [(iwl, frac)] * H
     cfg = dict(n_hop=H, dim_emb=D, dim_input=V, attention_mode=mode, softmax_variant=0, f_fixed=True,
                en_lin_map=True, fmt=fmt, fmt_w=list(fmt), fmt_att=list(fmt), fmt_bin=(iwl, frac), num_bit=num_bit)
+    cfg.update(extra or {})
     rng = np.random.default_rng(seed)
     wts = weights(seed, H, D, V, 1.0, with_emb=False)
     net = model.QNet(cfg, wts, device="cuda:0")
@@ -342,6 +344,10 @@ def test_answer_mfma_i8_bit_identical_to_float_path(env, oracle, D, V, B):
 @pytest.mark.parametrize("D,S_list,B", [(60, [1, 2, 10, 50, 64], 10), (128, [33, 300], 6), (256, [7, 129], 4),
                                         (128, [10000, 4097], 3)])
 def test_hops_float_attention(env, oracle, D, S_list, B):
+    run_float_case(env, oracle, D, S_list, B)
+
+
+def run_float_case(env, oracle, D, S_list, B, extra=None):
     torch, model = env.torch, env.model
     H, V, iwl = 3, 40, 5
     frac = 7 - iwl
@@ -349,6 +355,7 @@ def test_hops_float_attention(env, oracle, D, S_list, B):
     fmt_w = [(6, 1), (5, 2), (4, 3)]
     cfg = dict(n_hop=H, dim_emb=D, dim_input=V, attention_mode=1, softmax_variant=0, f_fixed=True, en_lin_map=True,
                fmt=fmt, fmt_w=fmt_w, fmt_att=list(fmt), fmt_bin=(iwl, frac))
+    cfg.update(extra or {})
     rng = np.random.default_rng(D + B)
     wts = weights(D, H, D, V, 1.0, with_emb=False)
     net = model.QNet(cfg, wts)
@@ -466,3 +473,37 @@ def test_word_index_embedding_duplicates_large_tables_ragged(env, V, D, rows):
     torch.cuda.synchronize()
     assert torch.equal(k1, k2) and torch.equal(v1, v2) and torch.equal(u1, u2)
     assert k1.abs().sum().item() > 0
+
+
+# ---------------------------------------------------------------------------------------------
+# in-hop softmax variants: exp_plan, shift-based, the scale layer
+# ---------------------------------------------------------------------------------------------
+SM_VARIANTS = {
+    "exp_plan": dict(softmax_variant=2),
+    "pow2_shift": dict(softmax_variant=1, softmax_shift_based=True),
+    # e^x / llrint(log2(total)) needs total >= 1.5: the scale layer compresses the scores
+    "exp_shift_scaled": dict(softmax_variant=0, softmax_shift_based=True, att_scale=[0.02, 0.015, 0.03]),
+    "scale_negative": dict(softmax_variant=0, att_scale=[-0.5, 0.25, -0.125]),
+    "scale_pow2": dict(softmax_variant=1, att_scale=[0.3, 0.7, 1.9]),
+}
+
+
+@pytest.mark.parametrize("variant", sorted(SM_VARIANTS))
+@pytest.mark.parametrize("path", ["fixed_small", "fixed_hist", "appx", "v0", "v1", "float"])
+def test_hops_softmax_variants(env, oracle, path, variant):
+    extra = dict(SM_VARIANTS[variant])
+    if path in ("appx", "v0", "v1") and variant == "exp_shift_scaled":
+        # Hamming scores span hundreds of units: compress harder so the normaliser stays >= 2
+        extra["att_scale"] = [0.002, 0.001, 0.0015]
+    if path == "fixed_small":
+        run_case(env, oracle, cfg_synth(60, 40, 5), B=12, S_list=[1, 2, 5, 17, 50, 64], seed=900, extra=extra)
+    elif path == "fixed_hist":
+        run_case(env, oracle, cfg_synth(128, 40, 5), B=6, S_list=[65, 300, 1000], seed=901, extra=extra)
+    elif path == "appx":
+        run_hamming_case(env, oracle, 3, 128, [1, 9, 64, 200], B=8, seed=902, extra=extra)
+    elif path == "v0":
+        run_hamming_case(env, oracle, 10, 128, [1, 9, 64, 200], B=8, seed=903, num_bit=4, extra=extra)
+    elif path == "v1":
+        run_hamming_case(env, oracle, 11, 128, [1, 9, 64, 200], B=8, seed=904, num_bit=8, extra=extra)
+    else:
+        run_float_case(env, oracle, 60, [1, 2, 10, 50, 64, 300], 6, extra=extra)
