@@ -40,7 +40,7 @@ extern "C" {
 
 #define QMANN_MAX_HOP 8
 
-enum { QMANN_OK = 0, QMANN_EINVAL = -1, QMANN_ERANGE = -2, QMANN_EUNSUPPORTED = -3 };
+enum { QMANN_OK = 0, QMANN_EINVAL = -1, QMANN_ERANGE = -2, QMANN_EUNSUPPORTED = -3, QMANN_EIO = -4 };
 
 /* attention_mode: MemN2N/define.h:10-15 (1..3) plus the packed-code Hamming forms */
 enum {

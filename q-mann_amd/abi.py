@@ -40,6 +40,15 @@ class Net(C.Structure):
     ]
 
 
+class Weights(C.Structure):
+    """include/qmann_weights.h: host matrices, row-major."""
+    _fields_ = [
+        ("n_hop", C.c_uint32), ("dim_emb", C.c_uint32), ("dim_input", C.c_uint32),
+        ("w_q", _vp), ("w_a", _vp * QMANN_MAX_HOP), ("w_c", _vp * QMANN_MAX_HOP), ("w_h", _vp * QMANN_MAX_HOP),
+        ("w_ans", _vp),
+    ]
+
+
 class Taps(C.Structure):
     _fields_ = [("score_codes", _vp), ("scores", _vp), ("probs", _vp), ("o", _vp), ("u", _vp)]
 
@@ -126,6 +135,8 @@ _proto("qmann_embed_story_idx", C.c_int, [C.POINTER(Net), _vp, C.c_uint32, C.c_u
                                           C.POINTER(_vp), _vp, _vp, C.c_size_t, _vp])
 _proto("qmann_embed_query_idx", C.c_int, [C.POINTER(Net), _vp, C.c_uint32, _vp, _vp, C.c_uint32, _vp])
 _proto("qmann_embed_query", C.c_int, [C.POINTER(Net), _vp, _vp, _vp, C.c_uint32, _vp])
+_proto("qmann_weights_save", C.c_int, [C.c_char_p, C.POINTER(Weights), C.POINTER(Fmt)])
+_proto("qmann_weights_load", C.c_int, [C.c_char_p, C.POINTER(Weights), C.c_int, C.POINTER(Fmt)])
 
 
 def check(rc: int, what: str):

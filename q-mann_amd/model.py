@@ -56,6 +56,43 @@ def babi_cfg(dim_input, attention_mode=2, softmax_base=0, iwl=5, n_hop=3, D=60, 
                 fmt_att=list(fmt), fmt_bin=(iwl, frac))
 
 
+def _weights_struct(w: dict, H: int, D: int, V: int, en_lin_map: bool):
+    """abi.Weights over contiguous float32 numpy arrays (kept alive by the caller's dict)."""
+    ws = abi.Weights()
+    ws.n_hop, ws.dim_emb, ws.dim_input = H, D, V
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    ws.w_q, ws.w_ans = ptr(w["w_q"]), ptr(w["w_ans"])
+    for h in range(H):
+        ws.w_a[h], ws.w_c[h] = ptr(w["w_a"][h]), ptr(w["w_c"][h])
+        if en_lin_map:
+            ws.w_h[h] = ptr(w["w_h"][h])
+    return ws
+
+
+def save_weights(directory, weights: dict, cfg: dict, fixed: bool = True):
+    """Write the reference-layout weight files (include/qmann_weights.h) for `weights` (the dict QNet takes)."""
+    H, D, V = cfg["n_hop"], cfg["dim_emb"], cfg["dim_input"]
+    lin = bool(cfg.get("en_lin_map", True))
+    w = {k: ([np.ascontiguousarray(m, np.float32) for m in v] if isinstance(v, (list, tuple))
+             else np.ascontiguousarray(v, np.float32)) for k, v in weights.items()}
+    fm = (abi.Fmt * H)(*[abi.Fmt(*f) for f in cfg["fmt_w"]]) if fixed else None
+    abi.check(abi.lib.qmann_weights_save(str(directory).encode(), C.byref(_weights_struct(w, H, D, V, lin)), fm),
+              "qmann_weights_save")
+
+
+def load_weights(directory, cfg: dict, from_fixed: bool = False) -> dict:
+    """Read the weight files back into the dict QNet takes (from_fixed: decode the *_fixed files on cfg['fmt_w'])."""
+    H, D, V = cfg["n_hop"], cfg["dim_emb"], cfg["dim_input"]
+    lin = bool(cfg.get("en_lin_map", True))
+    w = {"w_q": np.empty((D, V), np.float32), "w_ans": np.empty((V, D), np.float32),
+         "w_a": [np.empty((D, V), np.float32) for _ in range(H)], "w_c": [np.empty((D, V), np.float32) for _ in range(H)],
+         "w_h": [np.empty((D, D), np.float32) for _ in range(H)] if lin else None}
+    fm = (abi.Fmt * H)(*[abi.Fmt(*f) for f in cfg["fmt_w"]])
+    abi.check(abi.lib.qmann_weights_load(str(directory).encode(), C.byref(_weights_struct(w, H, D, V, lin)),
+                                         1 if from_fixed else 0, fm), "qmann_weights_load")
+    return w
+
+
 @dataclass
 class HopTaps:
     score_codes: torch.Tensor

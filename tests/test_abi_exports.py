@@ -20,7 +20,9 @@ def test_library_loads_and_reports_66(abi):
 
 
 def test_every_declared_symbol_is_exported(abi):
-    declared = abi.header_symbols("qmann_abi.h") + abi.header_symbols("qmann_batch.h")
+    declared = (abi.header_symbols("qmann_abi.h") + abi.header_symbols("qmann_batch.h")
+                + abi.header_symbols("qmann_weights.h"))
+    assert "qmann_weights_save" in declared and "qmann_weights_load" in declared
     cuda = [s for s in declared if s.startswith("cuda_")]
     assert len(cuda) == 66, len(cuda)
     missing = [s for s in declared if not hasattr(abi.lib, s)]
@@ -31,7 +33,8 @@ def test_symbols_are_unmangled_c(abi):
     out = subprocess.run(["nm", "-D", "--defined-only", str(abi.LIB_PATH)], capture_output=True, text=True,
                          check=True).stdout
     names = {l.split()[-1] for l in out.splitlines() if " T " in l}
-    for s in abi.header_symbols("qmann_abi.h") + abi.header_symbols("qmann_batch.h"):
+    for s in (abi.header_symbols("qmann_abi.h") + abi.header_symbols("qmann_batch.h")
+              + abi.header_symbols("qmann_weights.h")):
         assert s in names, s
 
 

@@ -507,3 +507,41 @@ def test_hops_softmax_variants(env, oracle, path, variant):
         run_hamming_case(env, oracle, 11, 128, [1, 9, 64, 200], B=8, seed=904, num_bit=8, extra=extra)
     else:
         run_float_case(env, oracle, 60, [1, 2, 10, 50, 64, 300], 6, extra=extra)
+
+
+# ---------------------------------------------------------------------------------------------
+# weight files: inference that starts from files, without training
+# ---------------------------------------------------------------------------------------------
+def test_forward_from_weight_files_equals_forward_from_memory(env, oracle, gold, tmp_path):
+    """Save (float + fixed-point words), load either set back, run the bAbI fixture through the full
+    forward: the float files reproduce the original model bit for bit, and so do the fixed files --
+    every layer quantises its weights on the way in and Q(Q(w)) = Q(w) -- except for the float answer
+    matrix, which is read from w_float.bin in both cases."""
+    torch, model = env.torch, env.model
+    b = gold("babi_qa1_test64.npz")
+    V = int(b["dim_input"])
+    cfg = model.babi_cfg(V, 2, 0, iwl=2)
+    wts = weights(404, 3, 60, V, 0.8)
+    model.save_weights(tmp_path, wts, cfg, fixed=True)
+    story = torch.from_numpy(b["story"].astype(np.float32)).to(env.dev)
+    ques = torch.from_numpy(b["question"].astype(np.float32)).to(env.dev)
+    n_sen = b["n_sen"].astype(np.int64)
+    row_off = torch.from_numpy(np.concatenate([[0], np.cumsum(n_sen)]).astype(np.int32)).to(env.dev)
+    outs = []
+    for w in (wts, model.load_weights(tmp_path, cfg), model.load_weights(tmp_path, cfg, from_fixed=True)):
+        net = model.QNet(cfg, w)
+        r = net.forward_bow(story, ques, row_off, int(n_sen.max()))
+        torch.cuda.synchronize()
+        outs.append((r["pred"].cpu().numpy(), r["u"].cpu().numpy()))
+    for pred, u in outs[1:]:
+        np.testing.assert_array_equal(u, outs[0][1])
+        np.testing.assert_array_equal(pred, outs[0][0])
+    # and the model is the oracle's model
+    m = oracle.make_model(cfg, wts)
+    o = 0
+    for q in range(8):
+        ns = int(n_sen[q])
+        opred, t = oracle.forward(m, b["story"][o:o + ns].astype(np.float32), b["question"][q].astype(np.float32),
+                                  taps=("u", "out_probs"))
+        o += ns
+        np.testing.assert_array_equal(outs[2][1][q], t["u"][2])

@@ -39,6 +39,53 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _worker_files(rank, world, port, q, directory):
+    """Rank 0 reads a model from weight files (fixed-point words), every rank ends with the same matrices."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+    import hashlib
+    import torch.distributed as dist
+    load_pkg()
+    import qmann_amd.model as model
+    from qmann_amd.parallel import broadcast_params
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = model.babi_cfg(30, 2, 0)
+    wts = model.load_weights(directory, cfg, from_fixed=True) if rank == 0 else None
+    wts, _ = broadcast_params(wts, cfg, torch.device("cpu"), rank, world, with_emb=True)
+    h = hashlib.sha256()
+    for k in ("w_q", "w_ans"):
+        h.update(wts[k].tobytes())
+    for k in ("w_a", "w_c", "w_h"):
+        for m in wts[k]:
+            h.update(m.tobytes())
+    q.put((rank, h.hexdigest(), wts["w_a"][2].shape))
+    dist.destroy_process_group()
+
+
+def test_two_rank_broadcast_of_a_file_backed_model(tmp_path):
+    load_pkg()
+    import qmann_amd.model as model
+    cfg = model.babi_cfg(30, 2, 0)
+    rng = np.random.default_rng(11)
+    H, D, V = 3, 60, 30
+    w = {"w_q": rng.normal(0, 1, (D, V)).astype(np.float32), "w_ans": rng.normal(0, 1, (V, D)).astype(np.float32),
+         "w_a": [rng.normal(0, 1, (D, V)).astype(np.float32) for _ in range(H)],
+         "w_c": [rng.normal(0, 1, (D, V)).astype(np.float32) for _ in range(H)],
+         "w_h": [rng.normal(0, 1, (D, D)).astype(np.float32) for _ in range(H)]}
+    model.save_weights(tmp_path, w, cfg, fixed=True)
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_files, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] and res[0][2] == (60, 30)
+
+
 def test_two_rank_broadcast_shard_gather():
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
