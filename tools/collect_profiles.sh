@@ -1,0 +1,24 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (via gpurun): rocprofv3 passes for one bench workload, CSV output under gpurun_out/prof/.
+#   tools/collect_profiles.sh <tag> <workload> [fetch] [sq]
+# kernel trace + stats always; "fetch" adds a FETCH_SIZE counter pass, "sq" an SQ instruction-mix pass
+# (counters are collected in their own runs, never together with tracing).
+set -e
+tag=$1; wl=$2; shift 2
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+P=$R/gpurun_out/prof
+mkdir -p $P
+cd /tmp && export TMPDIR=/tmp
+# only the small summaries travel back (gpurun merges at most 64 MiB): per-dispatch traces are dropped and
+# counter files are cut down to our kernels' rows
+prune() { find "$1" -type f ! -name '*kernel_stats.csv' ! -name '*counter_collection.csv' -delete; 
+          for c in $(find "$1" -name '*counter_collection.csv'); do { head -1 "$c"; grep -E 'k_hops|k_answer|k_embed|k_logits' "$c" || true; } > "$c.tmp"; mv "$c.tmp" "$c"; done; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/${tag}_stats -- python3 $R/bench.py --workload $wl --steps 10 --no-cpu-baseline > $P/${tag}_stats.log 2>&1
+prune $P/${tag}_stats
+for pass in "$@"; do
+  case $pass in
+    fetch) rocprofv3 --pmc FETCH_SIZE --output-format csv -d $P/${tag}_pmc_fetch -- python3 $R/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline > $P/${tag}_pmc_fetch.log 2>&1; prune $P/${tag}_pmc_fetch ;;
+    sq) rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $P/${tag}_pmc_sq -- python3 $R/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline > $P/${tag}_pmc_sq.log 2>&1; prune $P/${tag}_pmc_sq ;;
+  esac
+done
+echo "$tag $wl done"
