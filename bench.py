@@ -163,7 +163,7 @@ def cpu_baseline(cfg, wts, keys, vals, u0, S, D, budget_s=8.0):
     return one, many, preds
 
 
-def run_bow(args, wl, net, cfg, wts, dev, rank, world, model):
+def run_bow(args, name, wl, net, cfg, wts, dev, rank, world, model):
     """configs[1]: the full forward from bag-of-words stories (embedding + hops + answer)."""
     g = np.load(ROOT / "tests" / "golden" / "babi_qa1_test64.npz")
     n_sen = g["n_sen"].astype(np.int64)
@@ -229,7 +229,7 @@ def run_bow(args, wl, net, cfg, wts, dev, rank, world, model):
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int8",
         "data": "bAbI qa1 test stories (64-story fixture from the reference's sample.c, replicated), seeded random weights",
-        "config": {"workload": args.workload, "slots": "2..10 (mean 5.9)", "dim_emb": 60, "dim_input": cfg["dim_input"],
+        "config": {"workload": name, "slots": "2..10 (mean 5.9)", "dim_emb": 60, "dim_input": cfg["dim_input"],
                    "hops": 3, "queries_per_gpu": B, "format": "Q5.2 + EN_MQ weight formats", "attention_mode": 2,
                    "stages": "embed_story + embed_query + hops + answer",
                    "input": "uint16 word indices" if use_idx else "float bag-of-words",
@@ -257,7 +257,7 @@ def run_bow(args, wl, net, cfg, wts, dev, rank, world, model):
         res["host_inputs"] = {"bytes_per_step": int(sum(t.numel() * t.element_size() for t in srcs)), "h2d_ms": best * 1e3,
                               "pcie_inclusive_queries_per_s": B / (step_s + best),
                               "note": "pinned host buffers, copy then compute, no overlap"}
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, str(ROOT / "oracle"))
         from pyoracle import Oracle
         ora = Oracle()
@@ -303,11 +303,7 @@ def run_bow(args, wl, net, cfg, wts, dev, rank, world, model):
                                "one_thread": {"value": reps * len(n_sen) / t_used,
                                               "sample": f"the 64 fixture stories x {reps} passes, {t_used:.1f} s"},
                                "pred_agree": int(sum(int(a == b) for a, b in zip(gp, preds))), "pred_total": len(preds)}
-    if rank == 0:
-        print(json.dumps(res), flush=True)
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    return res
 
 
 def main():
@@ -318,26 +314,52 @@ def main():
     ap.add_argument("--workload", default="synth10k_d128", choices=sorted(WORKLOADS))
     ap.add_argument("--queries", type=int, default=0, help="queries per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="default workload only: skip the |mem| = 50 figure")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # QMANN_BENCH_REHEARSE=1: every rank on cuda:0 over gloo -- rehearses the N > 1 host logic on a one-GPU box
+    rehearse = os.environ.get("QMANN_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
 
     load_pkg()
+    out = run_workload(args, args.workload, dev, rank, world)
+    # BASELINE.json quotes its metric at |mem| = 50 (the bAbI cap) and sets its target at |mem| = 10 000:
+    # the default line is the 10 000-slot configuration and carries the 50-slot figure beside it
+    if args.workload == "synth10k_d128" and not args.no_secondary:
+        sec = run_workload(argparse.Namespace(**{**vars(args), "queries": 0}), "babi_mem50", dev, rank, world)
+        if rank == 0:
+            out["mem50"] = {k: sec[k] for k in ("value", "unit", "ms_per_step", "config", "roofline", "cpu_baseline") if k in sec}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def run_workload(args, name, dev, rank, world):
+    """One workload: W warm-up steps, K timed steps between barriers, max over ranks; returns the result dict."""
     import qmann_amd.abi as abi
     import qmann_amd.model as model
     from qmann_amd.parallel import broadcast_params
+    if world > 1:
+        import torch.distributed as dist
 
-    wl = WORKLOADS[args.workload]
+    wl = WORKLOADS[name]
     S, D, V, mode, nb = wl["S"], wl["D"], wl["V"], wl["mode"], wl["nb"]
     B = args.queries or wl["B"]
     H = 3
@@ -360,8 +382,7 @@ def main():
     w_ans_i8 = net.quantize_i8(net.w_ans, ans_fmt, abi.CODE_TWOS) if wl["ans"] == "i8" else None
 
     if wl.get("bow"):
-        run_bow(args, wl, net, cfg, wts, dev, rank, world, model)
-        return
+        return run_bow(args, name, wl, net, cfg, wts, dev, rank, world, model)
 
     # synthetic per-query memories, resident in HBM before the timed region
     gen = torch.Generator(device=dev)
@@ -422,7 +443,7 @@ def main():
     traffic = None
     tj = ROOT / "profiles" / "traffic.json"
     if tj.exists():
-        rec = json.loads(tj.read_text()).get(args.workload)
+        rec = json.loads(tj.read_text()).get(name)
         if rec and B == wl["B"]:
             traffic = rec["traffic_bytes_per_launch"]
 
@@ -431,11 +452,11 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int8", "data": "synthetic",
-        "config": {"workload": args.workload, "slots": S, "dim_emb": D, "dim_emb_pad": Dp, "hops": H,
+        "config": {"workload": name, "slots": S, "dim_emb": D, "dim_emb_pad": Dp, "hops": H,
                    "queries_per_gpu": B, "format": "Q5.2", "attention_mode": mode,
                    "key_row_bytes": key_row_bytes, "answer_layer": wl["ans"], "dim_answer": V,
                    "parallelism": f"replicas x{world}, query-sharded"},
-        "roofline": {"bound": "hbm", "kernel": KERNEL_OF_MODE[mode], "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": "k_hops_small" if (mode == 2 and S <= 64) else KERNEL_OF_MODE[mode], "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": bytes_per_query * B, "bytes_per_query": bytes_per_query,
                      "kernel_ms": hop_ms},
@@ -445,7 +466,7 @@ def main():
     }
     if bcast_ms is not None:
         out["param_broadcast_ms"] = bcast_ms
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         one, many, preds = cpu_baseline(cfg, wts, keys, vals, u0, S, D)
         n = one["n"]
         gp = pred[:n].cpu().numpy().tolist()
@@ -454,10 +475,7 @@ def main():
                                          f"{many['cores']} threads (one per usable host core), scalar C oracle -O2",
                                "one_thread": {"value": one["qps"], "sample": f"first {n} queries, {one['secs']:.1f} s"},
                                "pred_agree": int(sum(int(a == b) for a, b in zip(gp, preds))), "pred_total": n}
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    return out
 
 
 if __name__ == "__main__":

@@ -14,7 +14,7 @@ st = glob.glob(str(src / f"{tag}_stats" / "*" / "*kernel_stats.csv"))
 if st:
     rows = list(csv.DictReader(open(st[0])))
     with open(out / f"{tag}_kernel_stats_{workload}.csv", "w") as f:
-        f.write(f"# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --workload {workload} --steps 10 --no-cpu-baseline   (MI355X)\n")
+        f.write(f"# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --workload {workload} --steps 10 --no-cpu-baseline --no-secondary   (MI355X)\n")
         f.write("# kernel names cut to 100 chars; torch kernels are the synthetic-data generation\n")
         w = csv.writer(f); w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
         for r in rows:
@@ -33,7 +33,7 @@ if pf:
     m = sum(v) / len(v)
     traffic = 2 * m * 1024
     with open(out / f"{tag}_pmc_fetch_{workload}.txt", "w") as f:
-        f.write(f"rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --workload {workload} --steps 3 --warmup 1 --no-cpu-baseline (MI355X)\n")
+        f.write(f"rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --workload {workload} --steps 3 --warmup 1 --no-cpu-baseline --no-secondary (MI355X)\n")
         f.write(f"dominant kernel: {kname}; {len(v)} dispatches\n")
         f.write(f"FETCH_SIZE per dispatch (KiB, raw): {[round(x, 1) for x in v]}\n")
         f.write(f"mean raw = {m:.1f} KiB = {m * 1024 / 1e9:.3f} GB\n")
@@ -54,7 +54,7 @@ if sq:
         if kernel in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     with open(out / f"{tag}_pmc_sq_{workload}.txt", "w") as f:
-        f.write(f"rocprofv3 --pmc <SQ counters> --output-format csv -- python3 bench.py --workload {workload} --steps 3 --warmup 1 --no-cpu-baseline (MI355X)\n")
+        f.write(f"rocprofv3 --pmc <SQ counters> --output-format csv -- python3 bench.py --workload {workload} --steps 3 --warmup 1 --no-cpu-baseline --no-secondary (MI355X)\n")
         f.write("the k_hops_* kernel, mean per dispatch (SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles)\n")
         for k, v in sorted(agg.items()):
             f.write(f"{k:24s} {sum(v) / len(v):16.0f}\n")
