@@ -55,6 +55,8 @@ WORKLOADS = {
     "synth10k_d128_float": dict(S=10000, D=128, V=256, B=4096, mode=1, nb=8, ans="f32", sk=3.5, sv=30.0, su=3.5),
     "babi_mem50": dict(S=50, D=60, V=80, B=262144, mode=2, nb=8, ans="f32", sk=8.0, sv=30.0, su=8.0),
     "babi_joint_appx": dict(S=50, D=60, V=256, B=262144, mode=3, nb=8, ans="f32", sk=30.0, sv=30.0, su=30.0),
+    # BASELINE.json configs[2] shape with the CPU-spec weighted Hamming score on packed bit planes + popcount
+    "babi_joint_v1": dict(S=50, D=60, V=256, B=262144, mode=11, nb=8, ans="f32", sk=30.0, sv=30.0, su=30.0),
     # BASELINE.json configs[1]: real bAbI task-1 stories (the 64-story fixture produced by the reference's
     # sample.c, replicated), 3 hops, int8, EN_MQ formats, the WHOLE forward from bag-of-words input:
     # story + question embedding, hops, answer layer
@@ -456,7 +458,7 @@ def run_workload(args, name, dev, rank, world):
                    "queries_per_gpu": B, "format": "Q5.2", "attention_mode": mode,
                    "key_row_bytes": key_row_bytes, "answer_layer": wl["ans"], "dim_answer": V,
                    "parallelism": f"replicas x{world}, query-sharded"},
-        "roofline": {"bound": "hbm", "kernel": "k_hops_small" if (mode == 2 and S <= 64) else KERNEL_OF_MODE[mode], "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": "k_hops_small" if (mode != 1 and S <= 64) else KERNEL_OF_MODE[mode], "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": bytes_per_query * B, "bytes_per_query": bytes_per_query,
                      "kernel_ms": hop_ms},

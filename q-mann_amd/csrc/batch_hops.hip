@@ -27,7 +27,7 @@
 //   4. linear map H.u (int8 [D][Dp], L2-resident) and u' = Q(Q(Hu) + Q(o)).
 //
 // All integer work is exact; the only floating-point step is the softmax table.
-#include "hops_common.h"
+#include "hops_small.h"
 
 namespace {
 
@@ -146,90 +146,6 @@ k_hops_fixed(const HopArgs a)
     for (uint32_t c = tid; c < D; c += nthreads) a.u_out[(size_t)q * D + c] = u_f[c];
 }
 
-// Memories of at most 64 slots (bAbI stories: 2..50 sentences): one wavefront per query, slot r in
-// lane r for the softmax -- no histogram, no survivor list, 2.6 KB of LDS, barriers are one-wavefront.
-// Same arithmetic as k_hops_fixed stage by stage.
-template <int LPR>
-__global__ void __launch_bounds__(kWave)
-k_hops_small(const HopArgs a)
-{
-    constexpr uint32_t Dp = LPR * 16, RPW = kWave / LPR;
-    __shared__ float u_f[256];
-    __shared__ float o_f[256];
-    __shared__ short ku[256];
-    __shared__ int8_t sc[kWave];
-    const uint32_t lane = threadIdx.x;
-    const uint32_t q = blockIdx.x;
-    const uint32_t r0 = a.row_off[q];
-    const uint32_t S_in = a.row_off[q + 1] - r0;
-    const uint32_t S = S_in < (uint32_t)kWave ? S_in : (uint32_t)kWave;   // max_slots <= 64 is the caller's promise
-    const uint32_t D = a.D;
-    const uint32_t sub = lane / LPR, chunk = lane % LPR;
-
-    for (uint32_t c = lane; c < 256; c += kWave) u_f[c] = (c < D) ? a.u0[(size_t)q * D + c] : 0.0f;
-    __syncthreads();
-
-    for (uint32_t h = 0; h < a.n_hop; h++) {
-        const QFmt fa = a.act[h], fm = a.att[h], fb = a.bin;
-        const int maxm = (1 << (fm.iwl + fm.frac)) - 1;
-        const int maxa = (1 << (fa.iwl + fa.frac)) - 1;
-        for (uint32_t c = lane; c < Dp; c += kWave) ku[c] = (short)((c < D) ? qm_code(u_f[c], fb.iwl, fb.frac) : 0);
-        __syncthreads();
-
-        // scores: Dp/16 lanes per row, 64/LPR rows per load
-        if (S > 0) {
-            ScanConst c;
-            const uint32_t sh = make_scan_const(c, ku, chunk * 16, fm.iwl + fm.frac, (int)fb.frac);
-            const uint8_t *kb = (const uint8_t *)a.keys + (size_t)h * a.hop_stride + (size_t)r0 * Dp + chunk * 16;
-            for (uint32_t base = 0; base < S; base += RPW) {
-                const uint32_t r = base + sub;
-                i32x4 x = {0, 0, 0, 0};
-                if (r < S) x = *(const i32x4 *)(kb + (size_t)r * Dp);
-                const int v = row_lanes_sum<LPR>(lane_row_sum(x, c, sh));
-                if (chunk == 0 && r < S) sc[r] = (int8_t)(v > maxm ? maxm : (v < -maxm ? -maxm : v));
-            }
-        }
-        __syncthreads();
-
-        // softmax over slots, slot r in lane r
-        const bool live = lane < S;
-        const int code = live ? (int)sc[lane] : -128;
-        const SmCfg smc = sm_cfg(a, h);
-        const float xs = live ? sm_scaled((float)code / (float)(1 << fm.frac), smc) : -INFINITY;
-        float mx = xs;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        const float e = live ? sm_exp(xs - mx, smc) : 0.0f;              // score - max, exact on the score grid
-        double total = (double)e;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
-        const float p = live ? sm_quot(e, total, smc) : 0.0f;
-        const int kp = live ? qm_code(p, fa.iwl, fa.frac) : 0;
-        if (live) {
-            const size_t tb = (size_t)h * a.rows_total + r0 + lane;
-            if (a.tap_codes) a.tap_codes[tb] = code;
-            if (a.tap_scores) a.tap_scores[tb] = (float)code / (float)(1 << fm.frac);
-            if (a.tap_probs) a.tap_probs[tb] = p;
-        }
-
-        // read-out over the rows whose weight code is non-zero (the others add exact zeros)
-        const uint64_t survivors = __ballot(kp != 0);
-        for (uint32_t c = lane; c < Dp; c += kWave) {
-            const uint8_t *vb = (const uint8_t *)a.vals + (size_t)h * a.hop_stride + (size_t)r0 * Dp + c;
-            int acc = 0;
-            for (uint64_t m = survivors; m; m &= m - 1) {
-                const int r = __builtin_ctzll(m);
-                acc += qm_mul_code(__shfl(kp, r), sm_decode(vb[(size_t)r * Dp]), fa.frac, maxa);
-            }
-            acc = acc > maxa ? maxa : (acc < -maxa ? -maxa : acc);
-            o_f[c] = (float)acc / (float)(1 << fa.frac);
-        }
-        __syncthreads();
-        linmap_update<Dp>(a, q, h, ku, u_f, o_f, lane);
-    }
-    for (uint32_t c = lane; c < D; c += kWave) a.u_out[(size_t)q * D + c] = u_f[c];
-}
-
 __global__ void k_quantize_i8(const float *__restrict__ src, int8_t *__restrict__ dst, size_t rows, uint32_t cols,
                               uint32_t pitch, QFmt f, int signmag)
 {
@@ -328,10 +244,10 @@ int qmann_hops_i8(const qmann_net *net, const int8_t *keys, const int8_t *vals, 
         return qmann_hops_float_impl(a, net->dim_emb_pad, max_slots, n_query, stream);
 
     hipStream_t st = (hipStream_t)stream;
-    if (max_slots <= (uint32_t)kWave) {
-        if (net->dim_emb_pad == 64) k_hops_small<4><<<n_query, kWave, 0, st>>>(a);
-        else if (net->dim_emb_pad == 128) k_hops_small<8><<<n_query, kWave, 0, st>>>(a);
-        else k_hops_small<16><<<n_query, kWave, 0, st>>>(a);
+    if (max_slots <= (uint32_t)kWave) {                     // hops_small.h
+        if (net->dim_emb_pad == 64) k_hops_small<4, 4, kModeFixed, 8><<<n_query, kWave, 0, st>>>(a, 64);
+        else if (net->dim_emb_pad == 128) k_hops_small<8, 8, kModeFixed, 8><<<n_query, kWave, 0, st>>>(a, 128);
+        else k_hops_small<16, 16, kModeFixed, 8><<<n_query, kWave, 0, st>>>(a, 256);
         QM_LAUNCH_CHECK();
         return QMANN_OK;
     }

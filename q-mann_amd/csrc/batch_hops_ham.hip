@@ -22,100 +22,14 @@
 // Scores are not on an 8-bit grid here; every mode's row score is bounded by 127.D <= 32512 units,
 // so they are kept as int16 in LDS.  V0 evaluates the softmax once per distinct count (histogram),
 // the other modes per slot (max, sum of exp in double, quotient), as lib/layer_cuda.cu:1969-2060 does.
-#include "hops_common.h"
+#include "ham_common.h"
+#include "hops_small.h"
 
 namespace {
 
 constexpr uint32_t kOffUb = kOffHist;                 // u8  [256]  sign-magnitude bytes of Q_att(u)   (reuses the
 constexpr uint32_t kOffUpl = kOffHist + 256;          // u64 [4][8] bit-planes of u                    histogram area)
 static_assert(kOffUpl % 8 == 0 && kOffUpl + 4 * 8 * 8 <= kOffPtab, "u planes must fit the histogram area");
-
-enum { kModeAppx = 0, kModeV0 = 1, kModeV1 = 2 };
-
-// V0 scores are small counts (0 .. num_bit . D <= 2048): the softmax is evaluated once per distinct
-// count through a histogram (as the fixed-point kernel does per code).  The tables (hist u32, p float,
-// Q(p) u8, each nbins = num_bit . D + 1 entries) sit behind the score array.
-__host__ __device__ inline uint32_t v0_hist_bytes(uint32_t nbins) { return ((nbins * 4 + 15) / 16) * 16; }
-__host__ __device__ inline uint32_t v0_table_bytes(uint32_t nbins) { return 2 * v0_hist_bytes(nbins) + ((nbins + 15) / 16) * 16; }
-
-// ---- APPX: 4 key bytes against 4 query bytes -------------------------------------------------
-struct AppxConst {
-    uint32_t um[4];   // |u| bytes
-    uint32_t us[4];   // 0x80 where u < 0
-    uint32_t m7[4];   // 0x7F in real columns, 0 in padding
-    uint32_t m8[4];   // 0x80 in real columns, 0 in padding
-    int bias;         // 127 . (16 - padding columns of this lane): the same-sign terms' constant part
-};
-
-// 19 VALU operations per 4 columns.  Padding columns are forced to "same sign, both magnitudes 0"
-// by the masks (a term of exactly 127), which `bias` leaves out.
-__device__ __forceinline__ int appx_lane_sum(const i32x4 x, const AppxConst &c)
-{
-    int dot = 0;
-    uint32_t sad = 0, ndiff = 0;
-#pragma unroll
-    for (int d = 0; d < 4; d++) {
-        const uint32_t w = (uint32_t)x[d];
-        const uint32_t km = w & c.m7[d];
-        const uint32_t sd = (w ^ c.us[d]) & c.m8[d];                        // signs differ
-        const uint32_t dmask = __builtin_amdgcn_perm(0u, 0u, sd);           // 0xFF in those bytes
-        ndiff += (uint32_t)__builtin_popcount(sd);
-        // same sign: 127 - |ka - kb|  (the 127s are counted through ndiff)
-        sad = __builtin_amdgcn_sad_u8(km & ~dmask, c.um[d] & ~dmask, sad);
-        // opposite sign: +-(127 - ((ka + kb) & 127)); per byte ka + kb <= 254, no carry across bytes
-        const uint32_t s4 = km + c.um[d];                                   // bit 7 of a byte = carry out of 7 bits
-        const uint32_t val = ~s4 & (dmask & 0x7F7F7F7Fu);
-        const uint32_t ge = (km | 0x80808080u) - c.um[d];                   // bit 7: |k| >= |u|
-        const uint32_t lneg = (w & ge) | (c.us[d] & ~ge);                   // bit 7: sign of the larger operand
-        const uint32_t neg = ((s4 & lneg) | ~s4) & 0x80808080u;             // negative unless carry and larger > 0
-        const uint32_t sg = __builtin_amdgcn_perm(0x01010101u, 0x01010101u, neg);
-        dot = __builtin_amdgcn_sdot4((int)val, (int)sg, dot, false);
-    }
-    return dot + c.bias - 127 * (int)ndiff - (int)sad;
-}
-
-// ---- V0 / V1: two 64-bit plane words per lane -------------------------------------------------
-struct PlaneConst {
-    uint64_t u[2];      // query plane words at this lane's (group, plane) positions
-    uint64_t valid[2];  // real-column mask of the word's group
-    uint64_t us[2];     // query SIGN plane of the word's group
-    int wgt[2];         // V1 weight 2^(n-1-i) of the word's plane (0 for the sign plane)
-};
-
-template <int MODE, int NB>
-__device__ __forceinline__ int plane_lane_sum(const i32x4 x, const PlaneConst &c)
-{
-    uint64_t k[2];
-    k[0] = (uint64_t)(uint32_t)x[0] | ((uint64_t)(uint32_t)x[1] << 32);
-    k[1] = (uint64_t)(uint32_t)x[2] | ((uint64_t)(uint32_t)x[3] << 32);
-    if (MODE == kModeV0) {
-        return __popcll(~(k[0] ^ c.u[0]) & c.valid[0]) + __popcll(~(k[1] ^ c.u[1]) & c.valid[1]);
-    }
-    // V1: the key's sign plane of each word's group sits in the lane that holds plane 0 of that
-    // group: this lane (NB <= 2), the even lane of the pair (NB == 4) or the first lane of the
-    // quad (NB == 8) -- fetched with quad-permute DPP moves
-    uint64_t ks[2];
-    if (NB == 1) {
-        return 0;                                   // no magnitude planes: every weight is zero
-    } else if (NB == 2) {
-        ks[0] = k[0]; ks[1] = k[0];
-    } else {
-        constexpr int ctrl = (NB == 4) ? 0xA0 /* quad_perm [0,0,2,2] */ : 0x00 /* [0,0,0,0] */;
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, x[0], ctrl, 0xF, 0xF, true);
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, x[1], ctrl, 0xF, 0xF, true);
-        ks[0] = (uint64_t)lo | ((uint64_t)hi << 32);
-        ks[1] = ks[0];
-    }
-    int acc = 0;
-#pragma unroll
-    for (int t = 0; t < 2; t++) {
-        const uint64_t eq = ~(k[t] ^ c.u[t]);
-        const uint64_t sdiff = (ks[t] ^ c.us[t]) & c.valid[t];
-        const uint64_t ssame = ~(ks[t] ^ c.us[t]) & c.valid[t];
-        acc += c.wgt[t] * (__popcll(eq & ssame) - __popcll(eq & sdiff));
-    }
-    return acc;
-}
 
 // LPRK: lanes per key row; DP: padded embedding width; MODE; NB: planes (packed modes)
 template <int LPRK, int DP, int MODE, int NB>
@@ -181,19 +95,7 @@ k_hops_ham(const HopArgs a, const uint32_t key_row_bytes, const uint32_t lds_slo
                 scale = 1.0f / 1024.0f;                         // 2^-(n-1) . 2^ATTENTION_CONST_SCALE, n = 8
                 const int lim = 1 << (fm.iwl + 10);             // final Q(iwl, 31-iwl) clamps at +-2^iwl
                 AppxConst c;
-                const uint32_t c0 = (lane % LPRK) * 16;
-#pragma unroll
-                for (int d = 0; d < 4; d++) {
-                    const uint32_t b4 = *(const uint32_t *)(ub + c0 + 4 * d);
-                    c.um[d] = b4 & 0x7F7F7F7Fu;
-                    c.us[d] = b4 & 0x80808080u;
-                    uint32_t vm = 0;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) vm |= (c0 + 4 * d + i < D ? 0xFFu : 0u) << (8 * i);
-                    c.m7[d] = vm & 0x7F7F7F7Fu;
-                    c.m8[d] = vm & 0x80808080u;
-                }
-                c.bias = 127 * (int)(D >= c0 + 16 ? 16u : (D > c0 ? D - c0 : 0u));
+                make_appx_const(c, ub, (lane % LPRK) * 16, D);
                 auto row_sum = [&](const i32x4 x) { return appx_lane_sum(x, c); };
                 auto retire_c = [&](uint32_t r, int v) { sc[r] = v > lim ? lim : (v < -lim ? -lim : v); };
                 if (S >= (kWave / LPRK) * 4) scan_rows<LPRK, 4, true, kWaves>(kb, S, row_sum, retire_c, lane, wave);
@@ -201,17 +103,7 @@ k_hops_ham(const HopArgs a, const uint32_t key_row_bytes, const uint32_t lds_slo
             } else {
                 if (MODE == kModeV1) scale = 1.0f / (float)(1 << NB);
                 PlaneConst c;
-                const uint32_t chunk = lane % LPRK;
-#pragma unroll
-                for (int t = 0; t < 2; t++) {
-                    const uint32_t wi = 2 * chunk + t;          // word index inside the row
-                    const uint32_t grp = wi / NB, pl = wi % NB;
-                    c.u[t] = upl[grp * 8 + pl];
-                    c.us[t] = upl[grp * 8 + 0];
-                    const uint32_t ncol = D > 64 * grp ? D - 64 * grp : 0;
-                    c.valid[t] = ncol >= 64 ? ~0ull : ((1ull << ncol) - 1ull);
-                    c.wgt[t] = pl == 0 ? 0 : (1 << (NB - 1 - pl));
-                }
+                make_plane_const<NB>(c, upl, lane % LPRK, D);
                 auto row_sum = [&](const i32x4 x) { return plane_lane_sum<MODE, NB>(x, c); };
                 if (S >= (kWave / LPRK) * 4) scan_rows<LPRK, 4, true, kWaves>(kb, S, row_sum, retire, lane, wave);
                 else scan_rows_short<LPRK>(kb, S, row_sum, retire, lane, wave, kWaves);
@@ -408,6 +300,13 @@ int qmann_hops_appx_impl(const qmann_net *net, const int8_t *keys, const int8_t 
     if (n_query == 0) return QMANN_OK;
     if (n_query >= (1u << 24)) return QMANN_ERANGE;      // one workgroup per query: a launch holds < 2^32 threads
     hipStream_t st = (hipStream_t)stream;
+    if (max_slots <= (uint32_t)kWave) {                     // hops_small.h
+        if (net->dim_emb_pad == 64) k_hops_small<4, 4, kModeAppx, 8><<<n_query, kWave, 0, st>>>(a, 64);
+        else if (net->dim_emb_pad == 128) k_hops_small<8, 8, kModeAppx, 8><<<n_query, kWave, 0, st>>>(a, 128);
+        else k_hops_small<16, 16, kModeAppx, 8><<<n_query, kWave, 0, st>>>(a, 256);
+        QM_LAUNCH_CHECK();
+        return QMANN_OK;
+    }
     if (net->dim_emb_pad == 64) launch<4, 64, kModeAppx, 8>(a, 64, lds, max_slots, n_query, st);
     else if (net->dim_emb_pad == 128) launch<8, 128, kModeAppx, 8>(a, 128, lds, max_slots, n_query, st);
     else launch<16, 256, kModeAppx, 8>(a, 256, lds, max_slots, n_query, st);
@@ -439,7 +338,10 @@ int qmann_hops_packed(const qmann_net *net, const uint64_t *key_planes, size_t k
 #define QM_HAM(DP, NB)                                                                                   \
     do {                                                                                                 \
         constexpr int LPRK = (DP / 64) * NB * 8 / 16;                                                    \
-        if (v1) launch<LPRK, DP, kModeV1, NB>(a, row_bytes, lds, max_slots, n_query, st);                \
+        if (max_slots <= (uint32_t)kWave) {                 /* hops_small.h */                           \
+            if (v1) k_hops_small<DP / 16, LPRK, kModeV1, NB><<<n_query, kWave, 0, st>>>(a, row_bytes);   \
+            else k_hops_small<DP / 16, LPRK, kModeV0, NB><<<n_query, kWave, 0, st>>>(a, row_bytes);      \
+        } else if (v1) launch<LPRK, DP, kModeV1, NB>(a, row_bytes, lds, max_slots, n_query, st);         \
         else launch<LPRK, DP, kModeV0, NB>(a, row_bytes, lds, max_slots, n_query, st);                   \
     } while (0)
     if (Dp == 64) { if (nb == 2) QM_HAM(64, 2); else if (nb == 4) QM_HAM(64, 4); else QM_HAM(64, 8); }

@@ -340,41 +340,65 @@ __device__ __forceinline__ void readout_sparse(const HopArgs &a, uint32_t h, uin
 
 // lin_map + hop update from o_f (any read-out) and the Q_bin(u) codes in `ku`; ends with a barrier.
 // H is sign-magnitude int8 [D][Dp]: the matrix-vector product is the key scan's arithmetic (same
-// per-product form Qw(Qw(H).Qbin(u)), lib/layer_cuda.cu:71), Dp/16 lanes per output row.
+// per-product form Qw(Qw(H).Qbin(u)), lib/layer_cuda.cu:71), Dp/16 lanes per output row.  After the
+// butterfly all Dp/16 lanes of a row group hold the row's sum, so lane `chunk` keeps the sum of the
+// chunk-th row of a group of Dp/16 iterations and the hop update runs once per group on all lanes.
+// The update u' = Qa(Qa(lu) + Qa(o)) is done on integer codes of the activation format (the float
+// form adds two grid values exactly, so both give the same code).
+// `pre`: ScanConst already built for (word length of w[h], frac_bin) and this lane's chunk, or nullptr.
 template <uint32_t Dp>
 __device__ __forceinline__ void linmap_update(const HopArgs &a, uint32_t q, uint32_t h, const short *ku, float *u_f,
-                                              const float *o_f, uint32_t tid)
+                                              const float *o_f, uint32_t tid, const ScanConst *pre = nullptr,
+                                              uint32_t pre_sh = 0)
 {
     constexpr uint32_t LPR = Dp / 16, RPW = kWave / LPR;
     const QFmt fa = a.act[h], fw = a.w[h], fb = a.bin;
     const int maxw = (1 << (fw.iwl + fw.frac)) - 1;
+    const int maxa = (1 << (fa.iwl + fa.frac)) - 1;
     const uint32_t D = a.D;
     const uint32_t nthreads = blockDim.x, nwaves = nthreads / kWave;
     const uint32_t lane = tid & (kWave - 1), wave = tid / kWave;
     const uint32_t sub = lane / LPR, chunk = lane % LPR;
-    auto update = [&](uint32_t o_i, float lu) {
+    auto update = [&](uint32_t o_i, int lu_a) {          // lu_a: code of Qa(lu)
         const float o = o_f[o_i];
-        const float un = qm_quant(qm_quant(lu, fa.iwl, fa.frac) + qm_quant(o, fa.iwl, fa.frac), fa.iwl, fa.frac);
+        int un = lu_a + qm_code(o, fa.iwl, fa.frac);
+        un = un > maxa ? maxa : (un < -maxa ? -maxa : un);
+        const float unf = (float)un / (float)(1 << fa.frac);
         if (a.tap_o) a.tap_o[((size_t)q * a.n_hop + h) * D + o_i] = o;
-        if (a.tap_u) a.tap_u[((size_t)q * a.n_hop + h) * D + o_i] = un;
-        u_f[o_i] = un;
+        if (a.tap_u) a.tap_u[((size_t)q * a.n_hop + h) * D + o_i] = unf;
+        u_f[o_i] = unf;
     };
     if (a.en_lin_map) {
         ScanConst c;
-        const uint32_t sh = make_scan_const(c, ku, chunk * 16, fw.iwl + fw.frac, (int)fb.frac);
+        uint32_t sh;
+        if (pre) { c = *pre; sh = pre_sh; }
+        else sh = make_scan_const(c, ku, chunk * 16, fw.iwl + fw.frac, (int)fb.frac);
         const uint8_t *hb = (const uint8_t *)a.lin_map[h] + chunk * 16;
-        for (uint32_t base = wave * RPW; base < D; base += nwaves * RPW) {
-            const uint32_t r = base + sub;
-            i32x4 x = {0, 0, 0, 0};
-            if (r < D) x = *(const i32x4 *)(hb + (size_t)r * Dp);
-            int acc = row_lanes_sum<LPR>(lane_row_sum(x, c, sh));
-            if (chunk == 0 && r < D) {
-                acc = acc > maxw ? maxw : (acc < -maxw ? -maxw : acc);
-                update(r, (float)acc / (float)(1 << fw.frac));
+        const uint32_t n_it = (D + nwaves * RPW - 1) / (nwaves * RPW);
+        for (uint32_t g = 0; g < n_it; g += LPR) {
+            int keep = 0;
+            uint32_t keep_r = D;
+#pragma unroll
+            for (uint32_t t = 0; t < LPR; t++) {
+                if (g + t < n_it) {                      // wavefront-uniform
+                    const uint32_t r = ((g + t) * nwaves + wave) * RPW + sub;
+                    i32x4 x = {0, 0, 0, 0};
+                    if (r < D) x = *(const i32x4 *)(hb + (size_t)r * Dp);
+                    const int acc = row_lanes_sum<LPR>(lane_row_sum(x, c, sh));
+                    if (chunk == t) { keep = acc; keep_r = r; }
+                }
+            }
+            if (keep_r < D) {
+                // Qw of the row sum, then Qa of that value: shift between the two grids, toward zero
+                const int kw = keep > maxw ? maxw : (keep < -maxw ? -maxw : keep);
+                const uint32_t mag = (uint32_t)(kw < 0 ? -kw : kw);
+                const uint32_t ma = fa.frac >= fw.frac ? mag << (fa.frac - fw.frac) : mag >> (fw.frac - fa.frac);
+                const int la = ma > (uint32_t)maxa ? maxa : (int)ma;
+                update(keep_r, kw < 0 ? -la : la);
             }
         }
     } else {
-        for (uint32_t o_i = tid; o_i < D; o_i += nthreads) update(o_i, u_f[o_i]);
+        for (uint32_t o_i = tid; o_i < D; o_i += nthreads) update(o_i, qm_code(u_f[o_i], fa.iwl, fa.frac));
     }
     __syncthreads();
 }

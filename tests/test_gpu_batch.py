@@ -294,6 +294,16 @@ def test_hops_packed_popcount_bit_exact(env, oracle, mode, D, num_bit):
     run_hamming_case(env, oracle, mode, D, [1, 7, 50, 64, 129, 300], B=12, seed=31 + D + num_bit, num_bit=num_bit)
 
 
+@pytest.mark.parametrize("mode,D,num_bit", [(3, 60, 8), (3, 128, 8), (3, 256, 8), (10, 60, 8), (10, 64, 2), (10, 128, 1),
+                                            (10, 200, 4), (10, 256, 8), (11, 60, 8), (11, 64, 4), (11, 128, 2),
+                                            (11, 256, 8), (11, 256, 1)])
+def test_hops_one_wavefront_path_hamming(env, oracle, mode, D, num_bit):
+    """Every story <= 64 slots: the one-wavefront kernel with the Hamming-family scores."""
+    run_hamming_case(env, oracle, mode, D, [1, 2, 7, 16, 17, 33, 50, 63, 64], B=18, seed=700 + mode + D + num_bit,
+                     num_bit=num_bit)
+    run_hamming_case(env, oracle, mode, D, [5, 50], B=6, seed=701 + mode + D, num_bit=num_bit, iwl=3)
+
+
 def test_hops_packed_full_size_d256(env, oracle):
     """BASELINE config 5 shape: |memory| = 10 000, D = 256, binary-code Hamming attention."""
     run_hamming_case(env, oracle, 10, 256, [10000], B=2, seed=41, num_bit=1)
@@ -489,10 +499,10 @@ SM_VARIANTS = {
 
 
 @pytest.mark.parametrize("variant", sorted(SM_VARIANTS))
-@pytest.mark.parametrize("path", ["fixed_small", "fixed_hist", "appx", "v0", "v1", "float"])
+@pytest.mark.parametrize("path", ["fixed_small", "fixed_hist", "appx", "v0", "v1", "float", "appx_small", "v0_small", "v1_small"])
 def test_hops_softmax_variants(env, oracle, path, variant):
     extra = dict(SM_VARIANTS[variant])
-    if path in ("appx", "v0", "v1") and variant == "exp_shift_scaled":
+    if path.split("_")[0] in ("appx", "v0", "v1") and variant == "exp_shift_scaled":
         # Hamming scores span hundreds of units: compress harder so the normaliser stays >= 2
         extra["att_scale"] = [0.002, 0.001, 0.0015]
     if path == "fixed_small":
@@ -505,6 +515,12 @@ def test_hops_softmax_variants(env, oracle, path, variant):
         run_hamming_case(env, oracle, 10, 128, [1, 9, 64, 200], B=8, seed=903, num_bit=4, extra=extra)
     elif path == "v1":
         run_hamming_case(env, oracle, 11, 128, [1, 9, 64, 200], B=8, seed=904, num_bit=8, extra=extra)
+    elif path == "appx_small":
+        run_hamming_case(env, oracle, 3, 60, [1, 9, 50, 64], B=8, seed=905, extra=extra)
+    elif path == "v0_small":
+        run_hamming_case(env, oracle, 10, 60, [1, 9, 50, 64], B=8, seed=906, num_bit=8, extra=extra)
+    elif path == "v1_small":
+        run_hamming_case(env, oracle, 11, 128, [1, 9, 50, 64], B=8, seed=907, num_bit=4, extra=extra)
     else:
         run_float_case(env, oracle, 60, [1, 2, 10, 50, 64, 300], 6, extra=extra)
 
