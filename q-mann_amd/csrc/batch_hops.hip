@@ -95,7 +95,7 @@ k_hops_fixed(const HopArgs a)
         if (S > 0) {
             // each thread owns bins tid, tid + nthreads, ... (4 bins per thread in a one-wavefront group)
             const SmCfg smc = sm_cfg(a, h);
-            auto bin_x = [&](uint32_t d) { return sm_scaled((float)((int)d - 127) / (float)(1 << fm.frac), smc); };
+            auto bin_x = [&](uint32_t d) { return sm_scaled(qm_scale_down((float)((int)d - 127), fm.frac), smc); };
             float xmax = -INFINITY;
             for (uint32_t d = tid; d < 256; d += nthreads) {
                 uint32_t cnt = 0;
@@ -123,7 +123,7 @@ k_hops_fixed(const HopArgs a)
                 for (uint32_t r = tid; r < S; r += nthreads) {
                     const int code = sc[r];
                     if (a.tap_codes) a.tap_codes[tb + r] = code;
-                    if (a.tap_scores) a.tap_scores[tb + r] = (float)code / (float)(1 << fm.frac);
+                    if (a.tap_scores) a.tap_scores[tb + r] = qm_scale_down((float)code, fm.frac);
                     if (a.tap_probs) a.tap_probs[tb + r] = ptab[code + 127];
                 }
             }

@@ -63,7 +63,7 @@ k_hops_float(const HopArgs a)
         kuq[tid] = (int8_t)((tid < D) ? qm_code(uv, fsrc.iwl, fsrc.frac) : 0);   // exact: u is on that grid
         __syncthreads();
 
-        const float scale = 1.0f / (float)(1u << (fw.frac + fsrc.frac));
+        const float scale = qm_scale_down(1.0f, fw.frac + fsrc.frac);
         if (S > 0) {
             DotConst c;
             const uint32_t c0 = (lane % LPR) * 16;
@@ -121,7 +121,7 @@ k_hops_float(const HopArgs a)
             constexpr int UN = 4;
             constexpr uint32_t TILE = RPW * UN, STEP = kWaves * TILE;
             const uint32_t sub = lane / LPR, chunk = lane % LPR;
-            const float vscale = 1.0f / (float)(1u << fw.frac);
+            const float vscale = qm_scale_down(1.0f, fw.frac);
             float acc[16];
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[i] = 0.0f;

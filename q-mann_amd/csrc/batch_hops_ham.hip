@@ -101,7 +101,7 @@ k_hops_ham(const HopArgs a, const uint32_t key_row_bytes, const uint32_t lds_slo
                 if (S >= (kWave / LPRK) * 4) scan_rows<LPRK, 4, true, kWaves>(kb, S, row_sum, retire_c, lane, wave);
                 else scan_rows_short<LPRK>(kb, S, row_sum, retire_c, lane, wave, kWaves);
             } else {
-                if (MODE == kModeV1) scale = 1.0f / (float)(1 << NB);
+                if (MODE == kModeV1) scale = qm_scale_down(1.0f, NB);
                 PlaneConst c;
                 make_plane_const<NB>(c, upl, lane % LPRK, D);
                 auto row_sum = [&](const i32x4 x) { return plane_lane_sum<MODE, NB>(x, c); };

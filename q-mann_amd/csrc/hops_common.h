@@ -333,7 +333,7 @@ __device__ __forceinline__ void readout_sparse(const HopArgs &a, uint32_t h, uin
             }
         }
         acc = acc > maxa ? maxa : (acc < -maxa ? -maxa : acc);
-        o_f[c] = (float)acc / (float)(1 << fa.frac);
+        o_f[c] = qm_scale_down((float)acc, fa.frac);
     }
     __syncthreads();
 }
@@ -345,11 +345,13 @@ __device__ __forceinline__ void readout_sparse(const HopArgs &a, uint32_t h, uin
 // chunk-th row of a group of Dp/16 iterations and the hop update runs once per group on all lanes.
 // The update u' = Qa(Qa(lu) + Qa(o)) is done on integer codes of the activation format (the float
 // form adds two grid values exactly, so both give the same code).
-// `pre`: ScanConst already built for (word length of w[h], frac_bin) and this lane's chunk, or nullptr.
+// `pre` + `use_pre`: ScanConst already built for (word length of w[h], frac_bin) and this lane's chunk.
+// `rows0`: this lane's 16-byte pieces of the first group's rows, already in registers (a one-wavefront
+// caller that issued the loads early), or nullptr.
 template <uint32_t Dp>
 __device__ __forceinline__ void linmap_update(const HopArgs &a, uint32_t q, uint32_t h, const short *ku, float *u_f,
                                               const float *o_f, uint32_t tid, const ScanConst *pre = nullptr,
-                                              uint32_t pre_sh = 0)
+                                              uint32_t pre_sh = 0, bool use_pre = false, const i32x4 *rows0 = nullptr)
 {
     constexpr uint32_t LPR = Dp / 16, RPW = kWave / LPR;
     const QFmt fa = a.act[h], fw = a.w[h], fb = a.bin;
@@ -363,7 +365,7 @@ __device__ __forceinline__ void linmap_update(const HopArgs &a, uint32_t q, uint
         const float o = o_f[o_i];
         int un = lu_a + qm_code(o, fa.iwl, fa.frac);
         un = un > maxa ? maxa : (un < -maxa ? -maxa : un);
-        const float unf = (float)un / (float)(1 << fa.frac);
+        const float unf = qm_scale_down((float)un, fa.frac);
         if (a.tap_o) a.tap_o[((size_t)q * a.n_hop + h) * D + o_i] = o;
         if (a.tap_u) a.tap_u[((size_t)q * a.n_hop + h) * D + o_i] = unf;
         u_f[o_i] = unf;
@@ -371,7 +373,9 @@ __device__ __forceinline__ void linmap_update(const HopArgs &a, uint32_t q, uint
     if (a.en_lin_map) {
         ScanConst c;
         uint32_t sh;
-        if (pre) { c = *pre; sh = pre_sh; }
+        // (`pre` is never a conditional pointer: selecting between two addresses would force the caller's
+        // constants out of registers)
+        if (pre && use_pre) { c = *pre; sh = pre_sh; }
         else sh = make_scan_const(c, ku, chunk * 16, fw.iwl + fw.frac, (int)fb.frac);
         const uint8_t *hb = (const uint8_t *)a.lin_map[h] + chunk * 16;
         const uint32_t n_it = (D + nwaves * RPW - 1) / (nwaves * RPW);
@@ -383,7 +387,8 @@ __device__ __forceinline__ void linmap_update(const HopArgs &a, uint32_t q, uint
                 if (g + t < n_it) {                      // wavefront-uniform
                     const uint32_t r = ((g + t) * nwaves + wave) * RPW + sub;
                     i32x4 x = {0, 0, 0, 0};
-                    if (r < D) x = *(const i32x4 *)(hb + (size_t)r * Dp);
+                    if (rows0 && g == 0) x = rows0[t];
+                    else if (r < D) x = *(const i32x4 *)(hb + (size_t)r * Dp);
                     const int acc = row_lanes_sum<LPR>(lane_row_sum(x, c, sh));
                     if (chunk == t) { keep = acc; keep_r = r; }
                 }

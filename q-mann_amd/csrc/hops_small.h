@@ -15,6 +15,13 @@ __global__ void __launch_bounds__(kWave)
 k_hops_small(const HopArgs a, const uint32_t key_row_bytes)
 {
     constexpr uint32_t Dp = LPR * 16, RPWK = kWave / LPRK;
+    // bAbI width (Dp = 64): everything a hop reads from global memory -- its value rows, its linear-map
+    // rows (at its start) and the NEXT hop's key rows (as soon as the scan is done; addresses do not depend on
+    // the data) -- is requested early, so no global-memory latency sits between the stages of a hop.  Value rows pass through LDS
+    // (row-major tile) because the read-out owns columns, not row pieces.
+    constexpr bool PF = (LPR == 4 && LPRK <= 4);
+    constexpr int NK = PF ? LPRK : 1;                   // key loads covering 64 rows
+    __shared__ __attribute__((aligned(16))) uint8_t vt[PF ? kWave * 64 : 16];
     __shared__ float u_f[256];
     __shared__ float o_f[256];
     __shared__ short ku[256];
@@ -29,12 +36,43 @@ k_hops_small(const HopArgs a, const uint32_t key_row_bytes)
     const uint32_t D = a.D;
     const uint32_t subk = lane / LPRK, chunkk = lane % LPRK;
 
+    i32x4 kq[NK], vq[4], hq[4];
+    auto load_keys = [&](i32x4 (&k)[NK], uint32_t h) {
+        const uint8_t *kb = (const uint8_t *)a.keys + (size_t)h * a.key_hop_stride + (size_t)r0 * key_row_bytes + chunkk * 16;
+#pragma unroll
+        for (int j = 0; j < NK; j++) {
+            const uint32_t r = j * RPWK + subk;
+            k[j] = i32x4{0, 0, 0, 0};
+            if (r < S) k[j] = *(const i32x4 *)(kb + (size_t)r * key_row_bytes);
+        }
+    };
+    if (PF) load_keys(kq, 0);
+
     for (uint32_t c = lane; c < 256; c += kWave) u_f[c] = (c < D) ? a.u0[(size_t)q * D + c] : 0.0f;
     __syncthreads();
 
     for (uint32_t h = 0; h < a.n_hop; h++) {
         const QFmt fa = a.act[h], fm = a.att[h], fb = a.bin, fw = a.w[h];
         const int maxa = (1 << (fa.iwl + fa.frac)) - 1;
+        if (PF) {
+            const uint32_t sub = lane / LPR, chunk = lane % LPR;
+            const uint8_t *vb = (const uint8_t *)a.vals + (size_t)h * a.hop_stride + (size_t)r0 * Dp + chunk * 16;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t r = j * 16 + sub;
+                vq[j] = i32x4{0, 0, 0, 0};
+                if (r < S) vq[j] = *(const i32x4 *)(vb + (size_t)r * Dp);
+            }
+            if (a.en_lin_map) {
+                const uint8_t *hb = (const uint8_t *)a.lin_map[h] + chunk * 16;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t r = j * 16 + sub;
+                    hq[j] = i32x4{0, 0, 0, 0};
+                    if (r < D) hq[j] = *(const i32x4 *)(hb + (size_t)r * Dp);
+                }
+            }
+        }
         // codes of u: Q_bin for the scores (fixed) and the linear map; sign-magnitude Q_att bytes and
         // their bit planes for the Hamming forms
         for (uint32_t c = lane; c < Dp; c += kWave) {
@@ -62,6 +100,17 @@ k_hops_small(const HopArgs a, const uint32_t key_row_bytes)
         if (S > 0) {
             const uint8_t *kb = (const uint8_t *)a.keys + (size_t)h * a.key_hop_stride + (size_t)r0 * key_row_bytes + chunkk * 16;
             auto scan = [&](auto lane_sum, int lim) {
+                if (PF) {
+#pragma unroll
+                    for (int j = 0; j < NK; j++) {
+                        const uint32_t r = j * RPWK + subk;
+                        if (j * RPWK < S) {                                  // wavefront-uniform
+                            const int v = row_lanes_sum<LPRK>(lane_sum(kq[j]));
+                            if (chunkk == 0 && r < S) sc[r] = (int16_t)(v > lim ? lim : (v < -lim ? -lim : v));
+                        }
+                    }
+                    return;
+                }
                 for (uint32_t base = 0; base < S; base += RPWK) {
                     const uint32_t r = base + subk;
                     i32x4 x = {0, 0, 0, 0};
@@ -71,7 +120,7 @@ k_hops_small(const HopArgs a, const uint32_t key_row_bytes)
                 }
             };
             if (MODE == kModeFixed) {
-                unit = 1.0f / (float)(1 << fm.frac);
+                unit = qm_scale_down(1.0f, fm.frac);
                 csh = make_scan_const(csc, ku, chunkk * 16, fm.iwl + fm.frac, (int)fb.frac);
                 scan([&](const i32x4 x) { return lane_row_sum(x, csc, csh); }, (1 << (fm.iwl + fm.frac)) - 1);   // Qm, lib/layer_cuda.cu:135
             } else if (MODE == kModeAppx) {
@@ -80,11 +129,18 @@ k_hops_small(const HopArgs a, const uint32_t key_row_bytes)
                 make_appx_const(c, ub, chunkk * 16, D);
                 scan([&](const i32x4 x) { return appx_lane_sum(x, c); }, 1 << (fm.iwl + 10));      // Q(iwl, 31-iwl) clamps at +-2^iwl
             } else {
-                if (MODE == kModeV1) unit = 1.0f / (float)(1 << NB);
+                if (MODE == kModeV1) unit = qm_scale_down(1.0f, NB);
                 PlaneConst c;
                 make_plane_const<NB>(c, upl, chunkk, D);
                 scan([&](const i32x4 x) { return plane_lane_sum<MODE, NB>(x, c); }, 32767);
             }
+        }
+        if (PF) {
+            const uint32_t sub = lane / LPR, chunk = lane % LPR;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (j * 16 < (int)S) *(i32x4 *)(vt + (size_t)(j * 16 + sub) * 64 + chunk * 16) = vq[j];
+            if (h + 1 < a.n_hop) load_keys(kq, h + 1);      // the scan is done with this hop's keys
         }
         __syncthreads();
 
@@ -112,20 +168,21 @@ k_hops_small(const HopArgs a, const uint32_t key_row_bytes)
         // read-out over the rows whose weight code is non-zero (the others add exact zeros)
         const uint64_t survivors = __ballot(kp != 0);
         for (uint32_t c = lane; c < Dp; c += kWave) {
-            const uint8_t *vb = (const uint8_t *)a.vals + (size_t)h * a.hop_stride + (size_t)r0 * Dp + c;
+            const uint8_t *vb = PF ? (const uint8_t *)vt + c
+                                   : (const uint8_t *)a.vals + (size_t)h * a.hop_stride + (size_t)r0 * Dp + c;
             int acc = 0;
             for (uint64_t m = survivors; m; m &= m - 1) {
                 const int r = __builtin_ctzll(m);
                 acc += qm_mul_code(__shfl(kp, r), sm_decode(vb[(size_t)r * Dp]), fa.frac, maxa);
             }
             acc = acc > maxa ? maxa : (acc < -maxa ? -maxa : acc);
-            o_f[c] = (float)acc / (float)(1 << fa.frac);
+            o_f[c] = qm_scale_down((float)acc, fa.frac);
         }
         __syncthreads();
         // the key scan's lane constants serve the linear map as they are when both formats have the
         // same word length (always so at BW_WL 8): same u codes, same shift
         const bool reuse = MODE == kModeFixed && S > 0 && (fw.iwl + fw.frac == fm.iwl + fm.frac);
-        linmap_update<Dp>(a, q, h, ku, u_f, o_f, lane, reuse ? &csc : nullptr, csh);
+        linmap_update<Dp>(a, q, h, ku, u_f, o_f, lane, &csc, csh, reuse, PF ? hq : nullptr);
     }
     for (uint32_t c = lane; c < D; c += kWave) a.u_out[(size_t)q * D + c] = u_f[c];
 }

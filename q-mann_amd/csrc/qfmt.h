@@ -17,6 +17,9 @@
 #define QM_HD static inline
 #endif
 
+// x . 2^-k, exact (a full-precision float division costs ~10 instructions on the device)
+QM_HD float qm_scale_down(float x, uint32_t k) { return __builtin_ldexpf(x, -(int)k); }
+
 struct QFmt {
     uint32_t iwl;
     uint32_t frac;
@@ -27,7 +30,7 @@ QM_HD int32_t qm_code(float x, uint32_t iwl, uint32_t frac)
 {
     const int32_t M = (int32_t)((1u << (iwl + frac)) - 1u);
     const float scale = (float)(1 << frac);
-    const float maxf = (float)M / scale;
+    const float maxf = qm_scale_down((float)M, frac);
     if (x > maxf) return M;
     if (x < -maxf) return -M;
     float p = x * scale;
@@ -48,7 +51,7 @@ QM_HD uint32_t qm_signmag(float x, uint32_t iwl, uint32_t frac)
 
 QM_HD float qm_decode(int32_t code, uint32_t frac)
 {
-    return (float)code / (float)(1 << frac);
+    return qm_scale_down((float)code, frac);
 }
 
 // FLOAT_QUANT, including the iwl + frac == 0 binarisation
