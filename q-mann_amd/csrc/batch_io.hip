@@ -112,21 +112,30 @@ k_answer(const float *__restrict__ w_ans, const float *__restrict__ u, const uin
     }
 }
 
-// Answer layer for small dictionaries (V <= 64, bAbI single-task sizes): one WAVEFRONT per query,
-// lane v owns logit v -- the same arithmetic as k_answer without idle threads and block barriers.
+// Answer layer for small dictionaries (V <= 256: bAbI single-task and joint sizes): one WAVEFRONT per
+// query, lane l owns logits l, l + 64, ... (VPT of them) -- the same arithmetic as k_answer without
+// block barriers; W is staged transposed in LDS once per (persistent) workgroup.
+template <int VPT>
 __global__ void __launch_bounds__(kBlock)
 k_answer_small(const float *__restrict__ w_ans, const float *__restrict__ u, const uint32_t *__restrict__ answer,
                uint32_t *__restrict__ pred, float *__restrict__ probs, float *cost, uint32_t *match, uint32_t D,
                uint32_t V, uint32_t softmax_base, uint32_t n_query)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *wt = (float *)smem;                          // [D][V]: W transposed, lane v reads consecutive words
-    float *us = wt + (size_t)D * V + (threadIdx.x / kWave) * D;      // [kWaves][D]: this wavefront's query
+    constexpr uint32_t VP = 64 * VPT;                   // logits padded to whole wavefronts (zero columns)
+    float *wt = (float *)smem;                          // [D][VP]: W transposed, lanes read consecutive words
+    float *us = wt + (size_t)D * VP + (threadIdx.x / kWave) * D;     // [kWaves][D]: this wavefront's query
     const uint32_t lane = threadIdx.x & (kWave - 1);
     const size_t stride = (size_t)gridDim.x * kWaves;
-    const bool live = lane < V;
-    for (uint32_t i = threadIdx.x; i < D * V; i += kBlock) wt[(i % D) * V + i / D] = w_ans[i];
+    for (uint32_t i = threadIdx.x; i < D * VP; i += kBlock) {
+        const uint32_t c = i / VP, v = i % VP;
+        wt[i] = v < V ? w_ans[(size_t)v * D + c] : 0.0f;
+    }
     __syncthreads();
+    const SmCfg smc{softmax_base, false, false, 1.0f};  // sf_out is never shift-based (MemN2N.c:910)
+    bool live[VPT];
+#pragma unroll
+    for (int k = 0; k < VPT; k++) live[k] = lane + 64u * k < V;
     // cost / match are summed per wavefront and added once: one device-scope atomic per query on a
     // single word would serialise the whole batch (~12 ns each)
     float cost_acc = 0.0f;
@@ -135,29 +144,47 @@ k_answer_small(const float *__restrict__ w_ans, const float *__restrict__ u, con
         for (uint32_t c = lane; c < D; c += kWave) us[c] = u[q * D + c];
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        float sum = 0.0f;
-        if (live) {
-#pragma unroll 8
-            for (uint32_t c = 0; c < D; c++) {
-                const float t = wt[c * V + lane] * us[c];
-                sum += t;
+        float sum[VPT];
+#pragma unroll
+        for (int k = 0; k < VPT; k++) sum[k] = 0.0f;
+#pragma unroll 4
+        for (uint32_t c = 0; c < D; c++) {               // serial over the embedding axis, as the reference sums
+            const float uc = us[c];
+#pragma unroll
+            for (int k = 0; k < VPT; k++) {
+                const float t = wt[c * VP + lane + 64 * k] * uc;
+                sum[k] += t;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // reads of us[] done before the next query overwrites it
-        float mx = live ? sum : -INFINITY;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < VPT; k++) mx = (live[k] && sum[k] > mx) ? sum[k] : mx;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const float t = __shfl_xor(mx, o);
             mx = t > mx ? t : mx;
         }
-        const float e = live ? sm_exp(sum - mx, SmCfg{softmax_base, false, false, 1.0f}) : 0.0f;
-        double total = (double)e;
+        float e[VPT];
+        double total = 0.0;
+#pragma unroll
+        for (int k = 0; k < VPT; k++) {
+            e[k] = live[k] ? sm_exp(sum[k] - mx, smc) : 0.0f;
+            total += (double)e[k];
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
-        const float p = (softmax_base == QMANN_SOFTMAX_EXP) ? (float)((double)e / total) : e / (float)total;
-        if (probs && live) probs[q * V + lane] = p;
-        float bv = live ? p : -INFINITY;
-        uint32_t bi = live ? lane : 0u;
+        float bv = -INFINITY;
+        uint32_t bi = 0;
+        float p[VPT];
+#pragma unroll
+        for (int k = 0; k < VPT; k++) {
+            p[k] = (softmax_base == QMANN_SOFTMAX_EXP) ? (float)((double)e[k] / total) : e[k] / (float)total;
+            if (live[k]) {
+                if (probs) probs[q * V + lane + 64 * k] = p[k];
+                if (!(bv > p[k])) { bv = p[k]; bi = lane + 64 * k; }         // later index wins a tie
+            }
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const float tv = __shfl_xor(bv, o);
@@ -168,7 +195,10 @@ k_answer_small(const float *__restrict__ w_ans, const float *__restrict__ u, con
         if (answer) {
             const uint32_t y = answer[q];
             if (y < V) {
-                cost_acc += -__shfl(p, (int)y);
+                float py = 0.0f;
+#pragma unroll
+                for (int k = 0; k < VPT; k++) py = (y / 64u == (uint32_t)k) ? __shfl(p[k], (int)(y % 64u)) : py;
+                cost_acc += -py;
                 match_acc += (y == bi) ? 1u : 0u;
             }
         }
@@ -557,11 +587,18 @@ int qmann_answer_f32(const qmann_net *net, const float *w_ans, const float *u, c
     if (n_query >= (1u << 24)) return QMANN_ERANGE;      // one workgroup per query: a launch holds < 2^32 threads
     if (lds > 48 * 1024)
         QM_HIP(hipFuncSetAttribute((const void *)k_answer<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (V <= (uint32_t)kWave && (size_t)D * V <= 8192) {
-        const uint32_t blocks = (n_query + kWaves - 1) / kWaves;
-        const size_t lds_small = ((size_t)D * V + (size_t)kWaves * D) * sizeof(float);
-        k_answer_small<<<blocks < 2048u ? blocks : 2048u, kBlock, lds_small, (hipStream_t)stream>>>(
-            w_ans, u, answer, pred, probs, cost, match, D, V, net->softmax_base, n_query);
+    const uint32_t v_pad = V <= 64 ? 64u : (V <= 128 ? 128u : 256u);
+    const size_t lds_small = ((size_t)D * v_pad + (size_t)kWaves * D) * sizeof(float);
+    if (V <= 4u * kWave && lds_small <= 64 * 1024) {        // W^T fits LDS: one wavefront per query
+        const uint32_t need = (n_query + kWaves - 1) / kWaves;
+        // persistent workgroups: as many as the chip holds at this LDS size
+        const uint32_t per_cu = (uint32_t)(160 * 1024 / (lds_small + 512));
+        const uint32_t cap = 256u * (per_cu < 1 ? 1u : (per_cu > 8 ? 8u : per_cu));
+        const uint32_t blocks = need < cap ? need : cap;
+        hipStream_t st = (hipStream_t)stream;
+        if (V <= 64) k_answer_small<1><<<blocks, kBlock, lds_small, st>>>(w_ans, u, answer, pred, probs, cost, match, D, V, net->softmax_base, n_query);
+        else if (V <= 128) k_answer_small<2><<<blocks, kBlock, lds_small, st>>>(w_ans, u, answer, pred, probs, cost, match, D, V, net->softmax_base, n_query);
+        else k_answer_small<4><<<blocks, kBlock, lds_small, st>>>(w_ans, u, answer, pred, probs, cost, match, D, V, net->softmax_base, n_query);
         QM_LAUNCH_CHECK();
         return QMANN_OK;
     }

@@ -561,3 +561,40 @@ def test_forward_from_weight_files_equals_forward_from_memory(env, oracle, gold,
                                   taps=("u", "out_probs"))
         o += ns
         np.testing.assert_array_equal(outs[2][1][q], t["u"][2])
+
+
+# ---------------------------------------------------------------------------------------------
+# answer layer on its own: every dictionary size class, ties, bookkeeping
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("base", [0, 1, 2])
+@pytest.mark.parametrize("V,D", [(30, 60), (64, 60), (65, 60), (100, 20), (128, 60), (200, 60), (256, 60), (256, 128),
+                                 (300, 60), (1000, 33)])
+def test_answer_layer_vs_oracle(env, oracle, V, D, base):
+    """logits in the reference's serial order (bit-identical), softmax within 1e-5, arg-max with ties to the
+    highest index, cost = -sum p[answer], match count -- for the one-wavefront kernel (V <= 256, W^T in LDS)
+    and the workgroup-per-query kernel."""
+    torch, model = env.torch, env.model
+    rng = np.random.default_rng(V * 7 + D + base)
+    B = 37
+    cfg = cfg_synth(D, V, 5, base=base)
+    wts = weights(V + D, 3, D, V, 1.0, with_emb=False)
+    wts["w_ans"] = rng.normal(0, 0.3, (V, D)).astype(np.float32)
+    wts["w_ans"][V - 1] = wts["w_ans"][0]                         # a tie between the first and the last logit ...
+    u = (np.clip(np.rint(rng.normal(0, 20, (B, D))), -127, 127) / 4.0).astype(np.float32)
+    u[3] = 0.0                                                    # ... and an all-equal row: the highest index wins
+    ans = rng.integers(0, V, B).astype(np.int32)
+    net = model.QNet(cfg, wts)
+    pred, probs, cost, match = net.answer(torch.from_numpy(u).to(env.dev), torch.from_numpy(ans).to(env.dev), want_probs=True)
+    torch.cuda.synchronize()
+    pred = pred.cpu().numpy(); probs = probs.cpu().numpy()
+    want_cost, want_match = 0.0, 0
+    for q in range(B):
+        logits = oracle.dense_fwd(wts["w_ans"], u[q], False, (0, 0), (0, 0))
+        p = oracle.softmax_fwd(logits, variant=base)
+        np.testing.assert_allclose(probs[q], p, rtol=1e-5, atol=1e-7)
+        # the arg-max must be the reference's on OUR probabilities (ties are decided by index, not by rounding)
+        assert int(pred[q]) == oracle.argmax_hi(probs[q]), q
+        want_cost -= float(probs[q][ans[q]]); want_match += int(pred[q] == ans[q])
+    assert int(pred[3]) == V - 1
+    assert int(match.item()) == want_match
+    assert float(cost.item()) == pytest.approx(want_cost, rel=1e-5)
