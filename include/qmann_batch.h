@@ -98,6 +98,7 @@ int qmann_quantize_i8(const float *src, int8_t *dst, size_t rows, uint32_t cols,
                       qmann_fmt fmt, int layout, void *stream);
 
 /* The hot path: all hops of all queries in one launch (one workgroup per query).
+ *   max_slots                  -- bound on row_off[q+1] - row_off[q]; sizes the per-query LDS, a longer story is cut to it
  *   u0    [n_query][D] float   -- question embedding (emb_q output)
  *   u_out [n_query][D] float   -- sv[n_hop-1] output, input of the answer layer
  * Replaces, per query and hop, the reference sequence dot_mat_vec_fwd -> softmax_fwd ->

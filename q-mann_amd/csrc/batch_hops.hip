@@ -53,7 +53,8 @@ k_hops_fixed(const HopArgs a)
     const uint32_t nthreads = blockDim.x, nwaves = nthreads / kWave;      // 256 / 4, or 64 / 1 for short memories
     const uint32_t q = blockIdx.x;
     const uint32_t r0 = a.row_off[q];
-    const uint32_t S = a.row_off[q + 1] - r0;
+    const uint32_t S_in = a.row_off[q + 1] - r0;
+    const uint32_t S = S_in < a.max_slots ? S_in : a.max_slots;   // never index LDS past what the launch reserved
     const uint32_t D = a.D;
 
     for (uint32_t c = tid; c < 256; c += nthreads) u_f[c] = (c < D) ? a.u0[(size_t)q * D + c] : 0.0f;
@@ -228,6 +229,7 @@ int qmann_hops_i8(const qmann_net *net, const int8_t *keys, const int8_t *vals, 
         a.tap_o = taps->o; a.tap_u = taps->u;
     }
     a.rows_total = (uint32_t)(hop_stride / net->dim_emb_pad);
+    a.max_slots = max_slots;
     a.n_hop = net->n_hop; a.D = net->dim_emb; a.Dp = net->dim_emb_pad;
     a.softmax_base = net->softmax_base; a.en_lin_map = net->en_lin_map;
     a.softmax_shift = net->softmax_shift_based; a.en_att_scale = net->en_att_scale;

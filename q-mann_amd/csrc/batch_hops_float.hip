@@ -49,7 +49,8 @@ k_hops_float(const HopArgs a)
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     const uint32_t q = blockIdx.x;
     const uint32_t r0 = a.row_off[q];
-    const uint32_t S = a.row_off[q + 1] - r0;
+    const uint32_t S_in = a.row_off[q + 1] - r0;
+    const uint32_t S = S_in < a.max_slots ? S_in : a.max_slots;   // never index LDS past what the launch reserved
     const uint32_t D = a.D;
 
     u_f[tid] = (tid < D) ? a.u0[(size_t)q * D + tid] : 0.0f;

@@ -52,7 +52,8 @@ k_hops_ham(const HopArgs a, const uint32_t key_row_bytes, const uint32_t lds_slo
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     const uint32_t q = blockIdx.x;
     const uint32_t r0 = a.row_off[q];
-    const uint32_t S = a.row_off[q + 1] - r0;
+    const uint32_t S_in = a.row_off[q + 1] - r0;
+    const uint32_t S = S_in < a.max_slots ? S_in : a.max_slots;   // never index LDS past what the launch reserved
     const uint32_t D = a.D;
     // V0 tables sit behind the score array (lds_slots is the launch's slot capacity)
     unsigned char *tab = smem + kOffScores + (((size_t)lds_slots * sizeof(score_t) + 15) & ~(size_t)15);
@@ -295,6 +296,7 @@ int qmann_hops_appx_impl(const qmann_net *net, const int8_t *keys, const int8_t 
     HopArgs a;
     const int rc = fill_args(a, net, keys, vals, hop_stride, hop_stride, row_off, u0, u_out, taps);
     if (rc) return rc;
+    a.max_slots = max_slots;
     const size_t lds = ham_lds_bytes(max_slots, 0);
     if (lds > 160 * 1024 - 1024) return QMANN_ERANGE;
     if (n_query == 0) return QMANN_OK;
@@ -327,6 +329,7 @@ int qmann_hops_packed(const qmann_net *net, const uint64_t *key_planes, size_t k
     HopArgs a;
     const int rc = fill_args(a, net, key_planes, vals, key_hop_stride, val_hop_stride, row_off, u0, u_out, taps);
     if (rc) return rc;
+    a.max_slots = max_slots;
     const bool v1 = net->attention_mode == QMANN_ATT_HAMMING_V1;
     const size_t lds = ham_lds_bytes(max_slots, v1 ? 0u : nb * net->dim_emb + 1u);
     if (lds > 160 * 1024 - 1024) return QMANN_ERANGE;

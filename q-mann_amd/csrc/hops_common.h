@@ -24,6 +24,7 @@ struct HopArgs {
     float *tap_u;
     const int8_t *lin_map[QMANN_MAX_HOP];
     uint32_t rows_total;
+    uint32_t max_slots;      // the caller's bound on slots per query: LDS is sized by it, longer stories are cut to it
     uint32_t n_hop, D, Dp, softmax_base, en_lin_map;
     QFmt act[QMANN_MAX_HOP], w[QMANN_MAX_HOP], att[QMANN_MAX_HOP], bin;
     uint32_t softmax_shift, en_att_scale;     // in-hop softmax variants (qmann_net)

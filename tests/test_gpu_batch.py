@@ -598,3 +598,28 @@ def test_answer_layer_vs_oracle(env, oracle, V, D, base):
     assert int(pred[3]) == V - 1
     assert int(match.item()) == want_match
     assert float(cost.item()) == pytest.approx(want_cost, rel=1e-5)
+
+
+@pytest.mark.parametrize("S_true,bound", [(80, 64), (100, 70), (400, 300)])
+def test_story_longer_than_max_slots_is_cut_not_a_fault(env, S_true, bound):
+    """max_slots sizes the per-query LDS; a story that exceeds it must not index past the reservation.
+    The kernels cut it to its first max_slots rows (same result as handing over the cut story)."""
+    torch, model = env.torch, env.model
+    H, D, V, B = 3, 60, 40, 5
+    cfg = cfg_synth(D, V, 5)
+    net = model.QNet(cfg, weights(5, H, D, V, 1.0, with_emb=False))
+    rng = np.random.default_rng(S_true)
+    keys = np.zeros((H, B * S_true, net.Dp), np.int8); vals = np.zeros_like(keys)
+    keys[:, :, :D] = np.clip(np.rint(rng.normal(0, 30, (H, B * S_true, D))), -127, 127)
+    vals[:, :, :D] = np.clip(np.rint(rng.normal(0, 30, (H, B * S_true, D))), -127, 127)
+    u0 = torch.from_numpy((np.clip(np.rint(rng.normal(0, 20, (B, D))), -127, 127) / 4.0).astype(np.float32)).to(env.dev)
+    dk = torch.from_numpy(model.to_signmag(keys)).to(env.dev); dv = torch.from_numpy(model.to_signmag(vals)).to(env.dev)
+    ro_full = torch.from_numpy((np.arange(B + 1) * S_true).astype(np.int32)).to(env.dev)
+    u_cut = net.hops(dk, dv, ro_full, bound, u0).clone()
+    # the same stories handed over already cut
+    idx = np.concatenate([np.arange(q * S_true, q * S_true + bound) for q in range(B)])
+    dk2 = dk[:, idx].contiguous(); dv2 = dv[:, idx].contiguous()
+    ro2 = torch.from_numpy((np.arange(B + 1) * bound).astype(np.int32)).to(env.dev)
+    u_ref = net.hops(dk2, dv2, ro2, bound, u0)
+    torch.cuda.synchronize()
+    assert torch.equal(u_cut, u_ref)
