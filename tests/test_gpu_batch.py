@@ -623,3 +623,31 @@ def test_story_longer_than_max_slots_is_cut_not_a_fault(env, S_true, bound):
     u_ref = net.hops(dk2, dv2, ro2, bound, u0)
     torch.cuda.synchronize()
     assert torch.equal(u_cut, u_ref)
+
+
+# ---------------------------------------------------------------------------------------------
+# maximum sizes: the largest memory one workgroup's LDS can hold, and the refusal just above it
+# ---------------------------------------------------------------------------------------------
+def test_largest_memory_fixed_point(env, oracle):
+    """Score bytes live in LDS: 160 KB - 1 KB - fixed tables leaves room for ~153 000 slots per query."""
+    lds_cap = 160 * 1024 - 1024
+    S = 150000
+    assert env.abi.lib.qmann_hops_lds_bytes(S) <= lds_cap < env.abi.lib.qmann_hops_lds_bytes(S + 8192)
+    run_case(env, oracle, cfg_synth(128, 40, 5), B=2, S_list=[S, 64], seed=4242, sigma_u=4.0, sigma_k=4.0)
+
+
+def test_largest_memory_hamming_and_float(env, oracle):
+    run_hamming_case(env, oracle, 3, 128, [70000], B=1, seed=4243, sigma=25.0)           # int16 scores: ~76 000
+    run_hamming_case(env, oracle, 10, 256, [70000], B=1, seed=4244, num_bit=1)
+    run_float_case(env, oracle, 128, [37000], 1)                                         # float p per slot: ~38 000
+
+
+def test_memory_beyond_the_lds_is_refused(env):
+    torch, model = env.torch, env.model
+    cfg = cfg_synth(128, 40, 5)
+    net = model.QNet(cfg, weights(1, 3, 128, 40, 1.0, with_emb=False))
+    dk = torch.zeros((3, 8, net.Dp), dtype=torch.int8, device=env.dev)
+    ro = torch.tensor([0, 8], dtype=torch.int32, device=env.dev)
+    u0 = torch.zeros((1, 128), dtype=torch.float32, device=env.dev)
+    with pytest.raises(RuntimeError):
+        net.hops(dk, dk, ro, 200000, u0)                  # QMANN_ERANGE, no launch
