@@ -401,6 +401,7 @@ k_embed_query(const float *__restrict__ question, const float *__restrict__ w_q,
 // saturated to the format (a code needs no truncation when one factor is an integer), so the
 // result is bit-identical to the float path.  One wavefront per story row, lane = column.
 // ---------------------------------------------------------------------------
+typedef short s16x2 __attribute__((ext_vector_type(2)));
 constexpr int kMaxWords = 16;
 
 struct EmbedIdxArgs {
@@ -484,7 +485,9 @@ k_embed_story_idx(const EmbedIdxArgs a)
             for (uint32_t h = 0; h < a.n_hop; h++) {
                 const QFmt fw = a.w[h];
                 const int maxw = (1 << (fw.iwl + fw.frac)) - 1;
-                int sa[4] = {0, 0, 0, 0}, sc[4] = {0, 0, 0, 0};      // codes in units of 2^-frac_w
+                // Sums of <= 16 codes fit 16 bits: columns 0/2 and 1/3 of the dword are kept as packed
+                // int16 pairs (v_pk_* arithmetic).  Codes in units of 2^-frac_w.
+                s16x2 ae = {0, 0}, ao = {0, 0}, ce_ = {0, 0}, co = {0, 0};
                 for (uint32_t e = 0; e < a.max_words; e++) {
                     const uint32_t pe = (uint32_t)__shfl((int)pack, (int)e, 16);
                     if (!((pe >> 24) & 1u) || !col_ok) continue;
@@ -497,31 +500,37 @@ k_embed_story_idx(const EmbedIdxArgs a)
                         ta = ((const uint32_t *)a.t_a[h])[(size_t)we * dw + c4];
                         tc = ((const uint32_t *)a.t_c[h])[(size_t)we * dw + c4];
                     }
-                    if (ce == 1u) {                      // Qw(1 . kw) = kw
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            sa[k] += (int)(int8_t)(ta >> (8 * k));
-                            sc[k] += (int)(int8_t)(tc >> (8 * k));
-                        }
-                    } else {
+                    // sign-extended bytes: even columns (0, 2) and odd columns (1, 3)
+                    s16x2 ea = (__builtin_bit_cast(s16x2, ta) << 8) >> 8, oa = __builtin_bit_cast(s16x2, ta) >> 8;
+                    s16x2 ec = (__builtin_bit_cast(s16x2, tc) << 8) >> 8, oc = __builtin_bit_cast(s16x2, tc) >> 8;
+                    if (ce != 1u) {                      // a repeated word: Qw(Qw(count) . kw) per column (rare)
                         const int cc = count_code(ce, fw.frac, maxw);
 #pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            sa[k] += qm_mul_code(cc, (int)(int8_t)(ta >> (8 * k)), fw.frac, maxw);
-                            sc[k] += qm_mul_code(cc, (int)(int8_t)(tc >> (8 * k)), fw.frac, maxw);
+                        for (int k = 0; k < 2; k++) {
+                            ea[k] = (short)qm_mul_code(cc, ea[k], fw.frac, maxw); oa[k] = (short)qm_mul_code(cc, oa[k], fw.frac, maxw);
+                            ec[k] = (short)qm_mul_code(cc, ec[k], fw.frac, maxw); oc[k] = (short)qm_mul_code(cc, oc[k], fw.frac, maxw);
                         }
-                    }
+                    }                                    // else Qw(1 . kw) = kw
+                    ae += ea; ao += oa; ce_ += ec; co += oc;
                 }
-                uint32_t kw = 0, vw = 0;
+                // Qw of the sum, then the memory byte: magnitude moved to the target grid (toward zero),
+                // clamped, sign bit from the VALUE (a negative sum that truncates to zero is "minus zero")
+                auto to_bytes = [&](s16x2 x, QFmt dst) {
+                    const short mw = (short)maxw;
+                    x = __builtin_elementwise_min(__builtin_elementwise_max(x, s16x2{(short)-mw, (short)-mw}), s16x2{mw, mw});
+                    u16x2 mag = __builtin_bit_cast(u16x2, __builtin_elementwise_max(x, (s16x2)(-x)));
+                    mag = dst.frac >= fw.frac ? (u16x2)(mag << (unsigned short)(dst.frac - fw.frac))
+                                              : (u16x2)(mag >> (unsigned short)(fw.frac - dst.frac));
+                    const unsigned short md = (unsigned short)((1u << (dst.iwl + dst.frac)) - 1u);
+                    mag = __builtin_elementwise_min(mag, u16x2{md, md});
+                    const u16x2 sgn = __builtin_bit_cast(u16x2, (s16x2)(x >> 8)) & (unsigned short)0x0080;
+                    return __builtin_bit_cast(uint32_t, (u16x2)(mag | sgn));
+                };
+                uint32_t colmask = 0;
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int ka = sa[k] > maxw ? maxw : (sa[k] < -maxw ? -maxw : sa[k]);
-                    const int kc = sc[k] > maxw ? maxw : (sc[k] < -maxw ? -maxw : sc[k]);
-                    if (4 * c4 + (uint32_t)k < a.D) {
-                        kw |= (uint32_t)(uint8_t)sm_requant(ka, fw.frac, a.att[h]) << (8 * k);
-                        vw |= (uint32_t)(uint8_t)sm_requant(kc, fw.frac, a.act[h]) << (8 * k);
-                    }
-                }
+                for (int k = 0; k < 4; k++) colmask |= (4 * c4 + (uint32_t)k < a.D ? 0xFFu : 0u) << (8 * k);
+                const uint32_t kw = (to_bytes(ae, a.att[h]) | (to_bytes(ao, a.att[h]) << 8)) & colmask;
+                const uint32_t vw = (to_bytes(ce_, a.act[h]) | (to_bytes(co, a.act[h]) << 8)) & colmask;
                 if (row_ok && col_ok) {
                     *(uint32_t *)(a.keys + (size_t)h * a.hop_stride + s * a.Dp + 4 * c4) = kw;
                     *(uint32_t *)(a.vals + (size_t)h * a.hop_stride + s * a.Dp + 4 * c4) = vw;
@@ -531,30 +540,63 @@ k_embed_story_idx(const EmbedIdxArgs a)
     }
 }
 
-// question: word entries only (no time entry, sample.c:557-565); u0[j] = Qw0(sum_k Qw0(Qw0(W[j][k]) . Qw0(c_k)))
+// question: word entries only (no time entry, sample.c:557-565); u0[j] = Qw0(sum_k Qw0(Qw0(W[j][k]) . Qw0(c_k))),
+// written as floats on the Q(w[0]) grid.  Same lane layout as the story kernel: 16 lanes per question.
+template <bool TAB_LDS>
 __global__ void __launch_bounds__(kBlock)
 k_embed_query_idx(const uint16_t *__restrict__ words, const int8_t *__restrict__ t_q, float *__restrict__ u0,
                   uint32_t n_query, uint32_t max_words, uint32_t D, uint32_t Dp, uint32_t V, QFmt fw)
 {
-    const uint32_t lane = threadIdx.x & (kWave - 1);
-    const size_t stride = (size_t)gridDim.x * kWaves;
-    for (size_t q = (size_t)blockIdx.x * kWaves + threadIdx.x / kWave; q < n_query; q += stride) {
-        const uint16_t *wr = words + q * max_words;
-        uint32_t idx[kMaxWords], cnt[kMaxWords], n = 0;
-        for (uint32_t i = 0; i < max_words && i < (uint32_t)kMaxWords; i++) {
-            const uint32_t wdx = wr[i];
-            if (wdx == 0xFFFFu || wdx >= V) continue;
-            uint32_t j = 0;
-            for (; j < n; j++)
-                if (idx[j] == wdx) break;
-            if (j == n) { idx[n] = wdx; cnt[n] = 0; n++; }
-            cnt[j]++;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), sub = lane & 15u, grp = lane >> 4;
+    const uint32_t dw = Dp / 4;
+    uint32_t *tab = (uint32_t *)smem;
+    if (TAB_LDS) {
+        for (uint32_t i = tid; i < V * dw; i += kBlock) tab[i] = ((const uint32_t *)t_q)[i];
+        __syncthreads();
+    }
+    const int maxw = (1 << (fw.iwl + fw.frac)) - 1;
+    const size_t per_pass = (size_t)gridDim.x * kWaves * 4;
+    for (size_t q0 = ((size_t)blockIdx.x * kWaves + tid / kWave) * 4; q0 < n_query; q0 += per_pass) {
+        const size_t q = q0 + grp;
+        const bool q_ok = q < n_query;
+        uint32_t w = 0xFFFFu;
+        if (q_ok && sub < max_words) w = words[q * max_words + sub];
+        const bool valid = w != 0xFFFFu && w < V;
+        const uint32_t me = w | (valid ? 1u << 16 : 0u);
+        uint32_t cnt = 0;
+        bool dup = false;
+        for (uint32_t j = 0; j < max_words; j++) {
+            const uint32_t o = (uint32_t)__shfl((int)me, (int)j, 16);
+            const bool same = (((o ^ me) & 0xFFFFu) == 0u) && ((o >> 16) & 1u);
+            cnt += same ? 1u : 0u;
+            dup |= same && j < sub;
         }
-        for (uint32_t col = lane; col < D; col += kWave) {
-            float s = 0.0f;
-            for (uint32_t e = 0; e < n; e++)
-                s += qm_quant(qm_decode(t_q[(size_t)idx[e] * Dp + col], fw.frac) * count_value(cnt[e], fw), fw.iwl, fw.frac);
-            u0[q * D + col] = qm_quant(s, fw.iwl, fw.frac);
+        const uint32_t pack = (w & 0xFFFFu) | (cnt << 16) | ((valid && !dup) ? 1u << 24 : 0u);
+        for (uint32_t c0 = 0; c0 < dw; c0 += 16) {
+            const uint32_t c4 = c0 + sub;
+            const bool col_ok = c4 < dw;
+            int acc[4] = {0, 0, 0, 0};
+            for (uint32_t e = 0; e < max_words; e++) {
+                const uint32_t pe = (uint32_t)__shfl((int)pack, (int)e, 16);
+                if (!((pe >> 24) & 1u) || !col_ok) continue;
+                const uint32_t we = pe & 0xFFFFu, ce = (pe >> 16) & 0xFFu;
+                const uint32_t t = TAB_LDS ? tab[we * dw + c4] : ((const uint32_t *)t_q)[(size_t)we * dw + c4];
+                const int cc = count_code(ce, fw.frac, maxw);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int kw = (int)(int8_t)(t >> (8 * k));
+                    acc[k] += (ce == 1u) ? kw : qm_mul_code(cc, kw, fw.frac, maxw);
+                }
+            }
+            if (q_ok && col_ok) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t col = 4 * c4 + (uint32_t)k;
+                    const int v = acc[k] > maxw ? maxw : (acc[k] < -maxw ? -maxw : acc[k]);
+                    if (col < D) u0[q * D + col] = qm_scale_down((float)v, fw.frac);
+                }
+            }
         }
     }
 }
@@ -726,10 +768,17 @@ int qmann_embed_query_idx(const qmann_net *net, const uint16_t *words, uint32_t 
     if (max_words == 0 || max_words > (uint32_t)kMaxWords) return QMANN_ERANGE;
     if (!fmt8(net->w[0])) return QMANN_ERANGE;
     if (n_query == 0) return QMANN_OK;
-    const uint32_t blocks = (n_query + kWaves - 1) / kWaves;
-    k_embed_query_idx<<<blocks < (1u << 20) ? blocks : (1u << 20), kBlock, 0, (hipStream_t)stream>>>(
-        words, t_q, u0, n_query, max_words, net->dim_emb, net->dim_emb_pad, net->dim_input,
-        QFmt{net->w[0].iwl, net->w[0].frac});
+    if (net->dim_emb_pad & 3u) return QMANN_EINVAL;
+    const uint32_t need = (n_query + kWaves * 4 - 1) / (kWaves * 4);
+    const uint32_t blocks = need < 2048u ? need : 2048u;
+    const size_t tab_lds = (size_t)net->dim_input * net->dim_emb_pad;
+    const QFmt fw{net->w[0].iwl, net->w[0].frac};
+    if (tab_lds <= 48 * 1024)
+        k_embed_query_idx<true><<<blocks, kBlock, tab_lds, (hipStream_t)stream>>>(
+            words, t_q, u0, n_query, max_words, net->dim_emb, net->dim_emb_pad, net->dim_input, fw);
+    else
+        k_embed_query_idx<false><<<blocks, kBlock, 0, (hipStream_t)stream>>>(
+            words, t_q, u0, n_query, max_words, net->dim_emb, net->dim_emb_pad, net->dim_input, fw);
     QM_LAUNCH_CHECK();
     return QMANN_OK;
 }
