@@ -266,6 +266,7 @@ int qmann_hops_i8(const qmann_net *net, const int8_t *keys, const int8_t *vals, 
         }                                                                                               \
         k_hops_fixed<LPR, UN, NT, MINW><<<grid, block, lds, st>>>(a);                                   \
     } while (0)
+    // (bounding the kernel to 96 VGPRs for a fifth wavefront per SIMD measured 1-3 % slower: MINW stays 1)
     if (net->dim_emb_pad == 64) QM_LAUNCH_HOPS(4, kUnrollDefault, true, 1);
     else if (net->dim_emb_pad == 256) QM_LAUNCH_HOPS(16, kUnrollDefault, true, 1);
     else QM_LAUNCH_HOPS(8, kUnrollDefault, true, 1);
