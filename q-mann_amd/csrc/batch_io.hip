@@ -415,25 +415,12 @@ struct EmbedIdxArgs {
     QFmt act[QMANN_MAX_HOP], w[QMANN_MAX_HOP], att[QMANN_MAX_HOP];
 };
 
-// integer count -> value the format can hold: Qw(c) for c >= 0 (saturates at max / 2^frac, truncated)
-__device__ __forceinline__ float count_value(uint32_t c, QFmt f) { return qm_quant((float)c, f.iwl, f.frac); }
-// the same as an integer code in units of 2^-frac
+// integer count c >= 0 as a code of the format in units of 2^-frac: Qw(c), saturating at the format maximum
 __device__ __forceinline__ int count_code(uint32_t c, uint32_t frac, int maxw)
 {
     const uint64_t k = (uint64_t)c << frac;
     return k > (uint64_t)maxw ? maxw : (int)k;
 }
-// code k in units of 2^-frac_src -> sign-magnitude byte of Q(dst): shift (truncating toward zero) and clamp.
-// The sign of the byte follows the VALUE (a negative value that truncates to zero is "minus zero").
-__device__ __forceinline__ int8_t sm_requant(int k, uint32_t frac_src, QFmt dst)
-{
-    const int maxd = (1 << (dst.iwl + dst.frac)) - 1;
-    const uint32_t mag = (uint32_t)(k < 0 ? -k : k);
-    uint32_t m = dst.frac >= frac_src ? mag << (dst.frac - frac_src) : mag >> (frac_src - dst.frac);
-    if (m > (uint32_t)maxd) m = (uint32_t)maxd;
-    return (int8_t)(m | (k < 0 ? 0x80u : 0u));
-}
-
 // 16 lanes per story row (a lane owns 4 adjacent columns = one dword of a table row), 4 rows per
 // wavefront, persistent workgroups.  Duplicate words are found lane-parallel: lane i holds entry i,
 // compares with the row's other entries by shuffles, and the first occurrence carries the count.

@@ -250,11 +250,6 @@ __device__ __forceinline__ T block_max(T v, T *scratch, uint32_t lane, uint32_t 
     __syncthreads();
     return r;
 }
-__device__ __forceinline__ int block_max_int(int v, int *scratch, uint32_t lane, uint32_t wave)
-{
-    return block_max<int>(v, scratch, lane, wave);
-}
-
 __device__ __forceinline__ double block_sum_double(double v, double *scratch, uint32_t lane, uint32_t wave)
 {
 #pragma unroll
