@@ -259,6 +259,41 @@ def run_bow(args, name, wl, net, cfg, wts, dev, rank, world, model):
         res["host_inputs"] = {"bytes_per_step": int(sum(t.numel() * t.element_size() for t in srcs)), "h2d_ms": best * 1e3,
                               "pcie_inclusive_queries_per_s": B / (step_s + best),
                               "note": "pinned host buffers, copy then compute, no overlap"}
+        if use_idx:
+            # the same with the copy of batch i+1 overlapping the compute of batch i: two HIP streams, two
+            # input buffers, events in both directions (every entry point of the library takes a stream)
+            cs, ks = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+            net2 = model.QNet(cfg, wts, device=str(dev), stream=ks.cuda_stream)
+            with torch.cuda.stream(ks):
+                net2.make_tables()
+            bufs = [[torch.empty_like(t, device=dev) for t in srcs] for _ in range(2)]
+            copied = [torch.cuda.Event() for _ in range(2)]
+            done = [torch.cuda.Event() for _ in range(2)]
+            torch.cuda.synchronize()
+
+            def pipelined(n):
+                for i in range(n):
+                    b = i % 2
+                    with torch.cuda.stream(cs):
+                        cs.wait_event(done[b])                     # the buffer's previous batch has been consumed
+                        for a_, b_ in zip(srcs, bufs[b]):
+                            b_.copy_(a_, non_blocking=True)
+                        copied[b].record(cs)
+                    with torch.cuda.stream(ks):
+                        ks.wait_event(copied[b])
+                        sw_, qw_, ro_, an_ = bufs[b]
+                        keys, vals, u0 = net2.embed_idx(sw_, qw_)
+                        u = net2.hops(keys, vals, ro_, max_slots, u0)
+                        o2 = net2.answer(u, an_)
+                        done[b].record(ks)
+                torch.cuda.synchronize()
+                return o2
+            pipelined(args.warmup + 1)
+            t1 = time.perf_counter()
+            o2 = pipelined(args.steps)
+            dt = time.perf_counter() - t1
+            res["host_inputs"]["overlapped_queries_per_s"] = B * args.steps / dt
+            res["host_inputs"]["overlapped_pred_equal"] = bool(torch.equal(o2[0], out["pred"]))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, str(ROOT / "oracle"))
         from pyoracle import Oracle
