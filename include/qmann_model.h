@@ -1,0 +1,56 @@
+/*
+ * qmann_model.h -- the test-phase forward of a whole model as ONE host call per batch.
+ *
+ * What MemN2N/MemN2N.c does per query in its test loop (:2378-2699: pointer wiring :2410-2548,
+ * 31 layer calls :2626-2697, bookkeeping :2701-2702) this does per batch: story embedding ->
+ * question embedding -> every hop -> answer layer -> prediction / match / cost, through the batched
+ * kernels of qmann_batch.h.  The object owns the device copies of the parameters in the layouts the
+ * kernels want (int8 gather tables, sign-magnitude lin_map codes, packed bit planes are made per
+ * batch) and a workspace for the int8 memories that grows on demand.  Host language is C++ inside
+ * the library; the interface is plain C.
+ *
+ * Inputs are DEVICE pointers (the reference's cuda_data_in pools, or word-index arrays); every call
+ * takes a stream and returns without synchronising.  One object per host thread / stream.
+ */
+#ifndef QMANN_MODEL_H
+#define QMANN_MODEL_H
+
+#include "qmann_batch.h"
+#include "qmann_weights.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct qmann_model qmann_model;
+
+/* net: dimensions, attention mode, softmax variant and every Q-format (lin_map pointers are ignored:
+ * the object builds its own); w: HOST float matrices as the layer structs hold them (e.g. straight
+ * from qmann_weights_load, or the reference's emb_q.w_mat[0] ... after training).  The weights are
+ * uploaded and converted on `stream`; the host arrays may be freed when the call returns. */
+int qmann_model_create(qmann_model **out, const qmann_net *net, const qmann_weights *w, void *stream);
+void qmann_model_destroy(qmann_model *m);
+
+/* Forward from word indices (qmann_embed_story_idx's wire format).
+ *   story_words [rows_total][max_words] uint16, question_words [n_query][max_q_words] uint16,
+ *   row_off [n_query + 1], max_slots >= every story's slot count,
+ *   answer [n_query] uint32 or NULL; pred [n_query] uint32;
+ *   cost / match: single device words that are ACCUMULATED into (cross_entropy_run mode 3), or NULL. */
+int qmann_model_forward_words(qmann_model *m, const uint16_t *story_words, uint32_t rows_total, uint32_t max_words,
+                              const uint16_t *question_words, uint32_t max_q_words, const uint32_t *row_off,
+                              uint32_t max_slots, uint32_t n_query, const uint32_t *answer, uint32_t *pred,
+                              float *cost, uint32_t *match, void *stream);
+
+/* Forward from the reference's float bag-of-words pools (dev_m_test / dev_q_test, MemN2N.c:2337-2349):
+ *   story [rows_total][dim_input] float, question [n_query][dim_input] float. */
+int qmann_model_forward_bow(qmann_model *m, const float *story, uint32_t rows_total, const float *question,
+                            const uint32_t *row_off, uint32_t max_slots, uint32_t n_query, const uint32_t *answer,
+                            uint32_t *pred, float *cost, uint32_t *match, void *stream);
+
+/* device pointer to the last batch's final hop state u [n_query][D] (valid until the next call) */
+const float *qmann_model_last_u(const qmann_model *m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QMANN_MODEL_H */

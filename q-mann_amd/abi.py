@@ -135,6 +135,12 @@ _proto("qmann_embed_story_idx", C.c_int, [C.POINTER(Net), _vp, C.c_uint32, C.c_u
                                           C.POINTER(_vp), _vp, _vp, C.c_size_t, _vp])
 _proto("qmann_embed_query_idx", C.c_int, [C.POINTER(Net), _vp, C.c_uint32, _vp, _vp, C.c_uint32, _vp])
 _proto("qmann_embed_query", C.c_int, [C.POINTER(Net), _vp, _vp, _vp, C.c_uint32, _vp])
+_proto("qmann_model_create", C.c_int, [C.POINTER(_vp), C.POINTER(Net), C.POINTER(Weights), _vp])
+_proto("qmann_model_destroy", None, [_vp])
+_proto("qmann_model_forward_words", C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint32, _vp, C.c_uint32,
+                                              C.c_uint32, _vp, _vp, _vp, _vp, _vp])
+_proto("qmann_model_forward_bow", C.c_int, [_vp, _vp, C.c_uint32, _vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, _vp])
+_proto("qmann_model_last_u", _vp, [_vp])
 _proto("qmann_weights_save", C.c_int, [C.c_char_p, C.POINTER(Weights), C.POINTER(Fmt)])
 _proto("qmann_weights_load", C.c_int, [C.c_char_p, C.POINTER(Weights), C.c_int, C.POINTER(Fmt)])
 

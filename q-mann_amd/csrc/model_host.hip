@@ -1,0 +1,184 @@
+// model_host.hip -- include/qmann_model.h: host-side C++ that owns a model's device parameters and
+// runs the whole test-phase forward of a batch through the batched kernels.  No kernels here.
+#include "qfmt.h"
+#include "rt.h"
+#include "../../include/qmann_model.h"
+
+#include <new>
+#include <vector>
+
+struct qmann_model {
+    qmann_net net{};
+    qmann_net emb_net{};     // formats the embedding kernels quantise the memories to (see qmann_model_create)
+    uint32_t H = 0, D = 0, Dp = 0, V = 0;
+    // parameters on the device
+    float *w_q = nullptr, *w_ans = nullptr;
+    float *w_a[QMANN_MAX_HOP] = {}, *w_c[QMANN_MAX_HOP] = {};
+    int8_t *lin_map[QMANN_MAX_HOP] = {};
+    int8_t *t_q = nullptr, *t_a[QMANN_MAX_HOP] = {}, *t_c[QMANN_MAX_HOP] = {};
+    // workspace, grown on demand
+    int8_t *keys = nullptr, *vals = nullptr;
+    uint64_t *planes = nullptr;
+    float *u0 = nullptr, *u = nullptr;
+    size_t cap_rows = 0, cap_plane_words = 0, cap_query = 0;
+};
+
+namespace {
+
+bool packed_mode(const qmann_net &n) { return n.attention_mode == QMANN_ATT_HAMMING_V0 || n.attention_mode == QMANN_ATT_HAMMING_V1; }
+
+template <typename T>
+void regrow(T **p, size_t n)
+{
+    if (*p) QM_HIP(hipFree(*p));
+    *p = nullptr;
+    QM_HIP(hipMalloc((void **)p, (n ? n : 1) * sizeof(T)));
+}
+
+float *upload(const float *host, size_t n, hipStream_t st)
+{
+    float *d = nullptr;
+    QM_HIP(hipMalloc((void **)&d, n * sizeof(float)));
+    QM_HIP(hipMemcpyAsync(d, host, n * sizeof(float), hipMemcpyHostToDevice, st));
+    return d;
+}
+
+int ensure(qmann_model *m, size_t rows, uint32_t n_query)
+{
+    if (rows > m->cap_rows) {
+        const size_t cap = rows + rows / 4;
+        regrow(&m->keys, (size_t)m->H * cap * m->Dp);
+        regrow(&m->vals, (size_t)m->H * cap * m->Dp);
+        m->cap_rows = cap;
+    }
+    if (packed_mode(m->net)) {
+        const size_t words = (size_t)m->H * m->cap_rows * (m->Dp / 64) * m->net.num_bit;
+        if (words > m->cap_plane_words) { regrow(&m->planes, words); m->cap_plane_words = words; }
+    }
+    if (n_query > m->cap_query) {
+        const size_t cap = (size_t)n_query + n_query / 4;
+        regrow(&m->u0, cap * m->D);
+        regrow(&m->u, cap * m->D);
+        m->cap_query = cap;
+    }
+    return QMANN_OK;
+}
+
+// hops + answer on the memories sitting in the workspace (hop planes rows_total . Dp apart)
+int hops_and_answer(qmann_model *m, uint32_t rows_total, const uint32_t *row_off, uint32_t max_slots, uint32_t n_query,
+                    const uint32_t *answer, uint32_t *pred, float *cost, uint32_t *match, void *stream)
+{
+    const size_t hop_stride = (size_t)rows_total * m->Dp;
+    int rc;
+    if (packed_mode(m->net)) {
+        const size_t key_hop_stride = (size_t)rows_total * (m->Dp / 64) * m->net.num_bit * 8;
+        rc = qmann_pack_bitplanes(m->keys, m->planes, (size_t)m->H * rows_total, m->Dp, m->net.num_bit, stream);
+        if (rc) return rc;
+        rc = qmann_hops_packed(&m->net, m->planes, key_hop_stride, m->vals, hop_stride, row_off, max_slots, m->u0, m->u,
+                               nullptr, n_query, stream);
+    } else {
+        rc = qmann_hops_i8(&m->net, m->keys, m->vals, hop_stride, row_off, max_slots, m->u0, m->u, nullptr, n_query, stream);
+    }
+    if (rc) return rc;
+    return qmann_answer_f32(&m->net, m->w_ans, m->u, answer, pred, nullptr, cost, match, n_query, stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+int qmann_model_create(qmann_model **out, const qmann_net *net, const qmann_weights *w, void *stream)
+{
+    if (!out || !net || !w) return QMANN_EINVAL;
+    *out = nullptr;
+    if (net->n_hop == 0 || net->n_hop > QMANN_MAX_HOP || net->dim_emb == 0 || net->dim_emb > net->dim_emb_pad) return QMANN_EINVAL;
+    if (net->dim_emb_pad != 64 && net->dim_emb_pad != 128 && net->dim_emb_pad != 256) return QMANN_EUNSUPPORTED;
+    if (w->n_hop != net->n_hop || w->dim_emb != net->dim_emb || w->dim_input != net->dim_input) return QMANN_EINVAL;
+    if (!w->w_q || !w->w_ans) return QMANN_EINVAL;
+    for (uint32_t h = 0; h < net->n_hop; h++)
+        if (!w->w_a[h] || !w->w_c[h] || (net->en_lin_map && !w->w_h[h])) return QMANN_EINVAL;
+
+    qmann_model *m = new (std::nothrow) qmann_model();
+    if (!m) return QMANN_ERANGE;
+    m->net = *net;
+    m->emb_net = *net;
+    // mode 1 runs its attention on the embedding outputs as they are (weight grid, no attention
+    // re-quantisation: lib/layer.c:177-195 forces f_fixed = false on both dot_mat_vec layers)
+    if (net->attention_mode == QMANN_ATT_FLOAT)
+        for (uint32_t h = 0; h < net->n_hop; h++) m->emb_net.att[h] = m->emb_net.act[h] = net->w[h];
+    m->H = net->n_hop; m->D = net->dim_emb; m->Dp = net->dim_emb_pad; m->V = net->dim_input;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t DV = (size_t)m->D * m->V, DD = (size_t)m->D * m->D;
+    std::vector<float *> staged;             // float copies needed only for the conversion below
+    m->w_q = upload(w->w_q, DV, st);
+    m->w_ans = upload(w->w_ans, DV, st);
+    QM_HIP(hipMalloc((void **)&m->t_q, (size_t)m->V * m->Dp));
+    int rc = qmann_quantize_table_i8(m->w_q, m->t_q, m->D, m->Dp, m->V, net->w[0], stream);
+    for (uint32_t h = 0; h < m->H && rc == QMANN_OK; h++) {
+        m->w_a[h] = upload(w->w_a[h], DV, st);
+        m->w_c[h] = upload(w->w_c[h], DV, st);
+        QM_HIP(hipMalloc((void **)&m->t_a[h], (size_t)m->V * m->Dp));
+        QM_HIP(hipMalloc((void **)&m->t_c[h], (size_t)m->V * m->Dp));
+        rc = qmann_quantize_table_i8(m->w_a[h], m->t_a[h], m->D, m->Dp, m->V, net->w[h], stream);
+        if (rc == QMANN_OK) rc = qmann_quantize_table_i8(m->w_c[h], m->t_c[h], m->D, m->Dp, m->V, net->w[h], stream);
+        m->net.lin_map[h] = nullptr;
+        if (rc == QMANN_OK && net->en_lin_map) {
+            float *wh = upload(w->w_h[h], DD, st);
+            staged.push_back(wh);
+            QM_HIP(hipMalloc((void **)&m->lin_map[h], (size_t)m->D * m->Dp));
+            rc = qmann_quantize_i8(wh, m->lin_map[h], m->D, m->D, m->Dp, net->w[h], QMANN_CODE_SIGNMAG, stream);
+            m->net.lin_map[h] = m->lin_map[h];
+        }
+    }
+    QM_HIP(hipStreamSynchronize(st));        // the host arrays and the staged floats are free again
+    for (float *p : staged) QM_HIP(hipFree(p));
+    if (rc != QMANN_OK) { qmann_model_destroy(m); return rc; }
+    *out = m;
+    return QMANN_OK;
+}
+
+void qmann_model_destroy(qmann_model *m)
+{
+    if (!m) return;
+    auto drop = [](void *p) { if (p) QM_HIP(hipFree(p)); };
+    drop(m->w_q); drop(m->w_ans); drop(m->t_q);
+    for (uint32_t h = 0; h < QMANN_MAX_HOP; h++) { drop(m->w_a[h]); drop(m->w_c[h]); drop(m->lin_map[h]); drop(m->t_a[h]); drop(m->t_c[h]); }
+    drop(m->keys); drop(m->vals); drop(m->planes); drop(m->u0); drop(m->u);
+    delete m;
+}
+
+int qmann_model_forward_words(qmann_model *m, const uint16_t *story_words, uint32_t rows_total, uint32_t max_words,
+                              const uint16_t *question_words, uint32_t max_q_words, const uint32_t *row_off,
+                              uint32_t max_slots, uint32_t n_query, const uint32_t *answer, uint32_t *pred,
+                              float *cost, uint32_t *match, void *stream)
+{
+    if (!m || !story_words || !question_words || !row_off || !pred) return QMANN_EINVAL;
+    if (n_query == 0) return QMANN_OK;
+    int rc = ensure(m, rows_total, n_query);
+    if (rc) return rc;
+    rc = qmann_embed_story_idx(&m->emb_net, story_words, rows_total, max_words, 1, m->t_a, m->t_c, m->keys, m->vals,
+                               (size_t)rows_total * m->Dp, stream);
+    if (rc) return rc;
+    rc = qmann_embed_query_idx(&m->net, question_words, max_q_words, m->t_q, m->u0, n_query, stream);
+    if (rc) return rc;
+    return hops_and_answer(m, rows_total, row_off, max_slots, n_query, answer, pred, cost, match, stream);
+}
+
+int qmann_model_forward_bow(qmann_model *m, const float *story, uint32_t rows_total, const float *question,
+                            const uint32_t *row_off, uint32_t max_slots, uint32_t n_query, const uint32_t *answer,
+                            uint32_t *pred, float *cost, uint32_t *match, void *stream)
+{
+    if (!m || !story || !question || !row_off || !pred) return QMANN_EINVAL;
+    if (n_query == 0) return QMANN_OK;
+    int rc = ensure(m, rows_total, n_query);
+    if (rc) return rc;
+    rc = qmann_embed_story(&m->emb_net, story, rows_total, m->w_a, m->w_c, m->keys, m->vals, (size_t)rows_total * m->Dp, stream);
+    if (rc) return rc;
+    rc = qmann_embed_query(&m->net, question, m->w_q, m->u0, n_query, stream);
+    if (rc) return rc;
+    return hops_and_answer(m, rows_total, row_off, max_slots, n_query, answer, pred, cost, match, stream);
+}
+
+const float *qmann_model_last_u(const qmann_model *m) { return m ? m->u : nullptr; }
+
+}  // extern "C"

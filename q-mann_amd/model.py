@@ -93,6 +93,27 @@ def load_weights(directory, cfg: dict, from_fixed: bool = False) -> dict:
     return w
 
 
+def _net_from_cfg(cfg: dict):
+    """abi.Net (qmann_net) with the dimensions, modes and Q-formats of `cfg`; lin_map pointers left NULL."""
+    n = abi.Net()
+    n.n_hop, n.dim_emb, n.dim_emb_pad, n.dim_input = cfg["n_hop"], cfg["dim_emb"], pad16(cfg["dim_emb"]), cfg["dim_input"]
+    n.attention_mode = cfg["attention_mode"]
+    n.softmax_base = cfg.get("softmax_variant", 0)      # 0 e^x, 1 2^x, 2 exp_plan
+    n.softmax_shift_based = 1 if cfg.get("softmax_shift_based") else 0
+    if cfg.get("att_scale") is not None:                # EN_SC_ATT: one learnt scalar per hop
+        n.en_att_scale = 1
+        for h in range(cfg["n_hop"]):
+            n.att_scale[h] = float(np.float32(cfg["att_scale"][h]))
+    n.en_lin_map = 1 if cfg.get("en_lin_map", True) else 0
+    n.num_bit = cfg.get("num_bit", 8)
+    for h in range(cfg["n_hop"]):
+        n.act[h] = abi.Fmt(*cfg["fmt"][h])
+        n.w[h] = abi.Fmt(*cfg["fmt_w"][h])
+        n.att[h] = abi.Fmt(*cfg["fmt_att"][h])
+    n.bin = abi.Fmt(*cfg["fmt_bin"])
+    return n
+
+
 @dataclass
 class HopTaps:
     score_codes: torch.Tensor
@@ -114,22 +135,7 @@ class QNet:
         self.H, self.D, self.V = cfg["n_hop"], cfg["dim_emb"], cfg["dim_input"]
         self.Dp = pad16(self.D)
         self.stream = stream
-        n = self.net = abi.Net()
-        n.n_hop, n.dim_emb, n.dim_emb_pad, n.dim_input = self.H, self.D, self.Dp, self.V
-        n.attention_mode = cfg["attention_mode"]
-        n.softmax_base = cfg.get("softmax_variant", 0)      # 0 e^x, 1 2^x, 2 exp_plan
-        n.softmax_shift_based = 1 if cfg.get("softmax_shift_based") else 0
-        if cfg.get("att_scale") is not None:                # EN_SC_ATT: one learnt scalar per hop
-            n.en_att_scale = 1
-            for h in range(cfg["n_hop"]):
-                n.att_scale[h] = float(np.float32(cfg["att_scale"][h]))
-        n.en_lin_map = 1 if cfg.get("en_lin_map", True) else 0
-        n.num_bit = cfg.get("num_bit", 8)
-        for h in range(self.H):
-            n.act[h] = abi.Fmt(*cfg["fmt"][h])
-            n.w[h] = abi.Fmt(*cfg["fmt_w"][h])
-            n.att[h] = abi.Fmt(*cfg["fmt_att"][h])
-        n.bin = abi.Fmt(*cfg["fmt_bin"])
+        n = self.net = _net_from_cfg(cfg)
 
         def up(a):
             return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(self.dev)
@@ -284,3 +290,60 @@ class QNet:
         pred, probs, cost, match = self.answer(u, answer, want_probs=taps)
         return dict(pred=pred, probs=probs, cost=cost, match=match, u=u, u0=u0, keys=keys, vals=vals,
                     taps=r[1] if taps else None)
+
+
+class HostModel:
+    """include/qmann_model.h through ctypes: the library's own host-side object (C++), one call per batch.
+    `weights` is the dict QNet takes (host float arrays); nothing of the orchestration happens in Python."""
+
+    def __init__(self, cfg: dict, weights: dict, device="cuda:0", stream=None):
+        self.cfg, self.dev, self.stream = cfg, torch.device(device), stream
+        H, D, V = cfg["n_hop"], cfg["dim_emb"], cfg["dim_input"]
+        self.D = D
+        w = {k: ([np.ascontiguousarray(m, np.float32) for m in v] if isinstance(v, (list, tuple))
+                 else np.ascontiguousarray(v, np.float32)) for k, v in weights.items() if v is not None}
+        self._net = _net_from_cfg(cfg)
+        ws = _weights_struct(w, H, D, V, bool(cfg.get("en_lin_map", True)))
+        h = C.c_void_p()
+        abi.check(abi.lib.qmann_model_create(C.byref(h), C.byref(self._net), C.byref(ws), self._s()), "qmann_model_create")
+        self.h = h
+
+    def _s(self):
+        return C.c_void_p(self.stream) if self.stream else None
+
+    def close(self):
+        if getattr(self, "h", None) and abi is not None:      # (module globals are gone at interpreter shutdown)
+            abi.lib.qmann_model_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _out(self, B, answer):
+        pred = torch.empty(B, dtype=torch.int32, device=self.dev)
+        cost = torch.zeros(1, dtype=torch.float32, device=self.dev) if answer is not None else None
+        match = torch.zeros(1, dtype=torch.int32, device=self.dev) if answer is not None else None
+        return pred, cost, match
+
+    def last_u(self, B):
+        """copy of the final hop state of the last batch, [B][D]"""
+        p = abi.lib.qmann_model_last_u(self.h)
+        host = np.empty((B, self.D), np.float32)
+        abi.lib.cuda_copy_dev2host(host.ctypes.data_as(C.c_void_p), C.c_void_p(p), B * self.D)   # boundary B's own D2H verb
+        return torch.from_numpy(host).to(self.dev)
+
+    def forward_words(self, story_words, question_words, row_off, max_slots, answer=None):
+        B = question_words.shape[0]
+        pred, cost, match = self._out(B, answer)
+        abi.check(abi.lib.qmann_model_forward_words(self.h, _ptr(story_words), story_words.shape[0], story_words.shape[1],
+                                                    _ptr(question_words), question_words.shape[1], _ptr(row_off),
+                                                    max_slots, B, _ptr(answer), _ptr(pred), _ptr(cost), _ptr(match),
+                                                    self._s()), "qmann_model_forward_words")
+        return pred, cost, match
+
+    def forward_bow(self, story, question, row_off, max_slots, answer=None):
+        B = question.shape[0]
+        pred, cost, match = self._out(B, answer)
+        abi.check(abi.lib.qmann_model_forward_bow(self.h, _ptr(story), story.shape[0], _ptr(question), _ptr(row_off),
+                                                  max_slots, B, _ptr(answer), _ptr(pred), _ptr(cost), _ptr(match),
+                                                  self._s()), "qmann_model_forward_bow")
+        return pred, cost, match
