@@ -48,9 +48,10 @@ enum {
     QMANN_ATT_FIXED = 2,      /* per-product quantised dot product, quantised read-out            */
     QMANN_ATT_APPX = 3,       /* CUDA "approximate" Hamming attention (lib/layer_cuda.cu:355-541) */
     QMANN_ATT_HAMMING_V0 = 10,/* bit-agreement count over the top n bits (lib/common.c:223-246)   */
-    QMANN_ATT_HAMMING_V1 = 11,/* signed, weighted bit agreement (lib/common.c:249-312)            */
-    QMANN_ATT_SIGN = 12       /* +-1 dot product of the sign bits (BINARY_MODE, n = 1)            */
+    QMANN_ATT_HAMMING_V1 = 11 /* signed, weighted bit agreement (lib/common.c:249-312)            */
 };
+/* BINARY_MODE (define.h:87-88: the query binarised to +-1 in the scores and the linear map) is not a mode
+ * of its own: set qmann_net.bin = {0, 0}, exactly what the reference does (MemN2N.c:769-775). */
 
 /* byte layout of an int8 code */
 enum { QMANN_CODE_TWOS = 0 /* two's complement (weights) */, QMANN_CODE_SIGNMAG = 1 /* memories */ };
@@ -75,7 +76,7 @@ typedef struct qmann_net {
     qmann_fmt act[QMANN_MAX_HOP];   /* (iwl[h], frac[h])          MemN2N/MemN2N.c:715-716 */
     qmann_fmt w[QMANN_MAX_HOP];     /* (iwl_w[h], frac_w[h])      :718-719, 748-754       */
     qmann_fmt att[QMANN_MAX_HOP];   /* (iwl_att[h], frac_att[h])  :721-722                */
-    qmann_fmt bin;                  /* (iwl_bin, frac_bin)        :769-775                */
+    qmann_fmt bin;                  /* (iwl_bin, frac_bin)        :769-775; {0,0} binarises u   */
     const int8_t *lin_map[QMANN_MAX_HOP]; /* device, [D][Dp] sign-magnitude codes (QMANN_CODE_SIGNMAG) in format w[h]; NULL when !en_lin_map */
     /* in-hop softmax variants; all zero = the stock configuration */
     uint32_t softmax_shift_based;   /* EN_SHIFT_BASED_SM (define.h:54-55): power-of-two style normaliser, sf_in only (MemN2N.c:856) */

@@ -67,7 +67,7 @@ k_hops_fixed(const HopArgs a)
 
         // query codes Q_bin(u), histogram reset
         for (uint32_t c = tid; c < 256; c += nthreads) {
-            ku[c] = (short)((c < D) ? qm_code(u_f[c], fb.iwl, fb.frac) : 0);
+            ku[c] = (short)((c < D) ? qm_code_or_sign(u_f[c], fb.iwl, fb.frac) : 0);
             for (uint32_t i = 0; i < nwaves; i++) hist[i * 256 + c] = 0u;
         }
         if (tid == 0) misc[0] = 0u;
@@ -211,7 +211,7 @@ int qmann_hops_i8(const qmann_net *net, const int8_t *keys, const int8_t *vals, 
         return qmann_hops_appx_impl(net, keys, vals, hop_stride, row_off, max_slots, u0, u_out, taps, n_query, stream);
     if (net->attention_mode != QMANN_ATT_FIXED && net->attention_mode != QMANN_ATT_FLOAT) return QMANN_EUNSUPPORTED;
     if (net->softmax_base > QMANN_SOFTMAX_EXP_PLAN) return QMANN_EINVAL;
-    if (!fmt8(net->bin)) return QMANN_ERANGE;
+    if (!fmt8(net->bin) && net->bin.iwl + net->bin.frac != 0) return QMANN_ERANGE;     // (0,0) = BINARY_MODE: u binarised
     for (uint32_t h = 0; h < net->n_hop; h++) {
         if (!fmt8(net->act[h]) || !fmt8(net->w[h]) || !fmt8(net->att[h])) return QMANN_ERANGE;
         if (net->en_lin_map && !net->lin_map[h]) return QMANN_EINVAL;

@@ -60,7 +60,7 @@ k_hops_float(const HopArgs a)
         const QFmt fw = a.w[h], fb = a.bin;
         const QFmt fsrc = h == 0 ? a.w[0] : a.act[h - 1];              // grid u sits on (emb_q or sv[h-1])
         const float uv = u_f[tid];
-        ku[tid] = (short)((tid < D) ? qm_code(uv, fb.iwl, fb.frac) : 0);
+        ku[tid] = (short)((tid < D) ? qm_code_or_sign(uv, fb.iwl, fb.frac) : 0);
         kuq[tid] = (int8_t)((tid < D) ? qm_code(uv, fsrc.iwl, fsrc.frac) : 0);   // exact: u is on that grid
         __syncthreads();
 

@@ -69,7 +69,7 @@ k_hops_ham(const HopArgs a, const uint32_t key_row_bytes, const uint32_t lds_slo
         const QFmt fa = a.act[h], fm = a.att[h], fb = a.bin;
         // codes of u: Q_bin for the linear map, sign-magnitude Q_att bytes for the attention
         const float uv = u_f[tid];
-        ku[tid] = (short)((tid < D) ? qm_code(uv, fb.iwl, fb.frac) : 0);
+        ku[tid] = (short)((tid < D) ? qm_code_or_sign(uv, fb.iwl, fb.frac) : 0);
         const int kc = (tid < D) ? qm_code(uv, fm.iwl, fm.frac) : 0;
         const uint32_t ubyte = (uint32_t)(kc < 0 ? -kc : kc) | ((tid < D && !(uv >= 0.0f)) ? 0x80u : 0u);
         ub[tid] = (uint8_t)ubyte;
@@ -221,7 +221,7 @@ int fill_args(HopArgs &a, const qmann_net *net, const void *keys, const int8_t *
     if (net->dim_emb == 0 || net->dim_emb > net->dim_emb_pad) return QMANN_EINVAL;
     if (net->dim_emb_pad != 64 && net->dim_emb_pad != 128 && net->dim_emb_pad != 256) return QMANN_EUNSUPPORTED;
     if (net->softmax_base > QMANN_SOFTMAX_EXP_PLAN) return QMANN_EINVAL;
-    if (!fmt8(net->bin)) return QMANN_ERANGE;
+    if (!fmt8(net->bin) && net->bin.iwl + net->bin.frac != 0) return QMANN_ERANGE;     // (0,0) = BINARY_MODE: u binarised
     for (uint32_t h = 0; h < net->n_hop; h++) {
         if (!fmt8(net->act[h]) || !fmt8(net->w[h]) || !fmt8(net->att[h])) return QMANN_ERANGE;
         if (net->att[h].iwl + net->att[h].frac != 7 || net->att[h].iwl < 1) return QMANN_EUNSUPPORTED;

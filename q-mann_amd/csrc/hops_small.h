@@ -77,7 +77,7 @@ k_hops_small(const HopArgs a, const uint32_t key_row_bytes)
         // their bit planes for the Hamming forms
         for (uint32_t c = lane; c < Dp; c += kWave) {
             const float uv = u_f[c];
-            ku[c] = (short)((c < D) ? qm_code(uv, fb.iwl, fb.frac) : 0);
+            ku[c] = (short)((c < D) ? qm_code_or_sign(uv, fb.iwl, fb.frac) : 0);
             if (MODE != kModeFixed) {
                 const int kc = (c < D) ? qm_code(uv, fm.iwl, fm.frac) : 0;
                 const uint32_t ubyte = (uint32_t)(kc < 0 ? -kc : kc) | ((c < D && !(uv >= 0.0f)) ? 0x80u : 0u);

@@ -49,6 +49,14 @@ QM_HD uint32_t qm_signmag(float x, uint32_t iwl, uint32_t frac)
     return (uint32_t)(-(int64_t)t) | 0x80000000u;
 }
 
+// code of the OPERAND quantiser Qv(x): as qm_code, plus the iwl + frac == 0 case, which binarises to
+// +-1 (BINARY_MODE: iwl_bin = frac_bin = 0, MemN2N/MemN2N.c:769-775; lib/layer_cuda.h:207-253)
+QM_HD int32_t qm_code_or_sign(float x, uint32_t iwl, uint32_t frac)
+{
+    if (iwl + frac == 0) return (x >= 0.0f) ? 1 : -1;
+    return qm_code(x, iwl, frac);
+}
+
 QM_HD float qm_decode(int32_t code, uint32_t frac)
 {
     return qm_scale_down((float)code, frac);

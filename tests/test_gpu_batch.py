@@ -711,3 +711,19 @@ def test_host_model_forward_equals_oracle(env, oracle, gold, name, mode, num_bit
     assert excused <= (B // 4 if mode == 1 else max(1, B // 8)), excused
     assert int(m1.item()) == sum(int(p1[q] == ans[q]) for q in range(B))      # the device-side match counter
     hm.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# BINARY_MODE (define.h:87-88): the query enters the scores and the linear map as +-1
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("D,S_list", [(60, [1, 2, 9, 50, 64]), (128, [65, 300, 1000]), (256, [7, 129])])
+def test_binary_mode_fixed(env, oracle, D, S_list):
+    cfg = cfg_synth(D, 40, 5)
+    cfg["fmt_bin"] = (0, 0)
+    run_case(env, oracle, cfg, B=10, S_list=S_list, seed=1200 + D, sigma_k=6.0)
+
+
+@pytest.mark.parametrize("mode", [3, 11])
+def test_binary_mode_linear_map_in_hamming_kernels(env, oracle, mode):
+    for S_list in ([1, 9, 50], [70, 200]):
+        run_hamming_case(env, oracle, mode, 128, S_list, B=6, seed=1300 + mode, extra=dict(fmt_bin=(0, 0)))
