@@ -320,8 +320,15 @@ __device__ __forceinline__ void readout_sparse(const HopArgs &a, uint32_t h, uin
         const uint8_t *vb = (const uint8_t *)a.vals + (size_t)h * a.hop_stride + (size_t)r0 * Dp + c;
         int acc = 0;
         if (n_live <= (uint32_t)kLiveCap) {
-            for (uint32_t i = 0; i < n_live; i++)
-                acc += qm_mul_code((int)live_kp[i], sm_decode(vb[(size_t)live_row[i] * Dp]), fa.frac, maxa);
+            // four surviving rows per step, their (cold, HBM) value bytes requested together
+            for (uint32_t i0 = 0; i0 < n_live; i0 += 4) {
+                uint8_t vbyte[4];
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++) vbyte[j] = (i0 + j < n_live) ? vb[(size_t)live_row[i0 + j] * Dp] : (uint8_t)0;
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++)
+                    if (i0 + j < n_live) acc += qm_mul_code((int)live_kp[i0 + j], sm_decode(vbyte[j]), fa.frac, maxa);
+            }
         } else {                                   // cannot happen for p summing to 1; kept exact anyway
             for (uint32_t r = 0; r < S; r++) {
                 const int kp = kp_of_row(r);
@@ -378,15 +385,40 @@ __device__ __forceinline__ void linmap_update(const HopArgs &a, uint32_t q, uint
         for (uint32_t g = 0; g < n_it; g += LPR) {
             int keep = 0;
             uint32_t keep_r = D;
+            if (rows0) {                                 // (known at compile time per call site) rows already in registers
 #pragma unroll
-            for (uint32_t t = 0; t < LPR; t++) {
-                if (g + t < n_it) {                      // wavefront-uniform
-                    const uint32_t r = ((g + t) * nwaves + wave) * RPW + sub;
-                    i32x4 x = {0, 0, 0, 0};
-                    if (rows0 && g == 0) x = rows0[t];
-                    else if (r < D) x = *(const i32x4 *)(hb + (size_t)r * Dp);
-                    const int acc = row_lanes_sum<LPR>(lane_row_sum(x, c, sh));
-                    if (chunk == t) { keep = acc; keep_r = r; }
+                for (uint32_t t = 0; t < LPR; t++) {
+                    if (g + t < n_it) {                  // wavefront-uniform
+                        const uint32_t r = ((g + t) * nwaves + wave) * RPW + sub;
+                        i32x4 x = {0, 0, 0, 0};
+                        if (g == 0) x = rows0[t < 4 ? t : 3];
+                        else if (r < D) x = *(const i32x4 *)(hb + (size_t)r * Dp);
+                        const int acc = row_lanes_sum<LPR>(lane_row_sum(x, c, sh));
+                        if (chunk == t) { keep = acc; keep_r = r; }
+                    }
+                }
+            } else {
+                // rows are fetched four at a time before any of them is reduced: the loads are L2 hits
+                // (~0.6 us each) and would otherwise be paid one after the other
+                constexpr uint32_t BATCH = LPR < 4 ? LPR : 4;
+#pragma unroll
+                for (uint32_t t0 = 0; t0 < LPR; t0 += BATCH) {
+                    i32x4 x[BATCH];
+#pragma unroll
+                    for (uint32_t j = 0; j < BATCH; j++) {
+                        const uint32_t r = ((g + t0 + j) * nwaves + wave) * RPW + sub;
+                        x[j] = i32x4{0, 0, 0, 0};
+                        if (g + t0 + j < n_it && r < D) x[j] = *(const i32x4 *)(hb + (size_t)r * Dp);
+                    }
+#pragma unroll
+                    for (uint32_t j = 0; j < BATCH; j++) {
+                        const uint32_t t = t0 + j;
+                        if (g + t < n_it) {              // wavefront-uniform
+                            const uint32_t r = ((g + t) * nwaves + wave) * RPW + sub;
+                            const int acc = row_lanes_sum<LPR>(lane_row_sum(x[j], c, sh));
+                            if (chunk == t) { keep = acc; keep_r = r; }
+                        }
+                    }
                 }
             }
             if (keep_r < D) {
