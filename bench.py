@@ -334,7 +334,26 @@ def run_bow(args, name, wl, net, cfg, wts, dev, rank, world, model):
         for th in ths:
             th.join()
         wall = time.perf_counter() - t1
+        # the one stage of this forward whose CPU body is live in the reference (dense_mat_fwd, lib/layer.c:2671-2696):
+        # the reference's own compiled code (oracle/_ref, prebuilt where /root/reference exists) on the story rows
+        ref_stage = None
+        try:
+            from pyoracle import Reference
+            ref = Reference()
+            t1, n_rows = time.perf_counter(), 0
+            while time.perf_counter() - t1 < 3.0:
+                for h in range(cfg["n_hop"]):
+                    ref.dense_mat_fwd(wts["w_a"][h], st, True, cfg["fmt_w"][h])
+                    ref.dense_mat_fwd(wts["w_c"][h], st, True, cfg["fmt_w"][h])
+                n_rows += st.shape[0]
+            dt = time.perf_counter() - t1
+            ref_stage = {"stage": "story embedding: dense_mat_fwd for A and C of every hop (the reference's live CPU code)",
+                         "kind": "reference", "cores": 1, "story_rows_per_s": n_rows / dt,
+                         "queries_per_s_equivalent": n_rows / dt / float(np.mean(n_sen))}
+        except (FileNotFoundError, OSError):
+            pass
         res["cpu_baseline"] = {"value": sum(counts) / wall, "unit": "queries/s", "cores": cores, "kind": "port",
+                               "reference_stage": ref_stage,
                                "sample": f"the 64 fixture stories, {sum(counts)} forwards in {wall:.1f} s on {cores} threads "
                                          "(one per usable host core; the Python call overhead is part of it), scalar C oracle -O2",
                                "one_thread": {"value": reps * len(n_sen) / t_used,
