@@ -1,0 +1,92 @@
+"""The headers are C, and a plain C host can drive the library: compile checks without a GPU, and the
+example host (examples/forward_words.c: weight files -> qmann_model -> one call per batch) on the GPU."""
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_pkg
+
+INC = ["-I", str(ROOT / "include")]
+LINK = ["-L", str(ROOT / "q-mann_amd" / "lib"), "-lqmann_hip", "-L/opt/rocm/lib", "-lamdhip64",
+        f"-Wl,-rpath,{ROOT / 'q-mann_amd' / 'lib'}", "-Wl,-rpath,/opt/rocm/lib", "-lm"]
+
+
+def test_headers_are_strict_c99(tmp_path):
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "qmann_abi.h"\n#include "qmann_batch.h"\n#include "qmann_weights.h"\n#include "qmann_model.h"\n'
+                   "int main(void) { qmann_net n = {0}; qmann_weights w = {0}; (void)n; (void)w; return (int)sizeof(qmann_taps) * 0; }\n")
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", *INC, "-fsyntax-only", str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def build_example(tmp_path):
+    load_pkg()                                               # (the library must exist)
+    exe = tmp_path / "forward_words"
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", *INC, "-I/opt/rocm/include", str(ROOT / "examples" / "forward_words.c"),
+                        *LINK, "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return exe
+
+
+def test_example_host_compiles_and_links(tmp_path):
+    exe = build_example(tmp_path)
+    und = subprocess.run(["nm", "-D", "--undefined-only", str(exe)], capture_output=True, text=True, check=True).stdout
+    used = sorted({l.split()[-1] for l in und.splitlines() if " U qmann_" in l})
+    assert used == ["qmann_model_create", "qmann_model_destroy", "qmann_model_forward_words", "qmann_weights_load"]
+
+
+@pytest.mark.gpu
+def test_example_host_runs_and_matches_the_oracle(tmp_path, gold, oracle):
+    import qmann_amd.model as model
+    exe = build_example(tmp_path)
+    b = gold("babi_qa1_test64.npz")
+    V, dd, D, H, iwl = int(b["dim_input"]), int(b["dim_dict"]), 60, 3, 2
+    cfg = model.babi_cfg(V, 2, 0, iwl=iwl)
+    rng = np.random.default_rng(77)
+    wts = {"w_q": rng.normal(0, 0.8, (D, V)).astype(np.float32), "w_ans": rng.normal(0, 0.1, (V, D)).astype(np.float32),
+           "w_a": [rng.normal(0, 0.8, (D, V)).astype(np.float32) for _ in range(H)],
+           "w_c": [rng.normal(0, 0.8, (D, V)).astype(np.float32) for _ in range(H)],
+           "w_h": [rng.normal(0, 1.0, (D, D)).astype(np.float32) for _ in range(H)]}
+    wdir = tmp_path / "weights"; wdir.mkdir()
+    model.save_weights(wdir, wts, cfg, fixed=False)
+    story, ques = b["story"].astype(np.float32), b["question"].astype(np.float32)
+    n_sen = b["n_sen"].astype(np.int64); ans = b["answer"].argmax(1).astype(np.uint32)
+
+    def words(bow, nd, width, with_time):
+        out = np.full((bow.shape[0], width), 0xFFFF, np.uint16)
+        for r, row in enumerate(bow):
+            ent = [k for k in np.flatnonzero(row[:nd]) for _ in range(int(row[k]))]
+            if with_time:
+                ent.append(nd + int(np.flatnonzero(row[nd:])[0]))
+            out[r, :len(ent)] = ent
+        return out
+    sw, qw = words(story, dd, 12, True), words(ques, V, 8, False)
+    row_off = np.concatenate([[0], np.cumsum(n_sen)]).astype(np.uint32)
+    nq = len(n_sen)
+    with open(tmp_path / "batch.bin", "wb") as f:
+        f.write(struct.pack("<9I", V, D, H, iwl, nq, sw.shape[0], 12, 8, int(n_sen.max())))
+        f.write(row_off.tobytes()); f.write(sw.tobytes()); f.write(qw.tobytes()); f.write(ans.tobytes())
+    r = subprocess.run([str(exe), str(wdir), str(tmp_path / "batch.bin"), str(tmp_path / "pred.bin")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = (tmp_path / "pred.bin").read_bytes()
+    pred = np.frombuffer(raw[:4 * nq], np.uint32)
+    match = struct.unpack("<I", raw[4 * nq:4 * nq + 4])[0]
+    cost = struct.unpack("<f", raw[4 * nq + 4:])[0]
+    m = oracle.make_model(cfg, wts)
+    o, want_cost, checked = 0, 0.0, 0
+    for q in range(nq):
+        ns = int(n_sen[q])
+        opred, t = oracle.forward(m, story[o:o + ns], ques[q], taps=("out_probs",))
+        o += ns
+        top2 = np.sort(t["out_probs"])[-2:]
+        if top2[1] - top2[0] > 1e-6:
+            assert int(pred[q]) == opred, q
+            checked += 1
+        want_cost -= float(t["out_probs"][ans[q]])
+    assert checked >= nq - 2
+    assert match == int((pred == ans).sum())
+    assert cost == pytest.approx(want_cost, rel=1e-4)
