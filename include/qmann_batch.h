@@ -82,6 +82,9 @@ typedef struct qmann_net {
     uint32_t softmax_shift_based;   /* EN_SHIFT_BASED_SM (define.h:54-55): power-of-two style normaliser, sf_in only (MemN2N.c:856) */
     uint32_t en_att_scale;          /* EN_SC_ATT (define.h:58-59): scores times one learnt scalar before the softmax (MemN2N.c:2647-2649) */
     float att_scale[QMANN_MAX_HOP]; /* that scalar per hop (scale.w, lib/layer.h:786-810) */
+    uint32_t en_non_linearity;      /* EN_NON_LINEARITY (define.h): RELU layers non_lin[h] (MemN2N.c:894-896, 2668-2671): the attention of
+                                     * hop h >= 1 and the answer layer read RELU(sv), lin_map keeps reading sv (:2435-2437, 2471-2473, 2535-2537);
+                                     * u_out is then RELU(sv[n_hop-1]) */
 } qmann_net;
 
 /* optional per-query taps for parity tests; any pointer may be NULL */

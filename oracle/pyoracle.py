@@ -40,6 +40,7 @@ class QoModel(C.Structure):
         ("w_a", _f32p * QO_MAX_HOP), ("w_c", _f32p * QO_MAX_HOP), ("w_h", _f32p * QO_MAX_HOP),
         ("w_ans", _f32p),
         ("f_shift_based", C.c_bool), ("en_sc_att", C.c_bool), ("sc_att", C.c_float * QO_MAX_HOP),
+        ("en_non_lin", C.c_bool),
     ]
 
 
@@ -249,6 +250,7 @@ class Oracle:
             m.iwl_att[h], m.frac_att[h] = cfg["fmt_att"][h]
         m.iwl_bin, m.frac_bin = cfg["fmt_bin"]
         m.f_shift_based = bool(cfg.get("softmax_shift_based", False))
+        m.en_non_lin = bool(cfg.get("en_non_lin", False))
         if cfg.get("att_scale") is not None:
             m.en_sc_att = True
             for h in range(cfg["n_hop"]):

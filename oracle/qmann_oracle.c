@@ -591,18 +591,28 @@ static void hop_forward(const qo_model *m, unsigned h, const float *keys, const 
     float *o = (float *)malloc(D * sizeof(float));
     float *lu = (float *)malloc(D * sizeof(float));
 
+    /* EN_NON_LINEARITY: from the second hop on the attention reads non_lin[h-1].out = RELU(sv[h-1])
+     * (MemN2N.c:2435-2437, constructor :894-896), while lin_map[h] keeps reading sv[h-1] itself (:2471-2473) */
+    const float *u_sv = u;
+    float *u_relu = NULL;
+    if (m->en_non_lin && h > 0) {
+        u_relu = (float *)malloc(D * sizeof(float));
+        qo_activation_fwd(u_sv, u_relu, D, "RELU", m->f_fixed, m->iwl[h - 1], m->frac[h - 1]);
+    }
+    const float *u_att = u_relu ? u_relu : u_sv;
     /* attention scores: dotmv[h] (constructor MemN2N.c:846-850) */
     if (m->attention_mode == 1)
-        qo_dot_mat_vec_fwd(keys, u, s, n_sen, D, false, false, 0, 0, 0, 0);
+        qo_dot_mat_vec_fwd(keys, u_att, s, n_sen, D, false, false, 0, 0, 0, 0);
     else if (m->attention_mode == 2)
-        qo_dot_mat_vec_fwd(keys, u, s, n_sen, D, false, true,
+        qo_dot_mat_vec_fwd(keys, u_att, s, n_sen, D, false, true,
                            m->iwl_att[h], m->frac_att[h], m->iwl_bin, m->frac_bin);
     else if (m->attention_mode == 3)
-        qo_dot_mat_vec_fwd_appx(keys, u, s, n_sen, D, m->f_fixed, m->iwl_att[h], m->frac_att[h],
+        qo_dot_mat_vec_fwd_appx(keys, u_att, s, n_sen, D, m->f_fixed, m->iwl_att[h], m->frac_att[h],
                                 1 + m->iwl_att[h] + m->frac_att[h], false);
     else /* 10 / 11: the CPU hamming functions on the CUDA word alignment (frac = 31 - iwl) */
-        qo_attention_hamming(keys, u, s, n_sen, D, m->iwl_att[h], 31 - m->iwl_att[h], m->num_bit,
+        qo_attention_hamming(keys, u_att, s, n_sen, D, m->iwl_att[h], 31 - m->iwl_att[h], m->num_bit,
                              m->attention_mode == 10 ? 0 : 1);
+    free(u_relu);
     if (taps && taps->scores) memcpy(taps->scores + (size_t)h * n_sen, s, n_sen * sizeof(float));
     /* optional scale layer sc_sf_in[h] (MemN2N.c:2647-2649): plain float product with one scalar */
     if (m->en_sc_att)
@@ -641,7 +651,12 @@ static unsigned answer_forward(const qo_model *m, const float *u, qo_taps *taps)
     const unsigned D = m->dim_emb, V = m->dim_input;
     float *a = (float *)malloc(V * sizeof(float));
     float *ph = (float *)malloc(V * sizeof(float));
-    qo_dense_fwd(m->w_ans, u, a, D, V, "NULL", false, 0, 0, 0, 0);
+    float *u_in = (float *)malloc(D * sizeof(float));
+    /* with EN_NON_LINEARITY the answer layer reads non_lin[NUM_HOP-1].out (MemN2N.c:2535-2537) */
+    if (m->en_non_lin) qo_activation_fwd(u, u_in, D, "RELU", m->f_fixed, m->iwl[m->n_hop - 1], m->frac[m->n_hop - 1]);
+    else memcpy(u_in, u, D * sizeof(float));
+    qo_dense_fwd(m->w_ans, u_in, a, D, V, "NULL", false, 0, 0, 0, 0);
+    free(u_in);
     qo_softmax_fwd(a, ph, V, m->softmax_variant, false);
     unsigned pred = qo_argmax_hi(ph, V);
     if (taps) {

@@ -134,6 +134,7 @@ typedef struct {
     bool     f_shift_based;           /* EN_SHIFT_BASED_SM: sf_in only, MemN2N.c:856 (sf_out never, :910) */
     bool     en_sc_att;               /* EN_SC_ATT: scale layer between dotmv and sf_in, MemN2N.c:2647-2651 */
     float    sc_att[QO_MAX_HOP];      /* its scalar weight per hop (out = in * w, lib/layer_cuda.cu:1551-1558) */
+    bool     en_non_lin;              /* EN_NON_LINEARITY: RELU layer after sv[h], formats (iwl[h],frac[h]); MemN2N.c:894-896, 2668-2671 */
 } qo_model;
 
 typedef struct {                 /* optional taps; any pointer may be NULL */

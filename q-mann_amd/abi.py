@@ -37,6 +37,7 @@ class Net(C.Structure):
         ("act", Fmt * QMANN_MAX_HOP), ("w", Fmt * QMANN_MAX_HOP), ("att", Fmt * QMANN_MAX_HOP), ("bin", Fmt),
         ("lin_map", _vp * QMANN_MAX_HOP),
         ("softmax_shift_based", C.c_uint32), ("en_att_scale", C.c_uint32), ("att_scale", C.c_float * QMANN_MAX_HOP),
+        ("en_non_linearity", C.c_uint32),
     ]
 
 

@@ -76,7 +76,8 @@ k_hops_fixed(const HopArgs a)
         if (S > 0) {
             // lane constants: |u| pre-shifted so that saturation == the per-product clamp
             ScanConst c;
-            const uint32_t sh = make_scan_const(c, ku, (lane % LPR) * 16, fm.iwl + fm.frac, fv);
+            const uint32_t sh = make_scan_const(c, ku, (lane % LPR) * 16, fm.iwl + fm.frac, fv, hop_relu(a, h),
+                                                fb.iwl + fb.frac == 0);
             const uint8_t *kb = (const uint8_t *)a.keys + (size_t)h * a.hop_stride + (size_t)r0 * Dp;
             uint32_t *hw = hist + wave * 256;
             auto row_sum = [&](const i32x4 x) { return lane_row_sum(x, c, sh); };
@@ -144,7 +145,7 @@ k_hops_fixed(const HopArgs a)
         auto kp_of_row = [&](uint32_t r) { return (int)kplut[(int)sc[r] + 127]; };
         finish_hop<Dp>(a, q, h, r0, S, n_live, live_row, live_kp, kp_of_row, ku, u_f, o_f, tid);
     }
-    for (uint32_t c = tid; c < D; c += nthreads) a.u_out[(size_t)q * D + c] = u_f[c];
+    for (uint32_t c = tid; c < D; c += nthreads) a.u_out[(size_t)q * D + c] = relu_if(u_f[c], a.en_non_lin != 0);
 }
 
 __global__ void k_quantize_i8(const float *__restrict__ src, int8_t *__restrict__ dst, size_t rows, uint32_t cols,
@@ -232,7 +233,7 @@ int qmann_hops_i8(const qmann_net *net, const int8_t *keys, const int8_t *vals, 
     a.max_slots = max_slots;
     a.n_hop = net->n_hop; a.D = net->dim_emb; a.Dp = net->dim_emb_pad;
     a.softmax_base = net->softmax_base; a.en_lin_map = net->en_lin_map;
-    a.softmax_shift = net->softmax_shift_based; a.en_att_scale = net->en_att_scale;
+    a.softmax_shift = net->softmax_shift_based; a.en_att_scale = net->en_att_scale; a.en_non_lin = net->en_non_linearity;
     for (uint32_t h = 0; h < net->n_hop; h++) {
         a.att_scale[h] = net->att_scale[h];
         a.lin_map[h] = net->lin_map[h];

@@ -61,7 +61,7 @@ k_hops_float(const HopArgs a)
         const QFmt fsrc = h == 0 ? a.w[0] : a.act[h - 1];              // grid u sits on (emb_q or sv[h-1])
         const float uv = u_f[tid];
         ku[tid] = (short)((tid < D) ? qm_code_or_sign(uv, fb.iwl, fb.frac) : 0);
-        kuq[tid] = (int8_t)((tid < D) ? qm_code(uv, fsrc.iwl, fsrc.frac) : 0);   // exact: u is on that grid
+        kuq[tid] = (int8_t)((tid < D) ? qm_code(relu_if(uv, hop_relu(a, h)), fsrc.iwl, fsrc.frac) : 0);   // exact: u is on that grid
         __syncthreads();
 
         const float scale = qm_scale_down(1.0f, fw.frac + fsrc.frac);
@@ -198,7 +198,7 @@ k_hops_float(const HopArgs a)
         }
         linmap_update<Dp>(a, q, h, ku, u_f, o_f, tid);
     }
-    if (tid < D) a.u_out[(size_t)q * D + tid] = u_f[tid];
+    if (tid < D) a.u_out[(size_t)q * D + tid] = relu_if(u_f[tid], a.en_non_lin != 0);
 }
 
 template <int LPR>

@@ -70,8 +70,9 @@ k_hops_ham(const HopArgs a, const uint32_t key_row_bytes, const uint32_t lds_slo
         // codes of u: Q_bin for the linear map, sign-magnitude Q_att bytes for the attention
         const float uv = u_f[tid];
         ku[tid] = (short)((tid < D) ? qm_code_or_sign(uv, fb.iwl, fb.frac) : 0);
-        const int kc = (tid < D) ? qm_code(uv, fm.iwl, fm.frac) : 0;
-        const uint32_t ubyte = (uint32_t)(kc < 0 ? -kc : kc) | ((tid < D && !(uv >= 0.0f)) ? 0x80u : 0u);
+        const float ua = relu_if(uv, hop_relu(a, h));                    // what the attention reads
+        const int kc = (tid < D) ? qm_code(ua, fm.iwl, fm.frac) : 0;
+        const uint32_t ubyte = (uint32_t)(kc < 0 ? -kc : kc) | ((tid < D && !(ua >= 0.0f)) ? 0x80u : 0u);
         ub[tid] = (uint8_t)ubyte;
         if (MODE != kModeAppx) {
 #pragma unroll
@@ -183,7 +184,7 @@ k_hops_ham(const HopArgs a, const uint32_t key_row_bytes, const uint32_t lds_slo
         auto kp_of_row = [&](uint32_t r) { return MODE == kModeV0 ? (int)v0_kp[sc[r]] : (int)sc[r]; };
         finish_hop<DP>(a, q, h, r0, S, n_live, live_row, live_kp, kp_of_row, ku, u_f, o_f, tid);
     }
-    if (tid < D) a.u_out[(size_t)q * D + tid] = u_f[tid];
+    if (tid < D) a.u_out[(size_t)q * D + tid] = relu_if(u_f[tid], a.en_non_lin != 0);
 }
 
 // sign-magnitude bytes [rows][Dp] -> bit-planes [rows][Dp/64][nb]: one wavefront per (row, group),
@@ -241,7 +242,7 @@ int fill_args(HopArgs &a, const qmann_net *net, const void *keys, const int8_t *
     a.rows_total = (uint32_t)(val_hop_stride / net->dim_emb_pad);
     a.n_hop = net->n_hop; a.D = net->dim_emb; a.Dp = net->dim_emb_pad;
     a.softmax_base = net->softmax_base; a.en_lin_map = net->en_lin_map;
-    a.softmax_shift = net->softmax_shift_based; a.en_att_scale = net->en_att_scale;
+    a.softmax_shift = net->softmax_shift_based; a.en_att_scale = net->en_att_scale; a.en_non_lin = net->en_non_linearity;
     for (uint32_t h = 0; h < net->n_hop; h++) {
         a.att_scale[h] = net->att_scale[h];
         a.lin_map[h] = net->lin_map[h];

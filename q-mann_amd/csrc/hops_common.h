@@ -28,6 +28,7 @@ struct HopArgs {
     uint32_t n_hop, D, Dp, softmax_base, en_lin_map;
     QFmt act[QMANN_MAX_HOP], w[QMANN_MAX_HOP], att[QMANN_MAX_HOP], bin;
     uint32_t softmax_shift, en_att_scale;     // in-hop softmax variants (qmann_net)
+    uint32_t en_non_lin;                      // EN_NON_LINEARITY: see hop_relu() below
     float att_scale[QMANN_MAX_HOP];
 };
 }  // namespace qmann
@@ -122,7 +123,10 @@ __device__ __forceinline__ int lane_row_sum(const i32x4 x, const ScanConst &c, u
 
 // ScanConst of the 16 columns starting at c0 from the Q(v) codes `ku` of the vector; wl = word
 // length (iwl + frac) of the product format, fv = frac of the vector format.  Returns the result shift.
-__device__ __forceinline__ uint32_t make_scan_const(ScanConst &c, const short *ku, uint32_t c0, uint32_t wl, int fv)
+// `relu`: the codes are those of RELU(u) instead of u (negative codes become 0; a binarised operand,
+// format (0,0), becomes +1 everywhere because RELU(u) >= 0) -- see hop_relu().
+__device__ __forceinline__ uint32_t make_scan_const(ScanConst &c, const short *ku, uint32_t c0, uint32_t wl, int fv,
+                                                    bool relu = false, bool sign_fmt = false)
 {
     const uint32_t sh = 16u - wl;                       // result shift
     const int pre = (int)sh - fv;                       // |u| << pre (>= 0 since wl + fv <= 14)
@@ -131,7 +135,8 @@ __device__ __forceinline__ uint32_t make_scan_const(ScanConst &c, const short *k
         uint32_t m[4], sg = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const int k = ku[c0 + 4 * d + i];
+            int k = ku[c0 + 4 * d + i];
+            if (relu && k < 0) k = sign_fmt ? 1 : 0;
             const uint32_t a = (uint32_t)(k < 0 ? -k : k) << pre;
             m[i] = a > 0xFFFFu ? 0xFFFFu : a;
             sg |= (k < 0 ? 0x80u : 0u) << (8 * i);
@@ -263,6 +268,13 @@ __device__ __forceinline__ double block_sum_double(double v, double *scratch, ui
     __syncthreads();
     return r;
 }
+
+// EN_NON_LINEARITY (MemN2N/define.h, a RELU layer non_lin[h] after every sum_vec, MemN2N.c:894-896): from
+// the second hop on the ATTENTION reads RELU(sv[h-1]) (:2435-2437) while lin_map[h] keeps reading sv[h-1]
+// itself (:2471-2473), and the answer layer reads RELU(sv[H-1]) (:2535-2537).  The kernels therefore keep
+// the sum_vec state and apply the RELU where it is read.
+__device__ __forceinline__ bool hop_relu(const HopArgs &a, uint32_t h) { return a.en_non_lin && h > 0; }
+__device__ __forceinline__ float relu_if(float x, bool on) { return (on && !(x > 0.0f)) ? 0.0f : x; }
 
 // ---- softmax variants over slots ----------------------------------------------------------------
 // base EXP : e^(x-max), double normaliser, float quotient of the double division (lib/layer_cuda.cu:2006-2042);

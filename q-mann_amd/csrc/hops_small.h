@@ -79,8 +79,9 @@ k_hops_small(const HopArgs a, const uint32_t key_row_bytes)
             const float uv = u_f[c];
             ku[c] = (short)((c < D) ? qm_code_or_sign(uv, fb.iwl, fb.frac) : 0);
             if (MODE != kModeFixed) {
-                const int kc = (c < D) ? qm_code(uv, fm.iwl, fm.frac) : 0;
-                const uint32_t ubyte = (uint32_t)(kc < 0 ? -kc : kc) | ((c < D && !(uv >= 0.0f)) ? 0x80u : 0u);
+                const float ua = relu_if(uv, hop_relu(a, h));            // what the attention reads
+                const int kc = (c < D) ? qm_code(ua, fm.iwl, fm.frac) : 0;
+                const uint32_t ubyte = (uint32_t)(kc < 0 ? -kc : kc) | ((c < D && !(ua >= 0.0f)) ? 0x80u : 0u);
                 ub[c] = (uint8_t)ubyte;
                 if (MODE != kModeAppx) {
 #pragma unroll
@@ -121,7 +122,7 @@ k_hops_small(const HopArgs a, const uint32_t key_row_bytes)
             };
             if (MODE == kModeFixed) {
                 unit = qm_scale_down(1.0f, fm.frac);
-                csh = make_scan_const(csc, ku, chunkk * 16, fm.iwl + fm.frac, (int)fb.frac);
+                csh = make_scan_const(csc, ku, chunkk * 16, fm.iwl + fm.frac, (int)fb.frac, hop_relu(a, h), fb.iwl + fb.frac == 0);
                 scan([&](const i32x4 x) { return lane_row_sum(x, csc, csh); }, (1 << (fm.iwl + fm.frac)) - 1);   // Qm, lib/layer_cuda.cu:135
             } else if (MODE == kModeAppx) {
                 unit = 1.0f / 1024.0f;                          // 2^-(n-1) . 2^ATTENTION_CONST_SCALE, n = 8
@@ -181,10 +182,10 @@ k_hops_small(const HopArgs a, const uint32_t key_row_bytes)
         __syncthreads();
         // the key scan's lane constants serve the linear map as they are when both formats have the
         // same word length (always so at BW_WL 8): same u codes, same shift
-        const bool reuse = MODE == kModeFixed && S > 0 && (fw.iwl + fw.frac == fm.iwl + fm.frac);
+        const bool reuse = MODE == kModeFixed && S > 0 && (fw.iwl + fw.frac == fm.iwl + fm.frac) && !hop_relu(a, h);
         linmap_update<Dp>(a, q, h, ku, u_f, o_f, lane, &csc, csh, reuse, PF ? hq : nullptr);
     }
-    for (uint32_t c = lane; c < D; c += kWave) a.u_out[(size_t)q * D + c] = u_f[c];
+    for (uint32_t c = lane; c < D; c += kWave) a.u_out[(size_t)q * D + c] = relu_if(u_f[c], a.en_non_lin != 0);
 }
 
 }  // namespace

@@ -727,3 +727,26 @@ def test_binary_mode_fixed(env, oracle, D, S_list):
 def test_binary_mode_linear_map_in_hamming_kernels(env, oracle, mode):
     for S_list in ([1, 9, 50], [70, 200]):
         run_hamming_case(env, oracle, mode, 128, S_list, B=6, seed=1300 + mode, extra=dict(fmt_bin=(0, 0)))
+
+
+# ---------------------------------------------------------------------------------------------
+# EN_NON_LINEARITY: RELU layers; attention reads RELU(sv), lin_map reads sv, answer reads RELU(sv)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("path", ["fixed_small", "fixed_hist", "appx", "v0_small", "v1", "float", "binary"])
+def test_non_linearity(env, oracle, path):
+    extra = dict(en_non_lin=True)
+    if path == "fixed_small":
+        run_case(env, oracle, cfg_synth(60, 40, 5), B=12, S_list=[1, 2, 5, 17, 50, 64], seed=1400, extra=extra)
+    elif path == "fixed_hist":
+        run_case(env, oracle, cfg_synth(128, 40, 5), B=6, S_list=[65, 300, 1000], seed=1401, extra=extra)
+    elif path == "binary":
+        run_case(env, oracle, cfg_synth(60, 40, 5), B=8, S_list=[3, 40, 200], seed=1402, sigma_k=6.0,
+                 extra=dict(en_non_lin=True, fmt_bin=(0, 0)))
+    elif path == "appx":
+        run_hamming_case(env, oracle, 3, 128, [1, 9, 64, 200], B=8, seed=1403, extra=extra)
+    elif path == "v0_small":
+        run_hamming_case(env, oracle, 10, 60, [1, 9, 50, 64], B=8, seed=1404, num_bit=8, extra=extra)
+    elif path == "v1":
+        run_hamming_case(env, oracle, 11, 128, [1, 9, 64, 200], B=8, seed=1405, num_bit=8, extra=extra)
+    else:
+        run_float_case(env, oracle, 60, [1, 2, 10, 50, 64, 300], 6, extra=extra)
