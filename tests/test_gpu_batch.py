@@ -750,3 +750,40 @@ def test_non_linearity(env, oracle, path):
         run_hamming_case(env, oracle, 11, 128, [1, 9, 64, 200], B=8, seed=1405, num_bit=8, extra=extra)
     else:
         run_float_case(env, oracle, 60, [1, 2, 10, 50, 64, 300], 6, extra=extra)
+
+
+# ---------------------------------------------------------------------------------------------
+# bag-of-words embedding with fractional entries (position encoding, EN_PE) and dense rows
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("V,D,nnz", [(30, 60, 6), (256, 60, 9), (80, 128, 80), (40, 256, 3)])
+def test_bow_embedding_fractional_and_dense_rows(env, oracle, V, D, nnz):
+    """qmann_embed_story / _query against dense_mat_fwd / dense_fwd of the oracle (pinned by the reference's
+    live dense_mat_fwd) for rows whose entries are arbitrary floats -- fractional position-encoding weights,
+    negative values, values beyond the format -- and for rows denser than the kernel's non-zero list."""
+    torch, model = env.torch, env.model
+    rng = np.random.default_rng(V * 3 + D + nnz)
+    rows, nq = 41, 9
+    story = np.zeros((rows, V), np.float32); ques = np.zeros((nq, V), np.float32)
+    for r in range(rows):
+        idx = rng.choice(V, size=min(nnz, V), replace=False)
+        story[r, idx] = rng.choice([0.25, 0.3333333, 0.5, 0.8125, 1.0, 2.0, -0.75, 40.0], size=len(idx))
+    for q in range(nq):
+        idx = rng.choice(V, size=min(nnz, V), replace=False)
+        ques[q, idx] = rng.uniform(-1.5, 2.5, len(idx)).astype(np.float32)
+    cfg = model.babi_cfg(V, 2, 0, iwl=2, D=D)
+    wts = weights(V + D + nnz, 3, D, V, 0.8)
+    net = model.QNet(cfg, wts)
+    keys, vals, u0 = net.embed(torch.from_numpy(story).to(env.dev), torch.from_numpy(ques).to(env.dev))
+    torch.cuda.synchronize()
+    k = model.from_signmag(keys.cpu().numpy()); v = model.from_signmag(vals.cpu().numpy()); u0 = u0.cpu().numpy()
+    for h in range(3):
+        fw = cfg["fmt_w"][h]
+        ka = oracle.dense_mat_fwd(wts["w_a"][h], story, True, fw)          # on the weight grid ...
+        kc = oracle.dense_mat_fwd(wts["w_c"][h], story, True, fw)
+        want_k = oracle.code8(ka, *cfg["fmt_att"][h])                      # ... re-read on the attention / activation grids
+        want_v = oracle.code8(kc, *cfg["fmt"][h])
+        np.testing.assert_array_equal(k[h, :, :D], want_k, err_msg=f"keys hop {h}")
+        np.testing.assert_array_equal(v[h, :, :D], want_v, err_msg=f"values hop {h}")
+        assert not k[h, :, D:].any() and not v[h, :, D:].any()
+    for q in range(nq):
+        np.testing.assert_array_equal(u0[q], oracle.dense_fwd(wts["w_q"], ques[q], True, cfg["fmt_w"][0], cfg["fmt_w"][0]))
