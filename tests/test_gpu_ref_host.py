@@ -86,9 +86,16 @@ def test_reference_layer_api_drives_our_library(oracle, gold, tmp_path, att_mode
     assert cost == pytest.approx(want_cost, rel=1e-4)
 
 
-@pytest.mark.parametrize("binary,mode_name", [("MemN2N_ref", "quantized"), ("MemN2N_ref_mode3", "approximate"),
-                                              ("MemN2N_ref_cfg1", "normal")])
-def test_unmodified_reference_program_trains_and_tests(gold, tmp_path, binary, mode_name):
+# (binary, attention mode it prints, required drop of the training error, cap on the test error)
+@pytest.mark.parametrize("binary,mode_name,drop,cap", [
+    ("MemN2N_ref", "quantized", 0.2, 0.75),
+    ("MemN2N_ref_mode3", "approximate", 0.1, 0.95),
+    ("MemN2N_ref_cfg1", "normal", 0.2, 0.75),          # BASELINE config 1: float dot attention, no fixed point, one hop
+    # shift-based softmax + scale layer + RELU layers switched on together: their verbs inside the reference's
+    # own loops; a functional run (finite errors), not a learning claim for this combination
+    ("MemN2N_ref_feat", "quantized", None, 1.0),
+])
+def test_unmodified_reference_program_trains_and_tests(gold, tmp_path, binary, mode_name, drop, cap):
     """oracle/_ref/MemN2N_ref is the reference's whole host program -- MemN2N.c, sample.c, layer.c, common.c
     compiled where they lie with its own define.h -- linked against libqmann_hip.so in place of the CUDA
     object.  `./MemN2N 1 1 1 5` (run.sh's command line for task 1, one loop): 100 epochs of SGD, then the
@@ -112,9 +119,9 @@ def test_unmodified_reference_program_trains_and_tests(gold, tmp_path, binary, m
     err = [float(l.split("error:")[1].split(",")[0]) for l in itr]
     # training reduces the training error (a functional check of the whole loop, not an accuracy claim: 1 000
     # stories, 8-bit Q5.2; the Hamming-attention build learns more slowly at this setting)
-    # ("normal" = BASELINE config 1: float dot attention, no fixed point, one hop)
-    drop, cap = {"quantized": (0.2, 0.75), "approximate": (0.1, 0.95), "normal": (0.2, 0.75)}[mode_name]
-    assert err[-1] < err[0] - drop, (err[0], err[-1])
+    assert all(np.isfinite(e) and 0.0 <= e <= 1.0 for e in err), err[:5]
+    if drop is not None:
+        assert err[-1] < err[0] - drop, (err[0], err[-1])
     res = (tmp_path / "result.csv").read_text().strip().split(",")
     err_test = float(res[10])
-    assert 0.0 <= err_test < cap, err_test                      # chance is 5 of 6 wrong
+    assert 0.0 <= err_test <= cap, err_test                     # chance is 5 of 6 wrong
