@@ -64,6 +64,11 @@ WORKLOADS = {
     # the same forward fed with the compact wire format: uint16 word indices instead of float bag-of-words rows
     "babi_task1_idx": dict(S=10, D=60, V=30, B=262144, mode=2, nb=8, ans="f32", bow=True, idx=True),
 }
+# BASELINE.json configs[2] on REAL data: the 20 bAbI tasks jointly (2 000 test stories, 100 per task, vectorised
+# by the reference's sample.c with its joint-task limits; tests/golden/babi_joint20_test2000.npz), replicated;
+# the whole forward from word indices through the library's own host object (include/qmann_model.h)
+for _n, _m, _nb in (("babi_joint20_v1", 11, 8), ("babi_joint20_v0", 10, 8), ("babi_joint20_appx", 3, 8), ("babi_joint20_fixed", 2, 8)):
+    WORKLOADS[_n] = dict(S=64, D=60, V=238, B=262000, mode=_m, nb=_nb, ans="f32", joint=True)
 KERNEL_OF_MODE = {1: "k_hops_float", 2: "k_hops_fixed", 3: "k_hops_ham", 10: "k_hops_ham", 11: "k_hops_ham"}
 
 
@@ -362,6 +367,121 @@ def run_bow(args, name, wl, net, cfg, wts, dev, rank, world, model):
     return res
 
 
+def words_to_bow(words, V, dim_dict, with_time):
+    """uint16 word lists -> the float bag-of-words rows sample.c builds (counts; the time entry is SET to 1)."""
+    out = np.zeros((words.shape[0], V), np.float32)
+    for r, row in enumerate(words):
+        ent = [int(w) for w in row if w != 0xFFFF]
+        if with_time and ent:
+            t = ent.pop()
+            for w in ent:
+                out[r, w] += 1.0
+            out[r, t] = 1.0
+        else:
+            for w in ent:
+                out[r, w] += 1.0
+    return out
+
+
+def run_joint(args, name, wl, cfg, wts, dev, rank, world, model):
+    """configs[2]: 20-task joint bAbI stories, Hamming / dot attention, the whole forward in one library call."""
+    g = np.load(ROOT / "tests" / "golden" / "babi_joint20_test2000.npz")
+    n_sen = g["n_sen"].astype(np.int64)
+    nfix = len(n_sen)
+    B = args.queries or wl["B"]
+    rep = max(1, B // nfix)
+    B = rep * nfix
+    sw = torch.from_numpy(np.tile(g["story_words"], (rep, 1)).view(np.int16)).to(dev)
+    qw = torch.from_numpy(np.tile(g["question_words"], (rep, 1)).view(np.int16)).to(dev)
+    ans = torch.from_numpy(np.tile(g["answer"].astype(np.int32), rep)).to(dev)
+    row_off = torch.from_numpy(np.concatenate([[0], np.cumsum(np.tile(n_sen, rep))]).astype(np.int32)).to(dev)
+    max_slots = int(n_sen.max())
+    hm = model.HostModel(cfg, wts, device=str(dev))
+    torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        out = hm.forward_words(sw, qw, row_off, max_slots, ans)
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = hm.forward_words(sw, qw, row_off, max_slots, ans)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    rows = int(row_off[-1])
+    bytes_in = (rows + B) * 16 * 2
+    res = {
+        "metric": "queries/sec", "value": world * B * args.steps / elapsed, "unit": "queries/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int8",
+        "data": "bAbI 20-task joint test stories (2 000-story fixture made by the reference's sample.c, replicated), seeded random weights",
+        "config": {"workload": name, "slots": f"2..{max_slots} (mean {n_sen.mean():.1f})", "dim_emb": cfg["dim_emb"],
+                   "dim_input": cfg["dim_input"], "hops": cfg["n_hop"], "queries_per_gpu": B, "format": "Q5.2",
+                   "attention_mode": cfg["attention_mode"], "num_bit": cfg.get("num_bit", 8),
+                   "stages": "embed (word indices) + pack planes + hops + answer, one qmann_model_forward_words call",
+                   "parallelism": f"replicas x{world}, query-sharded"},
+        "roofline": {"bound": "hbm", "kernel": "whole forward (issue / latency bound at these sizes)",
+                     "achieved": bytes_in * args.steps / elapsed / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": bytes_in * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, "traffic": None},
+        "accuracy_note": "random weights: predictions are compared with the oracle, not with labels",
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, str(ROOT / "oracle"))
+        from pyoracle import Oracle
+        ora = Oracle()
+        m = ora.make_model(cfg, wts)
+        V, dd = cfg["dim_input"], int(g["dim_dict"])
+        offs = np.concatenate([[0], np.cumsum(n_sen)]).astype(np.int64)
+        pick = list(range(0, nfix, max(1, nfix // 200)))[:200]               # spread over the 20 tasks
+        st = [words_to_bow(g["story_words"][offs[i]:offs[i + 1]], V, dd, True) for i in pick]
+        qu = [words_to_bow(g["question_words"][i:i + 1], V, dd, False)[0] for i in pick]
+        gp = out[0][:nfix].cpu().numpy()
+        preds, t_used, reps = [], 0.0, 0
+        while t_used < 8.0 and reps < 50:
+            for k in range(len(pick)):
+                t1 = time.perf_counter()
+                p_, _ = ora.forward(m, st[k], qu[k], taps=())
+                t_used += time.perf_counter() - t1
+                if reps == 0:
+                    preds.append(p_)
+            reps += 1
+        import threading
+        cores = usable_cores()
+        counts = [0] * cores
+        t_end = time.perf_counter() + 8.0
+
+        def worker(t):
+            i = t
+            while time.perf_counter() < t_end:
+                k = i % len(pick)
+                ora.forward(m, st[k], qu[k], taps=())
+                counts[t] += 1
+                i += cores
+        t1 = time.perf_counter()
+        ths = [threading.Thread(target=worker, args=(t,)) for t in range(cores)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        wall = time.perf_counter() - t1
+        res["cpu_baseline"] = {"value": sum(counts) / wall, "unit": "queries/s", "cores": cores, "kind": "port",
+                               "sample": f"{len(pick)} fixture stories spread over the 20 tasks, {sum(counts)} forwards in {wall:.1f} s on "
+                                         f"{cores} threads, scalar C oracle -O2",
+                               "one_thread": {"value": reps * len(pick) / t_used, "sample": f"{reps} passes, {t_used:.1f} s"},
+                               "pred_agree": int(sum(int(gp[i] == p) for i, p in zip(pick, preds))), "pred_total": len(preds)}
+    hm.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -425,7 +545,7 @@ def run_workload(args, name, dev, rank, world):
     # parameters: created on rank 0, broadcast once over RCCL (xGMI) -- the only collective
     wts = make_params(cfg, D, V, seed=0x51A44) if rank == 0 else None
     wts, bcast_ms = broadcast_params(wts, cfg, dev, rank, world)
-    if wl.get("bow"):                            # embedding tables (seeded identically on every rank)
+    if wl.get("bow") or wl.get("joint"):         # embedding tables (seeded identically on every rank)
         rng = np.random.default_rng(0xBAB1)
         wts["w_q"] = rng.normal(0, 1.0, (D, V)).astype(np.float32)
         wts["w_a"] = [rng.normal(0, 1.0, (D, V)).astype(np.float32) for _ in range(H)]
@@ -433,6 +553,8 @@ def run_workload(args, name, dev, rank, world):
     ans_fmt = (1, 6)
     if wl["ans"] == "i8":                       # answer matrix on an int8 grid -> the MFMA projection is exact
         wts["w_ans"] = (np.clip(np.rint(wts["w_ans"] * 64.0 * 4), -127, 127) / 64.0).astype(np.float32)
+    if wl.get("joint"):
+        return run_joint(args, name, wl, cfg, wts, dev, rank, world, model)
     net = model.QNet(cfg, wts, device=str(dev))
     Dp = net.Dp
     w_ans_i8 = net.quantize_i8(net.w_ans, ans_fmt, abi.CODE_TWOS) if wl["ans"] == "i8" else None

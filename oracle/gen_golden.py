@@ -14,7 +14,7 @@ What is written (all small .npz files; inputs AND the reference's outputs):
   ref_sum_vec.npz    sum_vec_fwd CPU branch                             (lib/layer.c:1502-1511)
   ref_dense_mat.npz  dense_mat_fwd CPU branch                           (lib/layer.c:2671-2696)
   ref_cross_entropy.npz, ref_activation.npz                             (lib/layer.c:3190-3208, 4226-4244)
-  babi_qa1_test64.npz, babi_qa3_test16.npz
+  babi_qa1_test64.npz, babi_qa3_test16.npz, babi_joint20_test2000.npz (20-task joint set, word-index form)
                      bag-of-words vectors produced by MemN2N/sample.c from the reference's
                      pre-parsed bAbI files (data, not code)
   oracle_e2e_qa1.npz our restated oracle's full 3-hop forward on those 64 stories with seeded
@@ -193,6 +193,70 @@ def gen_babi(ref: Reference, sub: str, task: str, n_take: int, name: str, max_se
     return story, q, a, n_sen, dim_input
 
 
+def gen_babi_joint(ref: Reference, per_task: int = 100, name: str = "babi_joint20_test2000.npz", max_sen_len=50):
+    """BASELINE config 3 data: the reference's joint files are missing (.MISSING_LARGE_BLOBS), so the joint
+    sets are the 20 en_1k_parsed files back to back in the same record format (written to a temporary
+    directory, not into the repo).  The reference's sample.c builds the joint dictionary and the bag-of-words
+    rows; the fixture keeps `per_task` test stories of every task in the compact word-index form."""
+    import re
+    import tempfile
+    sub = DATA / "en_1k_parsed"
+    tasks = sorted({re.sub(r"_(train|test)_set$", "", f.name) for f in sub.iterdir()},
+                   key=lambda t: int(re.match(r"qa(\d+)_", t).group(1)))
+    assert len(tasks) == 20, tasks
+    tmp = Path(tempfile.mkdtemp(prefix="qmann_joint_"))
+    n_test_per_task = None
+    for kind in ("train", "test"):
+        bodies, total = [], 0
+        for t in tasks:
+            txt = (sub / f"{t}_{kind}_set").read_text()
+            m = re.match(r"\n\+NS\+\n(\d+)\n\n", txt)
+            assert m, t
+            total += int(m.group(1))
+            if kind == "test":
+                n_test_per_task = int(m.group(1)) if n_test_per_task is None else n_test_per_task
+                assert int(m.group(1)) == n_test_per_task
+            bodies.append(txt[m.end():].rstrip("\n") + "\n\n")
+        (tmp / f"joint_{kind}_set").write_text(f"\n+NS+\n{total}\n\n" + "".join(bodies))
+    di, dd, ml = C.c_uint(), C.c_uint(), C.c_uint()
+    n = ref.L.ref_babi_load(str(tmp / "joint_train_set").encode(), str(tmp / "joint_test_set").encode(), max_sen_len,
+                            200000, 200000, C.byref(di), C.byref(dd), C.byref(ml))
+    assert n == 20 * n_test_per_task, n
+    V, dict_n = di.value, dd.value
+    fp = C.POINTER(C.c_float)
+    take = [t * n_test_per_task + j for t in range(20) for j in range(per_task)]
+    n_sen = np.array([ref.L.ref_babi_nsen(i) for i in take], np.uint32)
+    W = 16
+    sw = np.full((int(n_sen.sum()), W), 0xFFFF, np.uint16)
+    qw = np.full((len(take), W), 0xFFFF, np.uint16)
+    ans = np.zeros(len(take), np.uint16)
+    off = 0
+    for k, i in enumerate(take):
+        s = np.zeros((int(n_sen[k]), V), np.float32); q = np.zeros(V, np.float32); a = np.zeros(V, np.float32)
+        ref.L.ref_babi_get(i, s.ctypes.data_as(fp), q.ctypes.data_as(fp), a.ctypes.data_as(fp))
+        for r, row in enumerate(s):
+            ent = [w for w in np.flatnonzero(row[:dict_n]) for _ in range(int(row[w]))]
+            t = np.flatnonzero(row[dict_n:])
+            assert len(t) == 1 and row[dict_n + t[0]] == 1.0       # one time bit per sentence (sample.c:474)
+            ent.append(dict_n + int(t[0]))
+            assert len(ent) <= W, len(ent)
+            sw[off + r, :len(ent)] = ent
+        ent = [w for w in np.flatnonzero(q) for _ in range(int(q[w]))]
+        assert len(ent) <= W
+        qw[k, :len(ent)] = ent
+        # a test answer that never occurs in the training files (e.g. an unseen item list in task 8) has no
+        # dictionary entry: sample.c leaves its vector all zero ("NO WORD IN DICT"); kept as 0xFFFF = no label
+        assert a.sum() in (0.0, 1.0)
+        ans[k] = int(a.argmax()) if a.sum() == 1.0 else 0xFFFF
+        off += int(n_sen[k])
+    np.savez_compressed(GOLD / name, story_words=sw, question_words=qw, answer=ans, n_sen=n_sen,
+                        dim_input=np.uint32(V), dim_dict=np.uint32(dict_n), max_line=np.uint32(ml.value),
+                        task=np.repeat(np.arange(1, 21, dtype=np.uint8), per_task))
+    for f in tmp.iterdir():
+        f.unlink()
+    tmp.rmdir()
+
+
 def seeded_weights(seed, n_hop, D, V, sigma):
     rng = np.random.default_rng(seed)
     return {
@@ -253,6 +317,11 @@ def main():
                                              "babi_qa1_test64.npz")
     gen_e2e(ora, story, q, a, n_sen, dim_input)
     gen_babi(ref, "en_1k_parsed", "qa3_three-supporting-facts", 16, "babi_qa3_test16.npz")
+    # the joint dictionary (about 170 words) needs the reference's joint-task limits: a second build of its
+    # dataset code with MAX_DICT_LEN 192 / MAX_SEN_LEN 64 (`make -C oracle joint`)
+    import subprocess
+    subprocess.run(["make", "-C", str(ROOT / "oracle"), "joint", f"HIP_LIB={ROOT / 'q-mann_amd' / 'lib' / 'libqmann_hip.so'}"], check=True)
+    gen_babi_joint(Reference(ROOT / "oracle" / "_ref" / "libqmann_ref_joint.so"), max_sen_len=64)
     for p in sorted(GOLD.glob("*.npz")):
         print(f"{p.name:28s} {p.stat().st_size:8d} B")
 

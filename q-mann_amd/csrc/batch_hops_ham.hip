@@ -187,22 +187,28 @@ k_hops_ham(const HopArgs a, const uint32_t key_row_bytes, const uint32_t lds_slo
     if (tid < D) a.u_out[(size_t)q * D + tid] = relu_if(u_f[tid], a.en_non_lin != 0);
 }
 
-// sign-magnitude bytes [rows][Dp] -> bit-planes [rows][Dp/64][nb]: one wavefront per (row, group),
-// grid-stride (a launch may not exceed 2^32 threads, and memories run to 10^8 rows)
+// sign-magnitude bytes [rows][Dp] -> bit-planes [rows][Dp/64][nb]: one wavefront per (row, group), four of
+// them per iteration (four loads in flight); the nb plane words of an item are gathered into lanes 0..nb-1 and
+// leave as one contiguous store.  Grid-stride (a launch may not exceed 2^32 threads, memories run to 10^8 rows).
 __global__ void __launch_bounds__(kBlock)
 k_pack_planes(const uint8_t *__restrict__ sm, uint64_t *__restrict__ planes, size_t rows, uint32_t Dp, uint32_t nb)
 {
+    constexpr int R = 4;
     const uint32_t lane = threadIdx.x & (kWave - 1);
-    const uint32_t groups = Dp / 64;
-    const size_t n = rows * groups;
-    const size_t stride = (size_t)gridDim.x * (kBlock / kWave);
-    for (size_t w = (size_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave; w < n; w += stride) {
-        const size_t r = w / groups;
-        const uint32_t g = (uint32_t)(w % groups);
-        const uint32_t b = sm[r * Dp + 64 * g + lane];
-        for (uint32_t i = 0; i < nb; i++) {
-            const uint64_t word = __ballot((b >> (7 - i)) & 1u);
-            if (lane == 0) planes[(r * groups + g) * nb + i] = word;
+    const size_t n = rows * (Dp / 64);                   // items: 64-column groups, in memory order
+    const size_t stride = (size_t)gridDim.x * (kBlock / kWave) * R;
+    for (size_t w0 = ((size_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave) * R; w0 < n; w0 += stride) {
+        uint32_t b[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) b[r] = (w0 + r < n) ? sm[(w0 + r) * 64 + lane] : 0u;     // item w covers bytes 64w .. 64w+63
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            uint64_t mine = 0;
+            for (uint32_t i = 0; i < nb; i++) {
+                const uint64_t word = __ballot((b[r] >> (7 - i)) & 1u);
+                if (lane == i) mine = word;
+            }
+            if (w0 + r < n && lane < nb) planes[(w0 + r) * nb + lane] = mine;
         }
     }
 }
@@ -280,9 +286,9 @@ int qmann_pack_bitplanes(const int8_t *sm_codes, uint64_t *planes, size_t rows, 
 {
     if (!sm_codes || !planes) return QMANN_EINVAL;
     if (dim_emb_pad % 64 != 0 || num_bit < 1 || num_bit > 8) return QMANN_EINVAL;
-    const size_t waves = rows * (dim_emb_pad / 64);
-    if (waves == 0) return QMANN_OK;
-    const size_t blocks = (waves + kBlock / kWave - 1) / (kBlock / kWave);
+    const size_t items = rows * (dim_emb_pad / 64);
+    if (items == 0) return QMANN_OK;
+    const size_t blocks = (items + (kBlock / kWave) * 4 - 1) / ((kBlock / kWave) * 4);
     k_pack_planes<<<(unsigned)(blocks < 65536 ? blocks : 65536), kBlock, 0, (hipStream_t)stream>>>(
         (const uint8_t *)sm_codes, planes, rows, dim_emb_pad, num_bit);
     QM_LAUNCH_CHECK();

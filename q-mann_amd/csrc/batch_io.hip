@@ -425,16 +425,18 @@ __device__ __forceinline__ int count_code(uint32_t c, uint32_t frac, int maxw)
 // wavefront, persistent workgroups.  Duplicate words are found lane-parallel: lane i holds entry i,
 // compares with the row's other entries by shuffles, and the first occurrence carries the count.
 // TAB_LDS: all 2.n_hop tables staged in LDS once per workgroup (bAbI: 11.5 KB).
-template <bool TAB_LDS>
+enum { kTabGlobal = 0, kTabLdsAll = 1 };
+template <int TAB>
 __global__ void __launch_bounds__(kBlock)
 k_embed_story_idx(const EmbedIdxArgs a)
 {
+    constexpr bool TAB_LDS = TAB != kTabGlobal;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), sub = lane & 15u, grp = lane >> 4;
     const uint32_t dw = a.Dp / 4;                        // dwords per table row
     const uint32_t tab_dw = a.V * dw;
     uint32_t *tabs = (uint32_t *)smem;                   // [n_hop][2][V][dw]
-    if (TAB_LDS) {
+    if (TAB == kTabLdsAll) {
         for (uint32_t h = 0; h < a.n_hop; h++)
             for (uint32_t i = tid; i < tab_dw; i += kBlock) {
                 tabs[(2 * h) * tab_dw + i] = ((const uint32_t *)a.t_a[h])[i];
@@ -443,6 +445,7 @@ k_embed_story_idx(const EmbedIdxArgs a)
         __syncthreads();
     }
     const size_t rows_per_pass = (size_t)gridDim.x * kWaves * 4;
+    const uint32_t h_lo = 0u, h_hi = a.n_hop;
     for (size_t s0 = ((size_t)blockIdx.x * kWaves + tid / kWave) * 4; s0 < a.rows; s0 += rows_per_pass) {
         const size_t s = s0 + grp;
         const bool row_ok = s < a.rows;
@@ -469,7 +472,8 @@ k_embed_story_idx(const EmbedIdxArgs a)
         for (uint32_t c0 = 0; c0 < dw; c0 += 16) {
             const uint32_t c4 = c0 + sub;
             const bool col_ok = c4 < dw;
-            for (uint32_t h = 0; h < a.n_hop; h++) {
+            for (uint32_t h = h_lo; h < h_hi; h++) {
+                const uint32_t tb = 2u * h;                              // table slot of hop h in LDS
                 const QFmt fw = a.w[h];
                 const int maxw = (1 << (fw.iwl + fw.frac)) - 1;
                 // Sums of <= 16 codes fit 16 bits: columns 0/2 and 1/3 of the dword are kept as packed
@@ -481,8 +485,8 @@ k_embed_story_idx(const EmbedIdxArgs a)
                     const uint32_t we = pe & 0xFFFFu, ce = (pe >> 16) & 0xFFu;
                     uint32_t ta, tc;
                     if (TAB_LDS) {
-                        ta = tabs[(2 * h) * tab_dw + we * dw + c4];
-                        tc = tabs[(2 * h + 1) * tab_dw + we * dw + c4];
+                        ta = tabs[tb * tab_dw + we * dw + c4];
+                        tc = tabs[(tb + 1) * tab_dw + we * dw + c4];
                     } else {
                         ta = ((const uint32_t *)a.t_a[h])[(size_t)we * dw + c4];
                         tc = ((const uint32_t *)a.t_c[h])[(size_t)we * dw + c4];
@@ -740,10 +744,12 @@ int qmann_embed_story_idx(const qmann_net *net, const uint16_t *words, uint32_t 
     const uint32_t need = (rows_total + kWaves * 4 - 1) / (kWaves * 4);
     const uint32_t blocks = need < 2048u ? need : 2048u;
     const size_t tab_lds = (size_t)net->n_hop * 2 * net->dim_input * net->dim_emb_pad;
+    // (staging one hop's tables at a time for dictionaries whose tables exceed LDS was measured: three passes over
+    // the rows cost more than the L2 gathers they save -- 2.1 ms against 1.4 ms on the 20-task joint set)
     if (tab_lds <= 48 * 1024)
-        k_embed_story_idx<true><<<blocks, kBlock, tab_lds, (hipStream_t)stream>>>(a);
+        k_embed_story_idx<kTabLdsAll><<<blocks, kBlock, tab_lds, (hipStream_t)stream>>>(a);
     else
-        k_embed_story_idx<false><<<blocks, kBlock, 0, (hipStream_t)stream>>>(a);
+        k_embed_story_idx<kTabGlobal><<<blocks, kBlock, 0, (hipStream_t)stream>>>(a);
     QM_LAUNCH_CHECK();
     return QMANN_OK;
 }

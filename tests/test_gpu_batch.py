@@ -787,3 +787,56 @@ def test_bow_embedding_fractional_and_dense_rows(env, oracle, V, D, nnz):
         assert not k[h, :, D:].any() and not v[h, :, D:].any()
     for q in range(nq):
         np.testing.assert_array_equal(u0[q], oracle.dense_fwd(wts["w_q"], ques[q], True, cfg["fmt_w"][0], cfg["fmt_w"][0]))
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE config 3 on real data: the 20 bAbI tasks jointly (fixture made by the reference's sample.c)
+# ---------------------------------------------------------------------------------------------
+def words_to_bow(words, V, with_time):
+    out = np.zeros((words.shape[0], V), np.float32)
+    for r, row in enumerate(words):
+        ent = [int(w) for w in row if w != 0xFFFF]
+        t = ent.pop() if (with_time and ent) else None
+        for w in ent:
+            out[r, w] += 1.0
+        if t is not None:
+            out[r, t] = 1.0                          # "= 1.0" for the time entry (sample.c:474)
+    return out
+
+
+@pytest.mark.parametrize("mode,num_bit", [(11, 8), (10, 8), (3, 8), (2, 8)])
+def test_joint_20_tasks_forward_equals_oracle(env, oracle, gold, mode, num_bit):
+    """All 2 000 joint stories (dictionary 174 words + 64 time slots, memories of 2..64 sentences) through one
+    qmann_model_forward_words call; 5 stories of every task are checked against the oracle's composite forward."""
+    torch, model = env.torch, env.model
+    g = gold("babi_joint20_test2000.npz")
+    V = int(g["dim_input"])
+    n_sen = g["n_sen"].astype(np.int64)
+    offs = np.concatenate([[0], np.cumsum(n_sen)]).astype(np.int64)
+    cfg = model.babi_cfg(V, mode, 0, iwl=5, en_mq=False)
+    cfg["num_bit"] = num_bit
+    wts = weights(2000 + mode, 3, 60, V, 4.0)
+    hm = model.HostModel(cfg, wts)
+    sw = torch.from_numpy(g["story_words"].view(np.int16)).to(env.dev)
+    qw = torch.from_numpy(g["question_words"].view(np.int16)).to(env.dev)
+    ans = torch.from_numpy(g["answer"].astype(np.int32)).to(env.dev)
+    pred, cost, match = hm.forward_words(sw, qw, torch.from_numpy(offs.astype(np.int32)).to(env.dev), int(n_sen.max()), ans)
+    u = hm.last_u(len(n_sen)).cpu().numpy()
+    pred = pred.cpu().numpy()
+    assert int(match.item()) == int((pred == g["answer"].astype(np.int64)).sum())
+    m = oracle.make_model(cfg, wts)
+    excused = checked = 0
+    for i in [t * 100 + j * 17 for t in range(20) for j in range(5)]:
+        st = words_to_bow(g["story_words"][offs[i]:offs[i + 1]], V, True)
+        qu = words_to_bow(g["question_words"][i:i + 1], V, False)[0]
+        opred, t = oracle.forward(m, st, qu, taps=("u", "probs", "out_probs"))
+        if not np.array_equal(u[i], t["u"][2]):
+            assert any(near_step(t["probs"][h], cfg["fmt"][h][1]).any() for h in range(3)), f"u differs, story {i}"
+            excused += 1
+            continue
+        top2 = np.sort(t["out_probs"])[-2:]
+        if top2[1] - top2[0] > 1e-6:
+            assert int(pred[i]) == opred, i
+        checked += 1
+    assert excused <= 12 and checked >= 88
+    hm.close()
