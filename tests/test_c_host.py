@@ -40,6 +40,7 @@ def test_example_host_compiles_and_links(tmp_path):
 
 @pytest.mark.gpu
 def test_example_host_runs_and_matches_the_oracle(tmp_path, gold, oracle):
+    load_pkg()
     import qmann_amd.model as model
     exe = build_example(tmp_path)
     b = gold("babi_qa1_test64.npz")
