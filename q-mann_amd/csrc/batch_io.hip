@@ -113,50 +113,54 @@ k_answer(const float *__restrict__ w_ans, const float *__restrict__ u, const uin
 }
 
 // Answer layer for small dictionaries (V <= 256: bAbI single-task and joint sizes): one WAVEFRONT per
-// query, lane l owns logits l, l + 64, ... (VPT of them) -- the same arithmetic as k_answer without
-// block barriers; W is staged transposed in LDS once per (persistent) workgroup.
+// query, lane l owns the VPT adjacent logits VPT.l .. VPT.l + VPT - 1 -- the same arithmetic as k_answer
+// without block barriers; W is staged transposed in LDS once per (persistent) workgroup, so a lane reads
+// its VPT weights of an embedding column with one 4.VPT-byte LDS load and the products / sums go through
+// the packed fp32 pipeline.
+// 16 wavefronts per workgroup share one copy of W^T (up to 61 KB): 2 workgroups fill a CU's 32 wavefront slots
+constexpr int kAnsBlock = 1024, kAnsWaves = kAnsBlock / kWave;
 template <int VPT>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kAnsBlock)
 k_answer_small(const float *__restrict__ w_ans, const float *__restrict__ u, const uint32_t *__restrict__ answer,
                uint32_t *__restrict__ pred, float *__restrict__ probs, float *cost, uint32_t *match, uint32_t D,
                uint32_t V, uint32_t softmax_base, uint32_t n_query)
 {
+    typedef float fvec __attribute__((ext_vector_type(VPT)));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr uint32_t VP = 64 * VPT;                   // logits padded to whole wavefronts (zero columns)
-    float *wt = (float *)smem;                          // [D][VP]: W transposed, lanes read consecutive words
-    float *us = wt + (size_t)D * VP + (threadIdx.x / kWave) * D;     // [kWaves][D]: this wavefront's query
+    float *wt = (float *)smem;                          // [D][VP]: W transposed
+    float *us = wt + (size_t)D * VP + (threadIdx.x / kWave) * D;     // [kAnsWaves][D]: this wavefront's query
     const uint32_t lane = threadIdx.x & (kWave - 1);
-    const size_t stride = (size_t)gridDim.x * kWaves;
-    for (uint32_t i = threadIdx.x; i < D * VP; i += kBlock) {
+    const size_t stride = (size_t)gridDim.x * kAnsWaves;
+    for (uint32_t i = threadIdx.x; i < D * VP; i += kAnsBlock) {
         const uint32_t c = i / VP, v = i % VP;
         wt[i] = v < V ? w_ans[(size_t)v * D + c] : 0.0f;
     }
     __syncthreads();
     const SmCfg smc{softmax_base, false, false, 1.0f};  // sf_out is never shift-based (MemN2N.c:910)
+    const uint32_t v0 = lane * VPT;                     // first logit of this lane
     bool live[VPT];
 #pragma unroll
-    for (int k = 0; k < VPT; k++) live[k] = lane + 64u * k < V;
+    for (int k = 0; k < VPT; k++) live[k] = v0 + k < V;
     // cost / match are summed per wavefront and added once: one device-scope atomic per query on a
     // single word would serialise the whole batch (~12 ns each)
     float cost_acc = 0.0f;
     uint32_t match_acc = 0;
-    for (size_t q = (size_t)blockIdx.x * kWaves + threadIdx.x / kWave; q < n_query; q += stride) {
+    for (size_t q = (size_t)blockIdx.x * kAnsWaves + threadIdx.x / kWave; q < n_query; q += stride) {
         for (uint32_t c = lane; c < D; c += kWave) us[c] = u[q * D + c];
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        float sum[VPT];
-#pragma unroll
-        for (int k = 0; k < VPT; k++) sum[k] = 0.0f;
+        fvec acc = 0.0f;
 #pragma unroll 4
         for (uint32_t c = 0; c < D; c++) {               // serial over the embedding axis, as the reference sums
-            const float uc = us[c];
-#pragma unroll
-            for (int k = 0; k < VPT; k++) {
-                const float t = wt[c * VP + lane + 64 * k] * uc;
-                sum[k] += t;
-            }
+            const fvec w = *(const fvec *)(wt + c * VP + v0);
+            const fvec t = w * us[c];
+            acc += t;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // reads of us[] done before the next query overwrites it
+        float sum[VPT];
+#pragma unroll
+        for (int k = 0; k < VPT; k++) sum[k] = acc[k];
         float mx = -INFINITY;
 #pragma unroll
         for (int k = 0; k < VPT; k++) mx = (live[k] && sum[k] > mx) ? sum[k] : mx;
@@ -181,8 +185,8 @@ k_answer_small(const float *__restrict__ w_ans, const float *__restrict__ u, con
         for (int k = 0; k < VPT; k++) {
             p[k] = (softmax_base == QMANN_SOFTMAX_EXP) ? (float)((double)e[k] / total) : e[k] / (float)total;
             if (live[k]) {
-                if (probs) probs[q * V + lane + 64 * k] = p[k];
-                if (!(bv > p[k])) { bv = p[k]; bi = lane + 64 * k; }         // later index wins a tie
+                if (probs) probs[q * V + v0 + k] = p[k];
+                if (!(bv > p[k])) { bv = p[k]; bi = v0 + k; }               // later index wins a tie
             }
         }
 #pragma unroll
@@ -197,7 +201,7 @@ k_answer_small(const float *__restrict__ w_ans, const float *__restrict__ u, con
             if (y < V) {
                 float py = 0.0f;
 #pragma unroll
-                for (int k = 0; k < VPT; k++) py = (y / 64u == (uint32_t)k) ? __shfl(p[k], (int)(y % 64u)) : py;
+                for (int k = 0; k < VPT; k++) py = (y % VPT == (uint32_t)k) ? __shfl(p[k], (int)(y / VPT)) : py;
                 cost_acc += -py;
                 match_acc += (y == bi) ? 1u : 0u;
             }
@@ -621,17 +625,14 @@ int qmann_answer_f32(const qmann_net *net, const float *w_ans, const float *u, c
     if (lds > 48 * 1024)
         QM_HIP(hipFuncSetAttribute((const void *)k_answer<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint32_t v_pad = V <= 64 ? 64u : (V <= 128 ? 128u : 256u);
-    const size_t lds_small = ((size_t)D * v_pad + (size_t)kWaves * D) * sizeof(float);
+    const size_t lds_small = ((size_t)D * v_pad + (size_t)kAnsWaves * D) * sizeof(float);
     if (V <= 4u * kWave && lds_small <= 64 * 1024) {        // W^T fits LDS: one wavefront per query
-        const uint32_t need = (n_query + kWaves - 1) / kWaves;
-        // persistent workgroups: as many as the chip holds at this LDS size
-        const uint32_t per_cu = (uint32_t)(160 * 1024 / (lds_small + 512));
-        const uint32_t cap = 256u * (per_cu < 1 ? 1u : (per_cu > 8 ? 8u : per_cu));
-        const uint32_t blocks = need < cap ? need : cap;
+        const uint32_t need = (n_query + kAnsWaves - 1) / kAnsWaves;
+        const uint32_t blocks = need < 512u ? need : 512u;  // persistent: two 16-wavefront workgroups per CU
         hipStream_t st = (hipStream_t)stream;
-        if (V <= 64) k_answer_small<1><<<blocks, kBlock, lds_small, st>>>(w_ans, u, answer, pred, probs, cost, match, D, V, net->softmax_base, n_query);
-        else if (V <= 128) k_answer_small<2><<<blocks, kBlock, lds_small, st>>>(w_ans, u, answer, pred, probs, cost, match, D, V, net->softmax_base, n_query);
-        else k_answer_small<4><<<blocks, kBlock, lds_small, st>>>(w_ans, u, answer, pred, probs, cost, match, D, V, net->softmax_base, n_query);
+        if (V <= 64) k_answer_small<1><<<blocks, kAnsBlock, lds_small, st>>>(w_ans, u, answer, pred, probs, cost, match, D, V, net->softmax_base, n_query);
+        else if (V <= 128) k_answer_small<2><<<blocks, kAnsBlock, lds_small, st>>>(w_ans, u, answer, pred, probs, cost, match, D, V, net->softmax_base, n_query);
+        else k_answer_small<4><<<blocks, kAnsBlock, lds_small, st>>>(w_ans, u, answer, pred, probs, cost, match, D, V, net->softmax_base, n_query);
         QM_LAUNCH_CHECK();
         return QMANN_OK;
     }
