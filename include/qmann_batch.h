@@ -110,7 +110,10 @@ int qmann_quantize_i8(const float *src, int8_t *dst, size_t rows, uint32_t cols,
  * attention_mode QMANN_ATT_FIXED (define.h mode 2), QMANN_ATT_APPX (mode 3; needs att formats with
  * iwl + frac = 7 and u grids no finer / wider than the attention grid, else QMANN_EUNSUPPORTED) or
  * QMANN_ATT_FLOAT (mode 1: float scores / softmax / read-out over the same int8 memories, which
- * then carry Q(w[h]) codes -- the embedding outputs, not re-quantised). */
+ * then carry Q(w[h]) codes -- the embedding outputs, not re-quantised), or QMANN_ATT_HAMMING_V0 / _V1
+ * computed straight from the int8 keys (the top num_bit bits of a sign-magnitude byte are its bit planes):
+ * same scores as qmann_hops_packed without a packing pass -- the choice for short memories and for
+ * num_bit = 8, where planes are no smaller than bytes. */
 int qmann_hops_i8(const qmann_net *net, const int8_t *keys, const int8_t *vals, size_t hop_stride,
                   const uint32_t *row_off, uint32_t max_slots, const float *u0, float *u_out,
                   const qmann_taps *taps, uint32_t n_query, void *stream);

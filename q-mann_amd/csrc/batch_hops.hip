@@ -178,6 +178,10 @@ int qmann_hops_appx_impl(const qmann_net *net, const int8_t *keys, const int8_t 
                          const uint32_t *row_off, uint32_t max_slots, const float *u0, float *u_out,
                          const qmann_taps *taps, uint32_t n_query, void *stream);   // batch_hops_ham.hip
 
+int qmann_hops_hambytes_impl(const qmann_net *net, const int8_t *keys, const int8_t *vals, size_t hop_stride,
+                             const uint32_t *row_off, uint32_t max_slots, const float *u0, float *u_out,
+                             const qmann_taps *taps, uint32_t n_query, void *stream);   // batch_hops_ham.hip
+
 int qmann_hops_float_impl(const HopArgs &a, uint32_t Dp, uint32_t max_slots, uint32_t n_query, void *stream);  // batch_hops_float.hip
 
 size_t qmann_hops_lds_bytes(uint32_t max_slots)
@@ -210,6 +214,8 @@ int qmann_hops_i8(const qmann_net *net, const int8_t *keys, const int8_t *vals, 
     if (net->dim_emb_pad != 64 && net->dim_emb_pad != 128 && net->dim_emb_pad != 256) return QMANN_EUNSUPPORTED;
     if (net->attention_mode == QMANN_ATT_APPX)
         return qmann_hops_appx_impl(net, keys, vals, hop_stride, row_off, max_slots, u0, u_out, taps, n_query, stream);
+    if (net->attention_mode == QMANN_ATT_HAMMING_V0 || net->attention_mode == QMANN_ATT_HAMMING_V1)
+        return qmann_hops_hambytes_impl(net, keys, vals, hop_stride, row_off, max_slots, u0, u_out, taps, n_query, stream);
     if (net->attention_mode != QMANN_ATT_FIXED && net->attention_mode != QMANN_ATT_FLOAT) return QMANN_EUNSUPPORTED;
     if (net->softmax_base > QMANN_SOFTMAX_EXP_PLAN) return QMANN_EINVAL;
     if (!fmt8(net->bin) && net->bin.iwl + net->bin.frac != 0) return QMANN_ERANGE;     // (0,0) = BINARY_MODE: u binarised

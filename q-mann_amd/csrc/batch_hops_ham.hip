@@ -74,7 +74,7 @@ k_hops_ham(const HopArgs a, const uint32_t key_row_bytes, const uint32_t lds_slo
         const int kc = (tid < D) ? qm_code(ua, fm.iwl, fm.frac) : 0;
         const uint32_t ubyte = (uint32_t)(kc < 0 ? -kc : kc) | ((tid < D && !(ua >= 0.0f)) ? 0x80u : 0u);
         ub[tid] = (uint8_t)ubyte;
-        if (MODE != kModeAppx) {
+        if (mode_is_planes(MODE)) {
 #pragma unroll
             for (int i = 0; i < NB; i++) {
                 const uint64_t word = __ballot((ubyte >> (7 - i)) & 1u);
@@ -82,7 +82,7 @@ k_hops_ham(const HopArgs a, const uint32_t key_row_bytes, const uint32_t lds_slo
             }
         }
         if (tid == 0) misc[0] = 0u;
-        if (MODE == kModeV0)
+        if (mode_is_v0(MODE))
             for (uint32_t d = tid; d < nbins; d += kBlock) v0_hist[d] = 0u;
         __syncthreads();
 
@@ -91,7 +91,7 @@ k_hops_ham(const HopArgs a, const uint32_t key_row_bytes, const uint32_t lds_slo
             const uint8_t *kb = (const uint8_t *)a.keys + (size_t)h * a.key_hop_stride + (size_t)r0 * key_row_bytes;
             auto retire = [&](uint32_t r, int v) {
                 sc[r] = (score_t)v;
-                if (MODE == kModeV0) atomicAdd(&v0_hist[v], 1u);
+                if (mode_is_v0(MODE)) atomicAdd(&v0_hist[v], 1u);
             };
             if (MODE == kModeAppx) {
                 scale = 1.0f / 1024.0f;                         // 2^-(n-1) . 2^ATTENTION_CONST_SCALE, n = 8
@@ -102,11 +102,18 @@ k_hops_ham(const HopArgs a, const uint32_t key_row_bytes, const uint32_t lds_slo
                 auto retire_c = [&](uint32_t r, int v) { sc[r] = v > lim ? lim : (v < -lim ? -lim : v); };
                 if (S >= (kWave / LPRK) * 4) scan_rows<LPRK, 4, true, kWaves>(kb, S, row_sum, retire_c, lane, wave);
                 else scan_rows_short<LPRK>(kb, S, row_sum, retire_c, lane, wave, kWaves);
-            } else {
+            } else if (mode_is_planes(MODE)) {
                 if (MODE == kModeV1) scale = qm_scale_down(1.0f, NB);
                 PlaneConst c;
                 make_plane_const<NB>(c, upl, lane % LPRK, D);
                 auto row_sum = [&](const i32x4 x) { return plane_lane_sum<MODE, NB>(x, c); };
+                if (S >= (kWave / LPRK) * 4) scan_rows<LPRK, 4, true, kWaves>(kb, S, row_sum, retire, lane, wave);
+                else scan_rows_short<LPRK>(kb, S, row_sum, retire, lane, wave, kWaves);
+            } else {
+                if (MODE == kModeV1Bytes) scale = qm_scale_down(1.0f, NB);
+                HamByteConst c;
+                make_hambyte_const<MODE, NB>(c, ub, (lane % LPRK) * 16, D);
+                auto row_sum = [&](const i32x4 x) { return hambyte_lane_sum<MODE, NB>(x, c); };
                 if (S >= (kWave / LPRK) * 4) scan_rows<LPRK, 4, true, kWaves>(kb, S, row_sum, retire, lane, wave);
                 else scan_rows_short<LPRK>(kb, S, row_sum, retire, lane, wave, kWaves);
             }
@@ -115,7 +122,7 @@ k_hops_ham(const HopArgs a, const uint32_t key_row_bytes, const uint32_t lds_slo
 
         // softmax over slots, evaluated per slot (lib/layer_cuda.cu:1895-1916, 1969-2060)
         uint32_t n_live = 0;
-        if (MODE == kModeV0 && S > 0) {
+        if (mode_is_v0(MODE) && S > 0) {
             // one exp per distinct count; normaliser sum_d count[d] . e[d] in double (lib/layer_cuda.cu:2024-2042)
             const SmCfg smc = sm_cfg(a, h);
             float xmax = -INFINITY;
@@ -181,7 +188,7 @@ k_hops_ham(const HopArgs a, const uint32_t key_row_bytes, const uint32_t lds_slo
                 __syncthreads();
             }
         }
-        auto kp_of_row = [&](uint32_t r) { return MODE == kModeV0 ? (int)v0_kp[sc[r]] : (int)sc[r]; };
+        auto kp_of_row = [&](uint32_t r) { return mode_is_v0(MODE) ? (int)v0_kp[sc[r]] : (int)sc[r]; };
         finish_hop<DP>(a, q, h, r0, S, n_live, live_row, live_kp, kp_of_row, ku, u_f, o_f, tid);
     }
     if (tid < D) a.u_out[(size_t)q * D + tid] = relu_if(u_f[tid], a.en_non_lin != 0);
@@ -319,6 +326,41 @@ int qmann_hops_appx_impl(const qmann_net *net, const int8_t *keys, const int8_t 
     if (net->dim_emb_pad == 64) launch<4, 64, kModeAppx, 8>(a, 64, lds, max_slots, n_query, st);
     else if (net->dim_emb_pad == 128) launch<8, 128, kModeAppx, 8>(a, 128, lds, max_slots, n_query, st);
     else launch<16, 256, kModeAppx, 8>(a, 256, lds, max_slots, n_query, st);
+    QM_LAUNCH_CHECK();
+    return QMANN_OK;
+}
+
+// V0 / V1 straight from sign-magnitude int8 keys (called from qmann_hops_i8)
+int qmann_hops_hambytes_impl(const qmann_net *net, const int8_t *keys, const int8_t *vals, size_t hop_stride,
+                             const uint32_t *row_off, uint32_t max_slots, const float *u0, float *u_out,
+                             const qmann_taps *taps, uint32_t n_query, void *stream)
+{
+    const uint32_t nb = net->num_bit, Dp = net->dim_emb_pad;
+    if (nb != 1 && nb != 2 && nb != 4 && nb != 8) return QMANN_EUNSUPPORTED;
+    HopArgs a;
+    const int rc = fill_args(a, net, keys, vals, hop_stride, hop_stride, row_off, u0, u_out, taps);
+    if (rc) return rc;
+    a.max_slots = max_slots;
+    const bool v1 = net->attention_mode == QMANN_ATT_HAMMING_V1;
+    const size_t lds = ham_lds_bytes(max_slots, v1 ? 0u : nb * net->dim_emb + 1u);
+    if (lds > 160 * 1024 - 1024) return QMANN_ERANGE;
+    if (n_query == 0) return QMANN_OK;
+    if (n_query >= (1u << 24)) return QMANN_ERANGE;      // one workgroup per query: a launch holds < 2^32 threads
+    hipStream_t st = (hipStream_t)stream;
+#define QM_HAMB(DP, NB)                                                                                   \
+    do {                                                                                                  \
+        constexpr int L = DP / 16;                                                                        \
+        if (max_slots <= (uint32_t)kWave) {                 /* hops_small.h */                            \
+            if (v1) k_hops_small<L, L, kModeV1Bytes, NB><<<n_query, kWave, 0, st>>>(a, DP);               \
+            else k_hops_small<L, L, kModeV0Bytes, NB><<<n_query, kWave, 0, st>>>(a, DP);                  \
+        } else if (v1) launch<L, DP, kModeV1Bytes, NB>(a, DP, lds, max_slots, n_query, st);               \
+        else launch<L, DP, kModeV0Bytes, NB>(a, DP, lds, max_slots, n_query, st);                         \
+    } while (0)
+#define QM_HAMB_NB(DP)                                                                                    \
+    do { if (nb == 1) QM_HAMB(DP, 1); else if (nb == 2) QM_HAMB(DP, 2); else if (nb == 4) QM_HAMB(DP, 4); else QM_HAMB(DP, 8); } while (0)
+    if (Dp == 64) QM_HAMB_NB(64); else if (Dp == 128) QM_HAMB_NB(128); else QM_HAMB_NB(256);
+#undef QM_HAMB_NB
+#undef QM_HAMB
     QM_LAUNCH_CHECK();
     return QMANN_OK;
 }

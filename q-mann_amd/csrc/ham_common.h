@@ -6,7 +6,12 @@
 
 namespace {
 
-enum { kModeAppx = 0, kModeV0 = 1, kModeV1 = 2 };
+// kModeV0 / kModeV1 read packed bit planes; kModeV0Bytes / kModeV1Bytes compute the same scores straight from
+// the sign-magnitude int8 memories (no packing pass; the choice for short memories and for num_bit = 8, where
+// planes are no smaller than bytes).  3 = kModeFixed (hops_small.h).
+enum { kModeAppx = 0, kModeV0 = 1, kModeV1 = 2, kModeV0Bytes = 4, kModeV1Bytes = 5 };
+constexpr bool mode_is_v0(int m) { return m == kModeV0 || m == kModeV0Bytes; }
+constexpr bool mode_is_planes(int m) { return m == kModeV0 || m == kModeV1; }
 
 // V0 scores are small counts (0 .. num_bit . D <= 2048): the softmax is evaluated once per distinct
 // count through a histogram (as the fixed-point kernel does per code).  The tables (hist u32, p float,
@@ -93,6 +98,52 @@ __device__ __forceinline__ int plane_lane_sum(const i32x4 x, const PlaneConst &c
     return acc;
 }
 
+
+// ---- V0 / V1 on int8 keys ---------------------------------------------------------------------------
+// The top num_bit bits of a sign-magnitude byte ARE planes 0..num_bit-1 of that column, so
+//   V0 = sum over real columns of (n - popcount((k ^ u) & top_n))                      (lib/common.c:223-246)
+//   V1 = sum over real columns of sgn.sgn.( (2^(n-1) - 1) - (((|k| ^ |u|) >> (8 - n)) & (2^(n-1) - 1)) )
+//        in units of 2^-n: the weights 2^(n-1-i) of bits i = 1..n-1 add up to that difference (lib/common.c:249-312)
+struct HamByteConst {
+    uint32_t ub[4];   // sign-magnitude bytes of Q_att(u) for this lane's 16 columns
+    uint32_t m[4];    // V0: top-n-bit mask, V1: low (n-1)-bit mask; 0 in padding columns
+    int bias;         // V0: n . (real columns of this lane)
+};
+template <int MODE, int NB>
+__device__ __forceinline__ void make_hambyte_const(HamByteConst &c, const uint8_t *ub, uint32_t c0, uint32_t D)
+{
+    constexpr uint32_t pat = mode_is_v0(MODE) ? ((0xFF00u >> NB) & 0xFFu) : ((1u << (NB - 1)) - 1u);
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        c.ub[d] = *(const uint32_t *)(ub + c0 + 4 * d);
+        uint32_t vm = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) vm |= (c0 + 4 * d + i < D ? pat : 0u) << (8 * i);
+        c.m[d] = vm;
+    }
+    c.bias = NB * (int)(D >= c0 + 16 ? 16u : (D > c0 ? D - c0 : 0u));
+}
+template <int MODE, int NB>
+__device__ __forceinline__ int hambyte_lane_sum(const i32x4 x, const HamByteConst &c)
+{
+    if (mode_is_v0(MODE)) {
+        uint32_t diff = 0;
+#pragma unroll
+        for (int d = 0; d < 4; d++) diff += (uint32_t)__builtin_popcount(((uint32_t)x[d] ^ c.ub[d]) & c.m[d]);
+        return c.bias - (int)diff;
+    }
+    if (NB == 1) return 0;                          // no magnitude bits compared: every weight is zero
+    int dot = 0;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const uint32_t xo = (uint32_t)x[d] ^ c.ub[d];
+        const uint32_t y = ((xo & 0x7F7F7F7Fu) >> (8 - NB));                // per byte: the compared magnitude bits that differ
+        const uint32_t t = ~y & c.m[d];                                     // W - y, 0 in padding columns
+        const uint32_t sg = __builtin_amdgcn_perm(0x01010101u, 0x01010101u, xo & 0x80808080u);   // -1 where the signs differ
+        dot = __builtin_amdgcn_sdot4((int)t, (int)sg, dot, false);
+    }
+    return dot;
+}
 
 // AppxConst of the 16 columns starting at c0, from the sign-magnitude Q_att(u) bytes `ub`
 __device__ __forceinline__ void make_appx_const(AppxConst &c, const uint8_t *ub, uint32_t c0, uint32_t D)

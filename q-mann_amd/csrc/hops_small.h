@@ -83,7 +83,7 @@ k_hops_small(const HopArgs a, const uint32_t key_row_bytes)
                 const int kc = (c < D) ? qm_code(ua, fm.iwl, fm.frac) : 0;
                 const uint32_t ubyte = (uint32_t)(kc < 0 ? -kc : kc) | ((c < D && !(ua >= 0.0f)) ? 0x80u : 0u);
                 ub[c] = (uint8_t)ubyte;
-                if (MODE != kModeAppx) {
+                if (mode_is_planes(MODE)) {
 #pragma unroll
                     for (int i = 0; i < NB; i++) {
                         const uint64_t word = __ballot((ubyte >> (7 - i)) & 1u);
@@ -129,11 +129,16 @@ k_hops_small(const HopArgs a, const uint32_t key_row_bytes)
                 AppxConst c;
                 make_appx_const(c, ub, chunkk * 16, D);
                 scan([&](const i32x4 x) { return appx_lane_sum(x, c); }, 1 << (fm.iwl + 10));      // Q(iwl, 31-iwl) clamps at +-2^iwl
-            } else {
+            } else if (mode_is_planes(MODE)) {
                 if (MODE == kModeV1) unit = qm_scale_down(1.0f, NB);
                 PlaneConst c;
                 make_plane_const<NB>(c, upl, chunkk, D);
                 scan([&](const i32x4 x) { return plane_lane_sum<MODE, NB>(x, c); }, 32767);
+            } else {
+                if (MODE == kModeV1Bytes) unit = qm_scale_down(1.0f, NB);
+                HamByteConst c;
+                make_hambyte_const<MODE, NB>(c, ub, chunkk * 16, D);
+                scan([&](const i32x4 x) { return hambyte_lane_sum<MODE, NB>(x, c); }, 32767);
             }
         }
         if (PF) {

@@ -43,7 +43,11 @@ float *upload(const float *host, size_t n, hipStream_t st)
     return d;
 }
 
-int ensure(qmann_model *m, size_t rows, uint32_t n_query)
+// packed planes pay off when they are smaller than the bytes (num_bit < 8) and the memory is long enough for
+// bandwidth to matter; otherwise the same scores come straight from the int8 keys
+bool use_planes(const qmann_model *m, uint32_t max_slots) { return packed_mode(m->net) && m->net.num_bit < 8 && max_slots > 64; }
+
+int ensure(qmann_model *m, size_t rows, uint32_t n_query, bool planes)
 {
     if (rows > m->cap_rows) {
         const size_t cap = rows + rows / 4;
@@ -51,7 +55,7 @@ int ensure(qmann_model *m, size_t rows, uint32_t n_query)
         regrow(&m->vals, (size_t)m->H * cap * m->Dp);
         m->cap_rows = cap;
     }
-    if (packed_mode(m->net)) {
+    if (planes) {
         const size_t words = (size_t)m->H * m->cap_rows * (m->Dp / 64) * m->net.num_bit;
         if (words > m->cap_plane_words) { regrow(&m->planes, words); m->cap_plane_words = words; }
     }
@@ -70,7 +74,7 @@ int hops_and_answer(qmann_model *m, uint32_t rows_total, const uint32_t *row_off
 {
     const size_t hop_stride = (size_t)rows_total * m->Dp;
     int rc;
-    if (packed_mode(m->net)) {
+    if (use_planes(m, max_slots)) {
         const size_t key_hop_stride = (size_t)rows_total * (m->Dp / 64) * m->net.num_bit * 8;
         rc = qmann_pack_bitplanes(m->keys, m->planes, (size_t)m->H * rows_total, m->Dp, m->net.num_bit, stream);
         if (rc) return rc;
@@ -154,7 +158,7 @@ int qmann_model_forward_words(qmann_model *m, const uint16_t *story_words, uint3
 {
     if (!m || !story_words || !question_words || !row_off || !pred) return QMANN_EINVAL;
     if (n_query == 0) return QMANN_OK;
-    int rc = ensure(m, rows_total, n_query);
+    int rc = ensure(m, rows_total, n_query, use_planes(m, max_slots));
     if (rc) return rc;
     rc = qmann_embed_story_idx(&m->emb_net, story_words, rows_total, max_words, 1, m->t_a, m->t_c, m->keys, m->vals,
                                (size_t)rows_total * m->Dp, stream);
@@ -170,7 +174,7 @@ int qmann_model_forward_bow(qmann_model *m, const float *story, uint32_t rows_to
 {
     if (!m || !story || !question || !row_off || !pred) return QMANN_EINVAL;
     if (n_query == 0) return QMANN_OK;
-    int rc = ensure(m, rows_total, n_query);
+    int rc = ensure(m, rows_total, n_query, use_planes(m, max_slots));
     if (rc) return rc;
     rc = qmann_embed_story(&m->emb_net, story, rows_total, m->w_a, m->w_c, m->keys, m->vals, (size_t)rows_total * m->Dp, stream);
     if (rc) return rc;

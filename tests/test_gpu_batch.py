@@ -219,7 +219,7 @@ def test_babi_end_to_end_from_bag_of_words(env, oracle, gold):
 # ---------------------------------------------------------------------------------------------
 # Hamming family
 # ---------------------------------------------------------------------------------------------
-def run_hamming_case(env, oracle, mode, D, S_list, B, seed, iwl=5, num_bit=8, sigma=40.0, extra=None):
+def run_hamming_case(env, oracle, mode, D, S_list, B, seed, iwl=5, num_bit=8, sigma=40.0, extra=None, from_bytes=False):
     """mode 3 (CUDA approximate attention, int8 keys) or 10 / 11 (packed bit planes + popcount)."""
     torch, model = env.torch, env.model
     H, V = 3, 40
@@ -249,6 +249,9 @@ def run_hamming_case(env, oracle, mode, D, S_list, B, seed, iwl=5, num_bit=8, si
     if mode == 3:
         u_out, taps = net.hops(dk, dv, dro, int(n_slots.max()), du0, taps=True)
         unit = 1.0 / 1024.0
+    elif from_bytes:                                # V0 / V1 straight from the int8 keys
+        u_out, taps = net.hops(dk, dv, dro, int(n_slots.max()), du0, taps=True)
+        unit = 1.0 if mode == 10 else 1.0 / (1 << num_bit)
     else:
         planes = net.pack_planes(dk, num_bit)
         u_out, taps = net.hops_packed(planes, dv, dro, int(n_slots.max()), du0, taps=True)
@@ -302,6 +305,19 @@ def test_hops_one_wavefront_path_hamming(env, oracle, mode, D, num_bit):
     run_hamming_case(env, oracle, mode, D, [1, 2, 7, 16, 17, 33, 50, 63, 64], B=18, seed=700 + mode + D + num_bit,
                      num_bit=num_bit)
     run_hamming_case(env, oracle, mode, D, [5, 50], B=6, seed=701 + mode + D, num_bit=num_bit, iwl=3)
+
+
+@pytest.mark.parametrize("mode", [10, 11])
+@pytest.mark.parametrize("D,num_bit", [(60, 8), (64, 2), (128, 8), (128, 4), (128, 1), (200, 8), (256, 8), (256, 2), (256, 1)])
+def test_hops_hamming_from_int8_keys_bit_exact(env, oracle, mode, D, num_bit):
+    """V0 / V1 computed from the sign-magnitude bytes (no bit planes): streaming kernel and one-wavefront kernel."""
+    run_hamming_case(env, oracle, mode, D, [1, 7, 50, 64, 129, 300], B=12, seed=41 + D + num_bit, num_bit=num_bit, from_bytes=True)
+    run_hamming_case(env, oracle, mode, D, [1, 2, 17, 33, 64], B=10, seed=42 + D + num_bit, num_bit=num_bit, from_bytes=True)
+
+
+def test_hops_hamming_from_int8_keys_full_size(env, oracle):
+    run_hamming_case(env, oracle, 10, 256, [10000, 4097], B=3, seed=43, num_bit=8, from_bytes=True)
+    run_hamming_case(env, oracle, 11, 128, [10000], B=2, seed=44, num_bit=8, from_bytes=True, sigma=25.0)
 
 
 def test_hops_packed_full_size_d256(env, oracle):
@@ -839,4 +855,37 @@ def test_joint_20_tasks_forward_equals_oracle(env, oracle, gold, mode, num_bit):
             assert int(pred[i]) == opred, i
         checked += 1
     assert excused <= 12 and checked >= 88
+    hm.close()
+
+
+@pytest.mark.parametrize("mode,num_bit", [(10, 2), (11, 4), (10, 8)])
+def test_host_model_long_stories_planes_or_bytes(env, mode, num_bit):
+    """The host object packs bit planes only when they are smaller than the bytes and the stories are long
+    (num_bit < 8, more than 64 slots); either way its result equals the explicit stage-by-stage pipeline."""
+    torch, model = env.torch, env.model
+    rng = np.random.default_rng(mode * 10 + num_bit)
+    V, D, B, W = 90, 60, 7, 12
+    n_sen = np.array([100, 3, 70, 65, 1, 128, 90], np.int64)
+    rows = int(n_sen.sum())
+    sw = np.full((rows, W), 0xFFFF, np.uint16)
+    for r in range(rows):
+        n = int(rng.integers(1, W - 1))
+        sw[r, :n] = rng.integers(0, V - 20, n)
+        sw[r, n] = V - 20 + int(rng.integers(0, 20))               # time entry
+    qw = np.full((B, 8), 0xFFFF, np.uint16)
+    for q in range(B):
+        n = int(rng.integers(1, 8)); qw[q, :n] = rng.integers(0, V - 20, n)
+    cfg = model.babi_cfg(V, mode, 0, iwl=5, en_mq=False); cfg["num_bit"] = num_bit
+    wts = weights(77 + mode, 3, D, V, 4.0)
+    d_sw = torch.from_numpy(sw.view(np.int16)).to(env.dev); d_qw = torch.from_numpy(qw.view(np.int16)).to(env.dev)
+    ro = torch.from_numpy(np.concatenate([[0], np.cumsum(n_sen)]).astype(np.int32)).to(env.dev)
+    hm = model.HostModel(cfg, wts)
+    pred, _, _ = hm.forward_words(d_sw, d_qw, ro, int(n_sen.max()))
+    u_host = hm.last_u(B)
+    net = model.QNet(cfg, wts); net.make_tables()
+    keys, vals, u0 = net.embed_idx(d_sw, d_qw)
+    u_ref = net.hops_packed(net.pack_planes(keys, num_bit), vals, ro, int(n_sen.max()), u0)
+    p_ref = net.answer(u_ref)[0]
+    torch.cuda.synchronize()
+    assert torch.equal(u_host, u_ref) and torch.equal(pred, p_ref)
     hm.close()
