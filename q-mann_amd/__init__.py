@@ -10,10 +10,12 @@ loaded, importing `qmann_amd.abi` raises.
 The directory is named `q-mann_amd`; import it through `load_pkg()` in
 tests/conftest.py / bench.py (module name `qmann_amd`).
 """
+import os
 from pathlib import Path
 
 PKG_DIR = Path(__file__).resolve().parent
 ROOT = PKG_DIR.parent
-LIB_PATH = PKG_DIR / "lib" / "libqmann_hip.so"
+# QMANN_LIB_PATH: another build of the same library (A/B timing of two builds inside one GPU session)
+LIB_PATH = Path(os.environ["QMANN_LIB_PATH"]) if os.environ.get("QMANN_LIB_PATH") else PKG_DIR / "lib" / "libqmann_hip.so"
 
 __all__ = ["PKG_DIR", "ROOT", "LIB_PATH"]
