@@ -18,7 +18,8 @@
  *                |code| -- the top byte of the reference's own FLOAT2FIXED word
  *                (lib/common.h:210), so "minus zero" (0x80) is representable as it is there.
  *                Dp = dim_emb_pad (multiple of 16, >= D); columns D..Dp-1 are 0.
- *                keys[h] carry Q(att[h]) codes, vals[h] carry Q(act[h]) codes --
+ *                keys[h] carry Q(att[h]) codes, vals[h] carry Q(act[h]) codes (valid codes of those
+ *                formats: |code| <= 2^(iwl+frac) - 1, which matters for word lengths below 8) --
  *                i.e. what the reference's dot_mat_vec layers see after their
  *                own operand quantisation (lib/layer_cuda.cu:120, :562).
  *   row_off    : uint32 [n_query + 1]            first row of each query's

@@ -498,7 +498,9 @@ k_embed_story_idx(const EmbedIdxArgs a)
                     // sign-extended bytes: even columns (0, 2) and odd columns (1, 3)
                     s16x2 ea = (__builtin_bit_cast(s16x2, ta) << 8) >> 8, oa = __builtin_bit_cast(s16x2, ta) >> 8;
                     s16x2 ec = (__builtin_bit_cast(s16x2, tc) << 8) >> 8, oc = __builtin_bit_cast(s16x2, tc) >> 8;
-                    if (ce != 1u) {                      // a repeated word: Qw(Qw(count) . kw) per column (rare)
+                    // Qw(1 . kw) = kw needs 1.0 to be a value of the format (iwl >= 1); a purely fractional
+                    // format saturates the count itself, like a repeated word: Qw(Qw(count) . kw) per column (rare)
+                    if (ce != 1u || (1 << fw.frac) > maxw) {
                         const int cc = count_code(ce, fw.frac, maxw);
 #pragma unroll
                         for (int k = 0; k < 2; k++) {
@@ -581,7 +583,7 @@ k_embed_query_idx(const uint16_t *__restrict__ words, const int8_t *__restrict__
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const int kw = (int)(int8_t)(t >> (8 * k));
-                    acc[k] += (ce == 1u) ? kw : qm_mul_code(cc, kw, fw.frac, maxw);
+                    acc[k] += (ce == 1u && (1 << fw.frac) <= maxw) ? kw : qm_mul_code(cc, kw, fw.frac, maxw);   // see k_embed_story_idx
                 }
             }
             if (q_ok && col_ok) {

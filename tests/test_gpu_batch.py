@@ -69,6 +69,9 @@ def run_case(env, oracle, cfg, B, S_list, seed, sigma_u=20.0, sigma_k=30.0, sigm
     vals = np.zeros((H, max(R, 1), Dp), np.int8)
     keys[:, :, :D] = np.clip(np.rint(rng.normal(0, sigma_k, (H, max(R, 1), D))), -127, 127)
     vals[:, :, :D] = np.clip(np.rint(rng.normal(0, sigma_k, (H, max(R, 1), D))), -127, 127)
+    for h in range(H):                               # memories hold valid codes of their formats (word length may be < 8)
+        mk = (1 << sum(cfg["fmt_att"][h])) - 1; mv = (1 << sum(cfg["fmt"][h])) - 1
+        keys[h] = np.clip(keys[h], -mk, mk); vals[h] = np.clip(vals[h], -mv, mv)
     u0 = (np.clip(np.rint(rng.normal(0, sigma_u, (B, D))), -127, 127) / (1 << cfg["fmt_w"][0][1])).astype(np.float32)
     dk = torch.from_numpy(model.to_signmag(keys)).to(env.dev)      # memories are sign-magnitude bytes
     dv = torch.from_numpy(model.to_signmag(vals)).to(env.dev)
@@ -241,8 +244,13 @@ def run_hamming_case(env, oracle, mode, D, S_list, B, seed, iwl=5, num_bit=8, si
     # exercise magnitude ties, zeros and full-scale values (carry out of 7 bits in the opposite-sign sum)
     keys[:, ::3, : D // 2] = np.clip(keys[:, ::3, : D // 2].astype(np.int16) * 3, -127, 127)
     keys[:, 1::5, ::4] = 0
-    u0 = (np.clip(np.rint(rng.normal(0, sigma, (B, D))), -127, 127) / (1 << frac)).astype(np.float32)
-    u0[:, ::7] = np.float32(127.0 / (1 << frac)) * np.sign(u0[:, ::7] + 0.1)
+    for h in range(H):                               # value codes must be codes of the activation format
+        mv = (1 << sum(cfg["fmt"][h])) - 1
+        vals[h] = np.clip(vals[h], -mv, mv)
+    w0 = cfg["fmt_w"][0]                             # u0 is an emb_q output: on the Q(w[0]) grid
+    m0 = (1 << sum(w0)) - 1
+    u0 = (np.clip(np.rint(rng.normal(0, sigma, (B, D))), -m0, m0) / (1 << w0[1])).astype(np.float32)
+    u0[:, ::7] = np.float32(m0 / (1 << w0[1])) * np.sign(u0[:, ::7] + 0.1)
     dk = torch.from_numpy(model.to_signmag(keys)).to(env.dev)
     dv = torch.from_numpy(model.to_signmag(vals)).to(env.dev)
     dro = torch.from_numpy(row_off).to(env.dev); du0 = torch.from_numpy(u0).to(env.dev)
@@ -263,13 +271,14 @@ def run_hamming_case(env, oracle, mode, D, S_list, B, seed, iwl=5, num_bit=8, si
     excused = 0
     for q in range(B):
         a, b = int(row_off[q]), int(row_off[q + 1])
-        kf = np.stack([keys[h, a:b, :D].astype(np.float32) / (1 << frac) for h in range(H)])
-        vf = np.stack([vals[h, a:b, :D].astype(np.float32) / (1 << frac) for h in range(H)])
+        kf = np.stack([keys[h, a:b, :D].astype(np.float32) / (1 << cfg["fmt_att"][h][1]) for h in range(H)])
+        vf = np.stack([vals[h, a:b, :D].astype(np.float32) / (1 << cfg["fmt"][h][1]) for h in range(H)])
         _, t = oracle.forward_mem(m, kf, vf, u0[q])
         ok = True
         for h in range(H):
             if not ok:
                 break
+            frac = cfg["fmt"][h][1]
             # bit-exact Hamming scores: integers in units of `unit`
             np.testing.assert_array_equal(g_scores[h, a:b], t["scores"][h], err_msg=f"scores q{q} h{h} mode {mode}")
             np.testing.assert_array_equal(g_codes[h, a:b], np.rint(t["scores"][h] / unit).astype(np.int32))
@@ -889,3 +898,99 @@ def test_host_model_long_stories_planes_or_bytes(env, mode, num_bit):
     torch.cuda.synchronize()
     assert torch.equal(u_host, u_ref) and torch.equal(pred, p_ref)
     hm.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# word lengths below 8 and unrelated formats per layer (BW_WL is a parameter of the reference, define.h:20-21)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", range(24))
+def test_hops_fixed_random_formats(env, oracle, seed):
+    """Random Q(iwl.frac) per role with word lengths 2..7 (activation, attention, weights per hop, query operand),
+    both hop kernels, ragged memories: integer parity must hold for every combination."""
+    rng = np.random.default_rng(5000 + seed)
+
+    def fmt(lo=2, hi=7):
+        wl = int(rng.integers(lo, hi + 1))
+        iwl = int(rng.integers(0, wl + 1))
+        return (iwl, wl - iwl)
+    H = 3
+    D = int(rng.choice([60, 64, 100, 128, 256]))
+    cfg = dict(n_hop=H, dim_emb=D, dim_input=40, attention_mode=2, softmax_variant=int(rng.integers(0, 3)), f_fixed=True,
+               en_lin_map=bool(rng.integers(0, 4)), fmt=[fmt() for _ in range(H)], fmt_w=[fmt() for _ in range(H)],
+               fmt_att=[fmt() for _ in range(H)], fmt_bin=fmt(1, 7))
+    small = seed % 2 == 0
+    S_list = [1, 3, 9, 33, 64] if small else [70, 200, 513]
+    # codes are drawn for 8-bit memories; the kernels see whatever the formats make of them
+    run_case(env, oracle, cfg, B=8, S_list=S_list, seed=6000 + seed, sigma_u=20.0, sigma_k=25.0, sigma_h=1.0)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_embedding_random_formats(env, oracle, seed):
+    """Both embedding paths (bag-of-words floats, word indices) with random word lengths 2..7 per role:
+    keys / values are the oracle's dense_mat_fwd outputs re-read on the attention / activation grids."""
+    torch, model = env.torch, env.model
+    rng = np.random.default_rng(7000 + seed)
+
+    def fmt():
+        wl = int(rng.integers(2, 8)); iwl = int(rng.integers(0, wl + 1))
+        return (iwl, wl - iwl)
+    H, V, dd = 3, int(rng.choice([30, 90, 300])), None
+    D = int(rng.choice([60, 100, 128]))
+    dd = V - 12
+    cfg = dict(n_hop=H, dim_emb=D, dim_input=V, attention_mode=2, softmax_variant=0, f_fixed=True, en_lin_map=True,
+               fmt=[fmt() for _ in range(H)], fmt_w=[fmt() for _ in range(H)], fmt_att=[fmt() for _ in range(H)], fmt_bin=fmt())
+    wts = weights(7100 + seed, H, D, V, float(rng.choice([0.3, 1.5, 6.0])))
+    rows, nq, W = 37, 11, 12
+    sw = np.full((rows, W), 0xFFFF, np.uint16); story = np.zeros((rows, V), np.float32)
+    for r in range(rows):
+        ws = rng.integers(0, min(dd, 5 if r % 4 == 0 else dd), int(rng.integers(1, W - 1)))
+        for k in ws:
+            story[r, k] += 1.0
+        t = dd + int(rng.integers(0, 12)); story[r, t] = 1.0
+        ent = list(ws) + [t]; sw[r, :len(ent)] = ent
+    qw = np.full((nq, 8), 0xFFFF, np.uint16); ques = np.zeros((nq, V), np.float32)
+    for q in range(nq):
+        ws = rng.integers(0, dd, int(rng.integers(1, 8)))
+        for k in ws:
+            ques[q, k] += 1.0
+        qw[q, :len(ws)] = ws
+    net = model.QNet(cfg, wts); net.make_tables()
+    k1, v1, u1 = net.embed(torch.from_numpy(story).to(env.dev), torch.from_numpy(ques).to(env.dev))
+    k2, v2, u2 = net.embed_idx(torch.from_numpy(sw.view(np.int16)).to(env.dev), torch.from_numpy(qw.view(np.int16)).to(env.dev))
+    torch.cuda.synchronize()
+    assert torch.equal(k1, k2) and torch.equal(v1, v2) and torch.equal(u1, u2)
+    k = model.from_signmag(k1.cpu().numpy()); v = model.from_signmag(v1.cpu().numpy())
+    for h in range(H):
+        ka = oracle.dense_mat_fwd(wts["w_a"][h], story, True, cfg["fmt_w"][h])
+        kc = oracle.dense_mat_fwd(wts["w_c"][h], story, True, cfg["fmt_w"][h])
+        np.testing.assert_array_equal(k[h, :, :D], oracle.code8(ka, *cfg["fmt_att"][h]), err_msg=f"keys hop {h}")
+        np.testing.assert_array_equal(v[h, :, :D], oracle.code8(kc, *cfg["fmt"][h]), err_msg=f"values hop {h}")
+    for q in range(nq):
+        np.testing.assert_array_equal(u1[q].cpu().numpy(), oracle.dense_fwd(wts["w_q"], ques[q], True, cfg["fmt_w"][0], cfg["fmt_w"][0]))
+
+
+@pytest.mark.parametrize("seed", range(18))
+def test_hops_hamming_random_formats(env, oracle, seed):
+    """Hamming family with unrelated activation / weight / operand formats (word lengths 2..7); the attention
+    grid stays Q(iwl.7-iwl) and contains the grids u arrives on, as the byte forms require."""
+    rng = np.random.default_rng(8000 + seed)
+    ia = int(rng.integers(1, 7)); att = (ia, 7 - ia)
+
+    def inside():                                   # a format whose grid lies inside the attention grid
+        i = int(rng.integers(0, ia + 1)); f = int(rng.integers(0, 7 - ia + 1))
+        if i + f < 2:
+            i, f = min(ia, 1), max(1, min(7 - ia, 1))
+        return (i, f)
+
+    def free():
+        wl = int(rng.integers(2, 8)); i = int(rng.integers(0, wl + 1))
+        return (i, wl - i)
+    H = 3
+    extra = dict(fmt=[inside() for _ in range(H)], fmt_w=[inside()] + [free() for _ in range(H - 1)],
+                 fmt_att=[att] * H, fmt_bin=free(), en_lin_map=bool(rng.integers(0, 5)))
+    mode = [3, 10, 11][seed % 3]
+    nb = int(rng.choice([1, 2, 4, 8]))
+    D = int(rng.choice([60, 128, 256]))
+    S_list = [1, 5, 33, 64] if seed % 2 else [70, 300]
+    from_bytes = (seed % 4 < 2 or (D <= 64 and nb == 1)) and mode != 3      # one plane of 64 columns is below a 16-byte row: bytes only
+    run_hamming_case(env, oracle, mode, D, S_list, B=6, seed=8100 + seed, iwl=ia, num_bit=nb, extra=extra, from_bytes=from_bytes)
