@@ -285,3 +285,62 @@ def test_one_query_through_the_layer_sequence(env, oracle, gold):
             np.testing.assert_allclose(a.cpu().numpy(), t["logits"], rtol=1e-5, atol=1e-5)
             lib.cuda_softmax_fwd(ptr(ph), ptr(a), None, None, ptr(empty(1)), V, False, False)
             np.testing.assert_allclose(ph.cpu().numpy(), t["out_probs"], rtol=1e-4, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------
+# random shapes / formats through the per-op verbs (word lengths 1..7, the binarising (0,0) operand format,
+# off-grid and saturating inputs)
+# ---------------------------------------------------------------------------------------------
+def rand_fmt(rng, lo=1, hi=7):
+    wl = int(rng.integers(lo, hi + 1)); iwl = int(rng.integers(0, wl + 1))
+    return (iwl, wl - iwl)
+
+
+def wild(rng, shape, fmt):
+    """values around the format's range: on-grid, off-grid, beyond the limits, tiny negatives"""
+    lim = 2.0 ** fmt[0]
+    x = rng.normal(0, 0.6 * lim + 0.05, shape).astype(np.float32)
+    flat = x.reshape(-1)
+    flat[::7] = np.float32(lim * 1.5); flat[::11] = np.float32(-lim * 2.0); flat[::13] = np.float32(-1e-5)
+    return x
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_forward_verbs_random_shapes_and_formats(env, oracle, seed):
+    rng = np.random.default_rng(9000 + seed)
+    # dense_fwd: operand format may be the binarising (0,0)
+    dim_in, dim_out = int(rng.integers(1, 300)), int(rng.integers(1, 300))
+    fw, fi = rand_fmt(rng), (rand_fmt(rng) if seed % 5 else (0, 0))
+    w, x = wild(rng, (dim_out, dim_in), fw), wild(rng, dim_in, fi if sum(fi) else (2, 5))
+    dw, dx, do = env.up(w), env.up(x), env.empty(dim_out)
+    env.lib.cuda_dense_fwd(env.ptr(dw), None, env.ptr(dx), env.ptr(do), None, dim_in, dim_out, b"NULL", True,
+                           fi[0], fi[1], fw[0], fw[1], 3, False)
+    np.testing.assert_array_equal(do.cpu().numpy(), oracle.dense_fwd(w, x, True, fi, fw), err_msg="dense_fwd")
+    # dense_mat_fwd
+    n, f = int(rng.integers(1, 70)), rand_fmt(rng)
+    X = wild(rng, (n, dim_in), f)
+    dX, dO = env.up(X), env.empty(n, dim_out)
+    env.lib.cuda_dense_mat_fwd(env.ptr(dw), None, env.ptr(dX), env.ptr(dO), None, dim_in, dim_out, n, True, f[0], f[1], 3, False)
+    np.testing.assert_array_equal(dO.cpu().numpy(), oracle.dense_mat_fwd(w, X, True, f), err_msg="dense_mat_fwd")
+    # dot_mat_vec_fwd: scores (matrix and vector formats differ) and the transposed read-out
+    r, c = int(rng.integers(1, 400)), int(rng.integers(1, 300))
+    fm, fv = rand_fmt(rng), (rand_fmt(rng) if seed % 4 else (0, 0))
+    M, u = wild(rng, (r, c), fm), wild(rng, c, fv if sum(fv) else (2, 5))
+    dM, du, ds = env.up(M), env.up(u), env.empty(r)
+    env.lib.cuda_dot_mat_vec_fwd(env.ptr(dM), env.ptr(du), env.ptr(ds), None, r, c, False, True, fm[0], fm[1], fv[0], fv[1], 3, False)
+    np.testing.assert_array_equal(ds.cpu().numpy(), oracle.dot_mat_vec_fwd(M, u, False, True, fm, fv), err_msg="scores")
+    p = oracle.softmax_fwd(rng.normal(0, 3, r).astype(np.float32), SM_CUDA)
+    dp, dq = env.up(p), env.empty(c)
+    env.lib.cuda_dot_mat_vec_fwd(env.ptr(dM), env.ptr(dp), env.ptr(dq), None, r, c, True, True, fm[0], fm[1], fm[0], fm[1], 3, False)
+    np.testing.assert_array_equal(dq.cpu().numpy(), oracle.dot_mat_vec_fwd(M, p, True, True, fm, fm), err_msg="read-out")
+    # sum_vec_fwd
+    a_, b_ = wild(rng, c, fm), wild(rng, c, fm)
+    da, db, dc = env.up(a_), env.up(b_), env.empty(c)
+    env.lib.cuda_sum_vec_fwd(env.ptr(da), env.ptr(db), env.ptr(dc), c, True, fm[0], fm[1], 3, False)
+    np.testing.assert_array_equal(dc.cpu().numpy(), oracle.sum_vec_fwd(a_, b_, True, fm), err_msg="sum_vec")
+    # approximate attention: word length 8 formats, n compared bits
+    ia = int(rng.integers(1, 7))
+    Ma, ua = wild(rng, (r, c), (ia, 7 - ia)), wild(rng, c, (ia, 7 - ia))
+    dMa, dua, dsa = env.up(Ma), env.up(ua), env.empty(r)
+    env.lib.cuda_dot_mat_vec_fwd_appx(env.ptr(dMa), env.ptr(dua), env.ptr(dsa), None, None, r, c, True, ia, 7 - ia, 3, 8, False, False)
+    np.testing.assert_array_equal(dsa.cpu().numpy(), oracle.dot_mat_vec_fwd_appx(Ma, ua, False, True, ia, 7 - ia, 8), err_msg="appx")
