@@ -129,3 +129,31 @@ def test_dup_grad_and_sum_vec_bwd(env, oracle):
     np.testing.assert_array_equal(do.cpu().numpy(), oracle.dup_grad_bwd(a, b, True, (5, 2)))
     env.lib.cuda_sum_vec_bwd(env.ptr(do), env.ptr(da), None, None, 60)
     np.testing.assert_array_equal(do.cpu().numpy(), a)
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_backward_verbs_random_shapes_and_formats(env, oracle, seed):
+    """dot_mat_vec_bwd (both orientations), dense_bwd, dense_mat_bwd with random shapes and word lengths 2..8
+    (the gradient format is Q(1.wl-2), so the word length matters)."""
+    rng = np.random.default_rng(9500 + seed)
+    wl = int(rng.integers(2, 8)); iwl = int(rng.integers(0, wl + 1)); fmt = (iwl, wl - iwl)
+    r, c = int(rng.integers(1, 90)), int(rng.integers(1, 130))
+    for f_trans in (False, True):
+        M, v = rnd(rng, (r, c), 2.0), rnd(rng, r if f_trans else c, 2.0)
+        gi = rnd(rng, c if f_trans else r, 0.3)
+        dM, dv, dg = env.up(M), env.up(v), env.up(gi)
+        gm, gv = env.zeros(r, c), env.zeros(r if f_trans else c)
+        env.lib.cuda_dot_mat_vec_bwd(env.ptr(dM), env.ptr(dv), env.ptr(dg), env.ptr(gm), env.ptr(gv), None, r, c, f_trans,
+                                     True, fmt[0], fmt[1], fmt[0], fmt[1], 3, False)
+        om, ov = oracle.dot_mat_vec_bwd(M, v, gi, f_trans, True, fmt)
+        np.testing.assert_array_equal(gm.cpu().numpy(), om, err_msg=f"grad mat trans={f_trans}")
+        np.testing.assert_array_equal(gv.cpu().numpy(), ov, err_msg=f"grad vec trans={f_trans}")
+    dim_in, dim_out = int(rng.integers(1, 120)), int(rng.integers(1, 120))
+    w, x, gi = rnd(rng, (dim_out, dim_in)), rnd(rng, dim_in), rnd(rng, dim_out, 0.5)
+    w_del0, out = rnd(rng, (dim_out, dim_in), 0.2), rnd(rng, dim_out)
+    dw, dwd, dx, dout, dgi, dgo = env.up(w), env.up(w_del0), env.up(x), env.up(out), env.up(gi), env.zeros(dim_in)
+    env.lib.cuda_dense_bwd(env.ptr(dw), env.ptr(dwd), None, None, env.ptr(dx), env.ptr(dout), env.ptr(dgi), env.ptr(dgo),
+                           None, dim_in, dim_out, b"NULL", True, fmt[0], fmt[1], fmt[0], fmt[1], 3, False)
+    owd, ogo, _ = oracle.dense_bwd(w, w_del0, x, out, gi, True, fmt)
+    np.testing.assert_array_equal(dwd.cpu().numpy(), owd, err_msg="dense w_del")
+    np.testing.assert_array_equal(dgo.cpu().numpy(), ogo, err_msg="dense grad_out")
