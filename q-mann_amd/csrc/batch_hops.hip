@@ -265,12 +265,9 @@ int qmann_hops_i8(const qmann_net *net, const int8_t *keys, const int8_t *vals, 
     const dim3 grid(n_query), block(max_slots <= 256 ? kWave : kBlock);
 #define QM_LAUNCH_HOPS(LPR, UN, NT, MINW)                                                               \
     do {                                                                                                \
-        static size_t attr_bytes = 0;       /* raise the dynamic-LDS limit only when it grows */        \
-        if (lds > attr_bytes) {                                                                         \
-            QM_HIP(hipFuncSetAttribute((const void *)k_hops_fixed<LPR, UN, NT, MINW>,                   \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
-            attr_bytes = lds;                                                                           \
-        }                                                                                               \
+        if (lds > kLdsDefaultLimit)         /* beyond the default 64 KB: raise the limit (no cached state:  */ \
+            QM_HIP(hipFuncSetAttribute((const void *)k_hops_fixed<LPR, UN, NT, MINW>,   /* thread- and    */ \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); /* device-safe */ \
         k_hops_fixed<LPR, UN, NT, MINW><<<grid, block, lds, st>>>(a);                                   \
     } while (0)
     // (bounding the kernel to 96 VGPRs for a fifth wavefront per SIMD measured 1-3 % slower: MINW stays 1)

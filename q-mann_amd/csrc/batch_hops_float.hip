@@ -204,12 +204,9 @@ k_hops_float(const HopArgs a)
 template <int LPR>
 void launch_float(const HopArgs &a, size_t lds, uint32_t n_query, hipStream_t st)
 {
-    static size_t attr_bytes = 0;
-    if (lds > attr_bytes) {
+    if (lds > kLdsDefaultLimit)
         QM_HIP(hipFuncSetAttribute((const void *)k_hops_float<LPR>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds));
-        attr_bytes = lds;
-    }
     k_hops_float<LPR><<<n_query, kBlock, lds, st>>>(a);
 }
 

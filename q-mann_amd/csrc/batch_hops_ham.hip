@@ -270,12 +270,9 @@ int fill_args(HopArgs &a, const qmann_net *net, const void *keys, const int8_t *
 template <int LPRK, int DP, int MODE, int NB>
 void launch(const HopArgs &a, uint32_t key_row_bytes, size_t lds, uint32_t lds_slots, uint32_t n_query, hipStream_t st)
 {
-    static size_t attr_bytes = 0;
-    if (lds > attr_bytes) {
+    if (lds > kLdsDefaultLimit)
         QM_HIP(hipFuncSetAttribute((const void *)k_hops_ham<LPRK, DP, MODE, NB>,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_bytes = lds;
-    }
     k_hops_ham<LPRK, DP, MODE, NB><<<n_query, kBlock, lds, st>>>(a, key_row_bytes, lds_slots);
 }
 

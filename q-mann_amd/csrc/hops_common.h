@@ -41,6 +41,8 @@ constexpr int kWave = 64;
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock / kWave;
 constexpr int kUnrollDefault = 4;  // 16-byte loads per lane and tile in the key scan (two tiles in flight)
+// dynamic LDS a kernel may use without hipFuncSetAttribute (static arrays come on top, hence the margin)
+constexpr size_t kLdsDefaultLimit = 48 * 1024;
 constexpr int kLiveCap = 256;     // surviving rows kept in LDS (at most 2^frac <= 128 can exist)
 
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
