@@ -51,6 +51,8 @@ WORKLOADS = {
     # answer layer ("f32" | "i8" = int8 MFMA), sigma of key/query codes and of value codes
     "synth10k_d128": dict(S=10000, D=128, V=256, B=8192, mode=2, nb=8, ans="f32", sk=3.5, sv=30.0, su=3.5),
     "synth10k_d256_ham": dict(S=10000, D=256, V=256, B=8192, mode=10, nb=1, ans="i8", sk=30.0, sv=30.0, su=30.0),
+    # config 5 with the larger of its two dictionary sizes (V in {256, 4 096}): the int8 MFMA projection is 17 GOP
+    "synth10k_d256_ham_v4096": dict(S=10000, D=256, V=4096, B=8192, mode=10, nb=1, ans="i8", sk=30.0, sv=30.0, su=30.0),
     "synth10k_d128_appx": dict(S=10000, D=128, V=256, B=8192, mode=3, nb=8, ans="f32", sk=30.0, sv=30.0, su=30.0),
     "synth10k_d128_float": dict(S=10000, D=128, V=256, B=4096, mode=1, nb=8, ans="f32", sk=3.5, sv=30.0, su=3.5),
     "babi_mem50": dict(S=50, D=60, V=80, B=262144, mode=2, nb=8, ans="f32", sk=8.0, sv=30.0, su=8.0),
