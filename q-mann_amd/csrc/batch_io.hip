@@ -747,8 +747,9 @@ int qmann_embed_story_idx(const qmann_net *net, const uint16_t *words, uint32_t 
     const uint32_t need = (rows_total + kWaves * 4 - 1) / (kWaves * 4);
     const uint32_t blocks = need < 2048u ? need : 2048u;
     const size_t tab_lds = (size_t)net->n_hop * 2 * net->dim_input * net->dim_emb_pad;
-    // (staging one hop's tables at a time for dictionaries whose tables exceed LDS was measured: three passes over
-    // the rows cost more than the L2 gathers they save -- 2.1 ms against 1.4 ms on the 20-task joint set)
+    // (for dictionaries whose tables exceed 48 KB both alternatives to L2 gathers were measured on the 20-task joint
+    // set and are slower than the 1.4 ms of the gathers: staging one hop's tables at a time (three passes over the
+    // rows, 2.1 ms) and one 91 KB copy per CU shared by a 1024-thread workgroup (1.6 ms))
     if (tab_lds <= 48 * 1024)
         k_embed_story_idx<kTabLdsAll><<<blocks, kBlock, tab_lds, (hipStream_t)stream>>>(a);
     else
