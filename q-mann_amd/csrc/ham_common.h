@@ -28,7 +28,7 @@ struct AppxConst {
     int bias;         // 127 . (16 - padding columns of this lane): the same-sign terms' constant part
 };
 
-// 15 VALU operations per 4 columns (the boolean pairs fuse into v_bitop3_b32).  Padding columns are forced to "same sign, both magnitudes 0"
+// 17 VALU operations per 4 columns in the compiled loop (the boolean pairs fuse into v_bitop3_b32).  Padding columns are forced to "same sign, both magnitudes 0"
 // by the masks (a term of exactly 127), which `bias` leaves out.
 __device__ __forceinline__ int appx_lane_sum(const i32x4 x, const AppxConst &c)
 {
