@@ -14,9 +14,12 @@ Workloads (config.workload):
   babi_mem50      bAbI-shaped: |memory| = 50 (MAX_SEN_LEN cap), D = 60, V = 30+50, 3 hops, int8 --
                   the |mem| = 50 size of BASELINE.json's metric string; latency/VALU bound.
 
-N > 1: launched by torch.distributed.run, one rank per GPU.  Queries are independent, so the
-batch is sharded with no data-path collective (weak scaling: 8 192 queries per GPU); RCCL is
-used once, to broadcast the quantized parameters from rank 0 (timed separately).
+N > 1: one rank per GPU.  Either the caller starts the ranks (torch.distributed.run sets WORLD_SIZE /
+RANK / LOCAL_RANK) or, when `--gpus N` is given with no WORLD_SIZE in the environment, this script
+starts them itself: the parent -- which never touches the GPU -- runs torch.distributed.run as a child
+process with N ranks of this same file and exits with its code.  Queries are independent, so the batch
+is sharded with no data-path collective (weak scaling: 8 192 queries per GPU); RCCL is used once, to
+broadcast the quantized parameters from rank 0 (timed separately).
 """
 from __future__ import annotations
 
@@ -29,7 +32,8 @@ import time
 from pathlib import Path
 
 import numpy as np
-import torch
+
+torch = None                    # imported in main(), after the launcher decision (see self_launch)
 
 ROOT = Path(__file__).resolve().parent
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
@@ -113,20 +117,60 @@ def usable_cores():
     return min(n, 16)
 
 
-def cpu_baseline(cfg, wts, keys, vals, u0, S, D, budget_s=8.0):
-    """The CPU oracle (our scalar restatement of the reference arithmetic) on a bounded sample of the
-    SAME queries: first one thread (the reference is single-threaded), then one thread per host core
-    the process may use, queries spread over threads (ctypes releases the GIL).  Checker
-    infrastructure used as a reported baseline only."""
-    import os
-    import threading
+def cpu_baseline_refport(cfg, wts, pool, what, gpu_preds=None, budget_s=4.0):
+    """The CPU baseline SURVEY.md 8(d) / BASELINE.md section 2 prescribe, timed on this box's host cores: the same
+    forward composed from the reference's own LIVE C functions (dense_mat_fwd, softmax_fwd, sum_vec_fwd,
+    hamming_similarity*: compiled unmodified from the reference tree into oracle/_ref, which travels prebuilt) and
+    the port for the ops whose CPU bodies are dead there (oracle/ref_forward.c), at the reference's own flags
+    (`gcc -w`, no -O) and at -O2, on one thread (the reference is single-threaded) and on every usable core; a C
+    pthread loop, no Python inside the timed region.  pool: (story, question) or (keys, vals, u0) float arrays of
+    queries of the SAME batch the GPU ran.  Checker infrastructure used as a reported baseline only.
+    Returns None when oracle/_ref is absent (then the caller reports the plain port)."""
     sys.path.insert(0, str(ROOT / "oracle"))
-    from pyoracle import Oracle
-    from qmann_amd.model import from_signmag
+    from pyoracle import Oracle, RefForward, SM_CPU_POW2
+    try:
+        rfs = {f: RefForward(f) for f in ("O2", "O0")}
+    except (FileNotFoundError, OSError):
+        return None
     ora = Oracle()
-    m = ora.make_model(cfg, wts)
+    # the reference's live CPU softmax is the 2^(x - max) form (lib/layer.c:1225); the arithmetic cost equals the e^x form
+    m_cpu = ora.make_model({**cfg, "softmax_variant": SM_CPU_POW2}, wts)
+    cores = usable_cores()
+    res = {}
+    for f, rf in rfs.items():
+        one = rf.time(m_cpu, pool, 1, budget_s)
+        many = rf.time(m_cpu, pool, cores, budget_s)
+        res[f] = {"flags": rf.flags, "value": many["qps"], "cores": cores,
+                  "sample": f"{many['n']} forwards in {many['secs']:.1f} s on {cores} threads",
+                  "one_thread": {"value": one["qps"], "sample": f"{one['n']} forwards in {one['secs']:.1f} s"}}
+    out = {"value": res["O2"]["value"], "unit": "queries/s", "cores": cores, "kind": "reference+port",
+           "flags": res["O2"]["flags"],
+           "sample": f"{what}: pool of {len(pool)} queries of the same batch, {res['O2']['sample']} (C pthread loop)",
+           "one_thread": res["O2"]["one_thread"],
+           "reference_flags": res["O0"],
+           "composition": "reference live C code: dense_mat_fwd, softmax_fwd (its CPU form 2^(x-max)), sum_vec_fwd, "
+                          "hamming_similarity{,_w}; port (dead CPU bodies in the reference): dot_mat_vec_fwd, dense_fwd, "
+                          "mode-3 attention, arg-max"}
+    if gpu_preds is not None:
+        # predictions: the GPU ran the e^x softmax (the CUDA form); compare with the port evaluating that same form
+        m_gpu = ora.make_model(cfg, wts)
+        n = min(len(pool), len(gpu_preds), 64)
+        t0, preds = time.perf_counter(), []
+        for item in pool[:n]:
+            if time.perf_counter() - t0 > 3.0 and preds:
+                break
+            pr, _ = (ora.forward_mem(m_gpu, *item, taps=()) if len(item) == 3 else ora.forward(m_gpu, *item, taps=()))
+            preds.append(pr)
+        out["pred_agree"] = int(sum(int(a == b) for a, b in zip(gpu_preds, preds)))
+        out["pred_total"] = len(preds)
+    return out
+
+
+def mem_pool(cfg, keys, vals, u0, S, D, n_max=64, bytes_max=2e9):
+    """First queries of the resident batch as the float-on-grid arrays the CPU code takes: (keys [H][S][D], vals, u0)."""
+    from qmann_amd.model import from_signmag
     H = cfg["n_hop"]
-    B = u0.shape[0]
+    n = int(max(1, min(u0.shape[0], n_max, bytes_max // max(2 * H * S * D * 4, 1))))
 
     def inputs(q):
         kf = np.stack([from_signmag(keys[h, q * S:(q + 1) * S, :D].cpu().numpy()).astype(np.float32)
@@ -134,42 +178,55 @@ def cpu_baseline(cfg, wts, keys, vals, u0, S, D, budget_s=8.0):
         vf = np.stack([from_signmag(vals[h, q * S:(q + 1) * S, :D].cpu().numpy()).astype(np.float32)
                        / np.float32(1 << cfg["fmt"][h][1]) for h in range(H)])
         return kf, vf, u0[q].cpu().numpy()
+    return [inputs(q) for q in range(n)]
 
-    # one thread
+
+def cpu_baseline_port(cfg, wts, pool, what, gpu_preds=None, budget_s=6.0):
+    """Fallback when oracle/_ref is absent: the scalar C oracle (-O2) alone, one thread and every usable core
+    (Python threads around ctypes calls, which release the GIL)."""
+    import threading
+    sys.path.insert(0, str(ROOT / "oracle"))
+    from pyoracle import Oracle
+    ora = Oracle()
+    m = ora.make_model(cfg, wts)
+    fwd = (lambda it: ora.forward_mem(m, *it, taps=())[0]) if len(pool[0]) == 3 else (lambda it: ora.forward(m, *it, taps=())[0])
     done, t_used, preds = 0, 0.0, []
-    while done < B and (t_used < budget_s or done < 2) and done < 4096:
-        kf, vf, uq = inputs(done)
+    while t_used < budget_s or done < 2:
         t0 = time.perf_counter()
-        pred, _ = ora.forward_mem(m, kf, vf, uq, taps=())
+        pr = fwd(pool[done % len(pool)])
         t_used += time.perf_counter() - t0
-        preds.append(pred)
+        if done < len(pool):
+            preds.append(pr)
         done += 1
-    one = {"qps": done / t_used, "n": done, "secs": t_used}
-
-    # every core: a pool of converted queries (bounded memory), threads walk it until the deadline
     cores = usable_cores()
-    per_query_bytes = 2 * H * S * D * 4
-    pool = [inputs(q) for q in range(min(B, max(cores, min(64, int(4e9 // max(per_query_bytes, 1))))))]
     counts = [0] * cores
-    deadline = [0.0]
+    t_end = time.perf_counter() + budget_s
 
     def worker(t):
         i = t
-        while time.perf_counter() < deadline[0]:
-            kf, vf, uq = pool[i % len(pool)]
-            ora.forward_mem(m, kf, vf, uq, taps=())
+        while time.perf_counter() < t_end:
+            fwd(pool[i % len(pool)])
             counts[t] += 1
             i += cores
-    threads = [threading.Thread(target=worker, args=(t,)) for t in range(cores)]
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(cores)]
     t0 = time.perf_counter()
-    deadline[0] = t0 + budget_s
-    for th in threads:
+    for th in ths:
         th.start()
-    for th in threads:
+    for th in ths:
         th.join()
     wall = time.perf_counter() - t0
-    many = {"qps": sum(counts) / wall, "n": sum(counts), "secs": wall, "cores": cores}
-    return one, many, preds
+    out = {"value": sum(counts) / wall, "unit": "queries/s", "cores": cores, "kind": "port", "flags": "gcc -O2",
+           "sample": f"{what}: pool of {len(pool)} queries, {sum(counts)} forwards in {wall:.1f} s on {cores} threads, scalar C oracle "
+                     "(oracle/_ref absent: no reference code in this figure)",
+           "one_thread": {"value": done / t_used, "sample": f"{done} forwards in {t_used:.1f} s"}}
+    if gpu_preds is not None:
+        out["pred_agree"] = int(sum(int(a == b) for a, b in zip(gpu_preds, preds)))
+        out["pred_total"] = min(len(preds), len(gpu_preds))
+    return out
+
+
+def cpu_baseline(cfg, wts, pool, what, gpu_preds=None):
+    return cpu_baseline_refport(cfg, wts, pool, what, gpu_preds) or cpu_baseline_port(cfg, wts, pool, what, gpu_preds)
 
 
 def run_bow(args, name, wl, net, cfg, wts, dev, rank, world, model):
@@ -302,70 +359,11 @@ def run_bow(args, name, wl, net, cfg, wts, dev, rank, world, model):
             res["host_inputs"]["overlapped_queries_per_s"] = B * args.steps / dt
             res["host_inputs"]["overlapped_pred_equal"] = bool(torch.equal(o2[0], out["pred"]))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        sys.path.insert(0, str(ROOT / "oracle"))
-        from pyoracle import Oracle
-        ora = Oracle()
-        m = ora.make_model(cfg, wts)
         st, qu = g["story"].astype(np.float32), g["question"].astype(np.float32)
-        preds, t_used, off, reps = [], 0.0, 0, 0
-        while t_used < 10.0 and reps < 200:
-            off = 0
-            for i in range(len(n_sen)):
-                ns = int(n_sen[i])
-                t1 = time.perf_counter()
-                p_, _ = ora.forward(m, st[off:off + ns], qu[i], taps=())
-                t_used += time.perf_counter() - t1
-                if reps == 0:
-                    preds.append(p_)
-                off += ns
-            reps += 1
-        gp = out["pred"][:len(n_sen)].cpu().numpy().tolist()
-        # the same on one thread per usable host core (the reference itself is single-threaded)
-        import threading
-        cores = usable_cores()
         offs = np.concatenate([[0], np.cumsum(n_sen)]).astype(np.int64)
-        counts = [0] * cores
-        t_end = time.perf_counter() + 8.0
-
-        def worker(t):
-            i = t
-            while time.perf_counter() < t_end:
-                k = i % len(n_sen)
-                ora.forward(m, st[offs[k]:offs[k + 1]], qu[k], taps=())
-                counts[t] += 1
-                i += cores
-        t1 = time.perf_counter()
-        ths = [threading.Thread(target=worker, args=(t,)) for t in range(cores)]
-        for th in ths:
-            th.start()
-        for th in ths:
-            th.join()
-        wall = time.perf_counter() - t1
-        # the one stage of this forward whose CPU body is live in the reference (dense_mat_fwd, lib/layer.c:2671-2696):
-        # the reference's own compiled code (oracle/_ref, prebuilt where /root/reference exists) on the story rows
-        ref_stage = None
-        try:
-            from pyoracle import Reference
-            ref = Reference()
-            t1, n_rows = time.perf_counter(), 0
-            while time.perf_counter() - t1 < 3.0:
-                for h in range(cfg["n_hop"]):
-                    ref.dense_mat_fwd(wts["w_a"][h], st, True, cfg["fmt_w"][h])
-                    ref.dense_mat_fwd(wts["w_c"][h], st, True, cfg["fmt_w"][h])
-                n_rows += st.shape[0]
-            dt = time.perf_counter() - t1
-            ref_stage = {"stage": "story embedding: dense_mat_fwd for A and C of every hop (the reference's live CPU code)",
-                         "kind": "reference", "cores": 1, "story_rows_per_s": n_rows / dt,
-                         "queries_per_s_equivalent": n_rows / dt / float(np.mean(n_sen))}
-        except (FileNotFoundError, OSError):
-            pass
-        res["cpu_baseline"] = {"value": sum(counts) / wall, "unit": "queries/s", "cores": cores, "kind": "port",
-                               "reference_stage": ref_stage,
-                               "sample": f"the 64 fixture stories, {sum(counts)} forwards in {wall:.1f} s on {cores} threads "
-                                         "(one per usable host core; the Python call overhead is part of it), scalar C oracle -O2",
-                               "one_thread": {"value": reps * len(n_sen) / t_used,
-                                              "sample": f"the 64 fixture stories x {reps} passes, {t_used:.1f} s"},
-                               "pred_agree": int(sum(int(a == b) for a, b in zip(gp, preds))), "pred_total": len(preds)}
+        pool = [(st[offs[i]:offs[i + 1]], qu[i]) for i in range(len(n_sen))]
+        res["cpu_baseline"] = cpu_baseline(cfg, wts, pool, "the 64 fixture stories (bag-of-words rows), whole forward",
+                                           gpu_preds=out["pred"][:len(n_sen)].cpu().numpy().tolist())
     return res
 
 
@@ -437,54 +435,19 @@ def run_joint(args, name, wl, cfg, wts, dev, rank, world, model):
         "accuracy_note": "random weights: predictions are compared with the oracle, not with labels",
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        sys.path.insert(0, str(ROOT / "oracle"))
-        from pyoracle import Oracle
-        ora = Oracle()
-        m = ora.make_model(cfg, wts)
         V, dd = cfg["dim_input"], int(g["dim_dict"])
         offs = np.concatenate([[0], np.cumsum(n_sen)]).astype(np.int64)
         pick = list(range(0, nfix, max(1, nfix // 200)))[:200]               # spread over the 20 tasks
-        st = [words_to_bow(g["story_words"][offs[i]:offs[i + 1]], V, dd, True) for i in pick]
-        qu = [words_to_bow(g["question_words"][i:i + 1], V, dd, False)[0] for i in pick]
+        pool = [(words_to_bow(g["story_words"][offs[i]:offs[i + 1]], V, dd, True),
+                 words_to_bow(g["question_words"][i:i + 1], V, dd, False)[0]) for i in pick]
         gp = out[0][:nfix].cpu().numpy()
-        preds, t_used, reps = [], 0.0, 0
-        while t_used < 8.0 and reps < 50:
-            for k in range(len(pick)):
-                t1 = time.perf_counter()
-                p_, _ = ora.forward(m, st[k], qu[k], taps=())
-                t_used += time.perf_counter() - t1
-                if reps == 0:
-                    preds.append(p_)
-            reps += 1
-        import threading
-        cores = usable_cores()
-        counts = [0] * cores
-        t_end = time.perf_counter() + 8.0
-
-        def worker(t):
-            i = t
-            while time.perf_counter() < t_end:
-                k = i % len(pick)
-                ora.forward(m, st[k], qu[k], taps=())
-                counts[t] += 1
-                i += cores
-        t1 = time.perf_counter()
-        ths = [threading.Thread(target=worker, args=(t,)) for t in range(cores)]
-        for th in ths:
-            th.start()
-        for th in ths:
-            th.join()
-        wall = time.perf_counter() - t1
-        res["cpu_baseline"] = {"value": sum(counts) / wall, "unit": "queries/s", "cores": cores, "kind": "port",
-                               "sample": f"{len(pick)} fixture stories spread over the 20 tasks, {sum(counts)} forwards in {wall:.1f} s on "
-                                         f"{cores} threads, scalar C oracle -O2",
-                               "one_thread": {"value": reps * len(pick) / t_used, "sample": f"{reps} passes, {t_used:.1f} s"},
-                               "pred_agree": int(sum(int(gp[i] == p) for i, p in zip(pick, preds))), "pred_total": len(preds)}
+        res["cpu_baseline"] = cpu_baseline(cfg, wts, pool, f"{len(pick)} fixture stories spread over the 20 tasks, whole forward",
+                                           gpu_preds=[int(gp[i]) for i in pick])
     hm.close()
     return res
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -493,40 +456,149 @@ def main():
     ap.add_argument("--queries", type=int, default=0, help="queries per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="default workload only: skip the |mem| = 50 figure")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_command(n_gpus: int, argv, port: int):
+    """The child command + environment additions that start `n_gpus` ranks of this file on one node.
+    Pure (no process is started): tests/test_bench_launcher.py checks it."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *argv]
+    env = {"HSA_ENABLE_IPC_MODE_LEGACY": "0", "MASTER_ADDR": "127.0.0.1", "QMANN_BENCH_SELF_LAUNCHED": "1"}
+    return cmd, env
+
+
+def self_launch(args, argv):
+    """`--gpus N` with no WORLD_SIZE: start the N ranks as a CHILD process tree and pass its output and exit
+    code through.  This parent has made no HIP call (torch is not even imported yet), and it never replaces
+    itself: a process that has initialised the GPU must not exec another program on this pool."""
+    import subprocess
+    cmd, extra = launch_command(args.gpus, argv, free_port())
+    env = dict(os.environ)
+    env.update(extra)
+    env.pop("WORLD_SIZE", None)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def main(argv=None):
+    global torch
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, argv))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU "
+                         f"(torch.distributed.run --nproc-per-node {args.gpus}) or leave WORLD_SIZE unset")
+    # QMANN_BENCH_PLUMBING=1: no GPU at all -- the launcher / rendezvous / broadcast / timing skeleton over gloo
+    # on CPU tensors (the CPU test of the N > 1 host logic; nothing is measured)
+    plumbing = os.environ.get("QMANN_BENCH_PLUMBING") == "1"
     # QMANN_BENCH_REHEARSE=1: every rank on cuda:0 over gloo -- rehearses the N > 1 host logic on a one-GPU box
     rehearse = os.environ.get("QMANN_BENCH_REHEARSE") == "1"
-    if rehearse:
-        local_rank = 0
+    import torch as _torch
+    torch = _torch
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        if rehearse:
+        if plumbing:
+            dist.init_process_group("gloo")
+        elif rehearse:
+            local_rank = 0
+            torch.cuda.set_device(0)
             dist.init_process_group("gloo")
         else:
+            torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    dev = torch.device(f"cuda:{local_rank}")
-    torch.cuda.set_device(dev)
-
-    load_pkg()
-    out = run_workload(args, args.workload, dev, rank, world)
-    # BASELINE.json quotes its metric at |mem| = 50 (the bAbI cap) and sets its target at |mem| = 10 000:
-    # the default line is the 10 000-slot configuration and carries the 50-slot figure beside it
-    if args.workload == "synth10k_d128" and not args.no_secondary:
-        sec = run_workload(argparse.Namespace(**{**vars(args), "queries": 0}), "babi_mem50", dev, rank, world)
-        if rank == 0:
-            out["mem50"] = {k: sec[k] for k in ("value", "unit", "ms_per_step", "config", "roofline", "cpu_baseline") if k in sec}
+        backend = dist.get_backend()
+    if plumbing:
+        out = run_plumbing(args, rank, world)
+    else:
+        dev = torch.device(f"cuda:{local_rank}")
+        torch.cuda.set_device(dev)
+        load_pkg()
+        out = run_workload(args, args.workload, dev, rank, world)
+        # BASELINE.json quotes its metric at |mem| = 50 (the bAbI cap) and sets its target at |mem| = 10 000:
+        # the default line is the 10 000-slot configuration and carries the 50-slot figure beside it
+        if args.workload == "synth10k_d128" and not args.no_secondary:
+            sec = run_workload(argparse.Namespace(**{**vars(args), "queries": 0}), "babi_mem50", dev, rank, world)
+            if rank == 0:
+                out["mem50"] = {k: sec[k] for k in ("value", "unit", "ms_per_step", "config", "roofline", "cpu_baseline", "ranks") if k in sec}
+                out["config"]["value_is"] = ("the |mem| = 10 000 shard (BASELINE.json configs[3], the configuration the north-star "
+                                             "roofline target is set on); `mem50` is the |mem| = 50 size the metric string names")
     if rank == 0:
+        if world > 1:
+            out["collective"] = {"backend": backend, "world_size_seen": world,
+                                 "library": "RCCL over xGMI" if backend == "nccl" else "gloo (rehearsal / plumbing: not RCCL)",
+                                 "self_launched": os.environ.get("QMANN_BENCH_SELF_LAUNCHED") == "1"}
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def rank_stats(world, dev, **vals):
+    """min / max over ranks of per-rank figures (one small all-gather; rank 0 reports them)."""
+    if world == 1:
+        return None
+    import torch.distributed as dist
+    names = sorted(vals)
+    t = torch.tensor([float(vals[n]) for n in names], dtype=torch.float64, device=dev)
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t)
+    m = torch.stack(parts).cpu().numpy()
+    return {n: {"min": float(m[:, i].min()), "max": float(m[:, i].max())} for i, n in enumerate(names)}
+
+
+def run_plumbing(args, rank, world):
+    """The N > 1 host logic with no GPU: parameters made on rank 0 and broadcast once, a barrier-bracketed timed
+    region, max over ranks, per-rank statistics -- over gloo on CPU tensors.  Measures nothing."""
+    load_pkg_parallel = importlib.util.spec_from_file_location("qmann_parallel", ROOT / "q-mann_amd" / "parallel.py")
+    par = importlib.util.module_from_spec(load_pkg_parallel)
+    load_pkg_parallel.loader.exec_module(par)
+    dev = torch.device("cpu")
+    cfg = dict(n_hop=3, dim_emb=8, dim_input=12)
+    wts = make_params(cfg, 8, 12, seed=0x51A44) if rank == 0 else None
+    wts, bcast_ms = par.broadcast_params(wts, cfg, dev, rank, world)
+    check = float(sum(float(np.abs(w).sum()) for w in wts["w_h"]) + float(np.abs(wts["w_ans"]).sum()))
+    B = 64
+    lo, hi = par.shard_range(B * world, rank, world)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    out = {"metric": "plumbing (nothing measured)", "value": 0.0, "unit": "queries/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int8", "data": "none",
+           "config": {"workload": "plumbing", "shard": [lo, hi], "parallelism": f"replicas x{world}, query-sharded"}}
+    if bcast_ms is not None:
+        out["param_broadcast_ms"] = bcast_ms
+    st = rank_stats(world, dev, param_checksum=check, shard_size=hi - lo, rank=rank)
+    if st:
+        out["ranks"] = st
+    return out
 
 
 def run_workload(args, name, dev, rank, world):
@@ -605,6 +677,7 @@ def run_workload(args, name, dev, rank, world):
         pred = run_answer(u)
         ev[i][2].record()
     torch.cuda.synchronize()
+    elapsed_local = time.perf_counter() - t0                          # this rank's own steps, before it waits for the others
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -620,12 +693,20 @@ def run_workload(args, name, dev, rank, world):
     if mode == 1:
         bytes_per_query += H * S * Dp                                 # float read-out streams every value row too
     achieved = bytes_per_query * B / (hop_ms * 1e-3) / 1e9
-    traffic = None
+    # HBM traffic from the PMC counters cannot be collected inside this process (rocprofv3 wraps the run): the figure
+    # is the one recorded by tools/summarize_profiles.py from a separate `rocprofv3 --pmc FETCH_SIZE` pass of this same
+    # command, and the line says so
+    traffic, traffic_source = None, None
     tj = ROOT / "profiles" / "traffic.json"
     if tj.exists():
         rec = json.loads(tj.read_text()).get(name)
         if rec and B == wl["B"]:
             traffic = rec["traffic_bytes_per_launch"]
+            traffic_source = f"{rec['source']} (a separate rocprofv3 --pmc FETCH_SIZE pass, x2 gfx950 correction; NOT measured in this run)"
+    # SURVEY.md 8(d) prices a query at keys + values; the quantised read-out touches only the <= 2^frac surviving
+    # value rows (bit-identical to summing all rows), so `achieved` counts the key bytes the scan must stream
+    survey_bytes = H * S * (key_row_bytes + Dp)
+    survey_gbs = survey_bytes * B / (hop_ms * 1e-3) / 1e9
 
     out = {
         "metric": "queries/sec", "value": world * B * args.steps / elapsed, "unit": "queries/s",
@@ -637,24 +718,27 @@ def run_workload(args, name, dev, rank, world):
                    "key_row_bytes": key_row_bytes, "answer_layer": wl["ans"], "dim_answer": V,
                    "parallelism": f"replicas x{world}, query-sharded"},
         "roofline": {"bound": "hbm", "kernel": "k_hops_small" if (mode != 1 and S <= 64) else KERNEL_OF_MODE[mode], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes_per_launch": bytes_per_query * B, "bytes_per_query": bytes_per_query,
+                     "bytes_counted": "keys + values (float read-out streams both)" if mode == 1 else
+                                      "key planes only: Q(p) = 0 for all but <= 2^frac rows, the value plane is not streamed",
+                     "bytes_per_query_survey_formula": survey_bytes,
+                     "frac_by_survey_formula": survey_gbs / HBM_PEAK_GBS,
                      "kernel_ms": hop_ms},
         "answer_layer": {"ms": ans_ms, "int_ops": 2.0 * B * V * D,
                          "tops": 2.0 * B * V * D / (ans_ms * 1e-3) / 1e12,
                          "mfma_int8_peak_tops": 5000.0 if wl["ans"] == "i8" else None},
     }
+    st = rank_stats(world, dev, roofline_frac=achieved / HBM_PEAK_GBS, kernel_ms=hop_ms,
+                    queries_per_s=B * args.steps / elapsed_local)
+    if st:
+        out["ranks"] = st
     if bcast_ms is not None:
         out["param_broadcast_ms"] = bcast_ms
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        one, many, preds = cpu_baseline(cfg, wts, keys, vals, u0, S, D)
-        n = one["n"]
-        gp = pred[:n].cpu().numpy().tolist()
-        out["cpu_baseline"] = {"value": many["qps"], "unit": "queries/s", "cores": many["cores"], "kind": "port",
-                               "sample": f"queries of the same batch: {many['n']} in {many['secs']:.1f} s on "
-                                         f"{many['cores']} threads (one per usable host core), scalar C oracle -O2",
-                               "one_thread": {"value": one["qps"], "sample": f"first {n} queries, {one['secs']:.1f} s"},
-                               "pred_agree": int(sum(int(a == b) for a, b in zip(gp, preds))), "pred_total": n}
+        pool = mem_pool(cfg, keys, vals, u0, S, D)
+        out["cpu_baseline"] = cpu_baseline(cfg, wts, pool, f"|mem| = {S}, D = {D}, {H} hops + answer layer",
+                                           gpu_preds=pred[:len(pool)].cpu().numpy().tolist())
     return out
 
 

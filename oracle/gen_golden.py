@@ -14,7 +14,9 @@ What is written (all small .npz files; inputs AND the reference's outputs):
   ref_sum_vec.npz    sum_vec_fwd CPU branch                             (lib/layer.c:1502-1511)
   ref_dense_mat.npz  dense_mat_fwd CPU branch                           (lib/layer.c:2671-2696)
   ref_cross_entropy.npz, ref_activation.npz                             (lib/layer.c:3190-3208, 4226-4244)
-  babi_qa1_test64.npz, babi_qa3_test16.npz, babi_joint20_test2000.npz (20-task joint set, word-index form)
+  babi_qa1_test64.npz, babi_qa3_test16.npz, babi_joint20_test2000.npz (20-task joint set, word-index form),
+  babi_qa1_test1000_words.npz, babi_joint20_test20000_words.npz (the FULL test sets of BASELINE configs 2 / 3,
+                     word indices as bytes)
                      bag-of-words vectors produced by MemN2N/sample.c from the reference's
                      pre-parsed bAbI files (data, not code)
   oracle_e2e_qa1.npz our restated oracle's full 3-hop forward on those 64 stories with seeded
@@ -35,7 +37,9 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "oracle"))
 from pyoracle import Oracle, Reference, SM_CPU_POW2  # noqa: E402
 
-GOLD = ROOT / "tests" / "golden"
+import os
+
+GOLD = Path(os.environ.get("QMANN_GOLDEN_OUT", ROOT / "tests" / "golden"))   # the regeneration test writes elsewhere
 DATA = Path("/root/reference/MemN2N/dataset")
 FORMATS = [(0, 7), (2, 5), (4, 3), (5, 2), (6, 1), (0, 0)]
 
@@ -193,6 +197,56 @@ def gen_babi(ref: Reference, sub: str, task: str, n_take: int, name: str, max_se
     return story, q, a, n_sen, dim_input
 
 
+def words_of(ref: Reference, idx, V, dict_n, W=16):
+    """Stories `idx` of the loaded test set in the compact word-index form (uint16, 0xFFFF unused; a story row's last
+    entry is its time index): what sample.c's bag-of-words rows contain, nothing else."""
+    fp = C.POINTER(C.c_float)
+    n_sen = np.array([ref.L.ref_babi_nsen(i) for i in idx], np.uint32)
+    sw = np.full((int(n_sen.sum()), W), 0xFFFF, np.uint16)
+    qw = np.full((len(idx), W), 0xFFFF, np.uint16)
+    ans = np.zeros(len(idx), np.uint16)
+    off = 0
+    for k, i in enumerate(idx):
+        s = np.zeros((int(n_sen[k]), V), np.float32); q = np.zeros(V, np.float32); a = np.zeros(V, np.float32)
+        ref.L.ref_babi_get(i, s.ctypes.data_as(fp), q.ctypes.data_as(fp), a.ctypes.data_as(fp))
+        for r, row in enumerate(s):
+            ent = [w for w in np.flatnonzero(row[:dict_n]) for _ in range(int(row[w]))]
+            t = np.flatnonzero(row[dict_n:])
+            assert len(t) == 1 and row[dict_n + t[0]] == 1.0       # one time bit per sentence (sample.c:474)
+            ent.append(dict_n + int(t[0]))
+            assert len(ent) <= W, len(ent)
+            sw[off + r, :len(ent)] = ent
+        ent = [w for w in np.flatnonzero(q) for _ in range(int(q[w]))]
+        assert len(ent) <= W
+        qw[k, :len(ent)] = ent
+        assert a.sum() in (0.0, 1.0)
+        ans[k] = int(a.argmax()) if a.sum() == 1.0 else 0xFFFF
+        off += int(n_sen[k])
+    return sw, qw, ans, n_sen
+
+
+def save_words_u8(name, sw, qw, ans, n_sen, **meta):
+    """Full test sets are kept as bytes (dictionaries + time slots stay below 255; 0xFF = unused, answer 0xFF = no
+    label), trimmed to the widest row: indices only, a few hundred KB."""
+    assert int(sw[sw != 0xFFFF].max()) < 255 and int(qw[qw != 0xFFFF].max()) < 255
+    ws = int((sw != 0xFFFF).sum(1).max()); wq = int((qw != 0xFFFF).sum(1).max())
+    to8 = lambda a: np.where(a == 0xFFFF, 0xFF, a).astype(np.uint8)
+    np.savez_compressed(GOLD / name, story_words=to8(sw[:, :ws]), question_words=to8(qw[:, :wq]), answer=to8(ans),
+                        n_sen=n_sen.astype(np.uint8), **meta)
+
+
+def gen_babi_full_words(ref: Reference, sub: str, task: str, name: str, max_sen_len=50):
+    """BASELINE config 2 data in full: every test story of one task (qa1: 1 000) in word-index form."""
+    tr = str(DATA / sub / f"{task}_train_set").encode()
+    te = str(DATA / sub / f"{task}_test_set").encode()
+    di, dd, ml = C.c_uint(), C.c_uint(), C.c_uint()
+    n = ref.L.ref_babi_load(tr, te, max_sen_len, 200000, 20000, C.byref(di), C.byref(dd), C.byref(ml))
+    assert n > 0, n
+    sw, qw, ans, n_sen = words_of(ref, range(n), di.value, dd.value)
+    save_words_u8(name, sw, qw, ans, n_sen, dim_input=np.uint32(di.value), dim_dict=np.uint32(dd.value),
+                  max_line=np.uint32(ml.value))
+
+
 def gen_babi_joint(ref: Reference, per_task: int = 100, name: str = "babi_joint20_test2000.npz", max_sen_len=50):
     """BASELINE config 3 data: the reference's joint files are missing (.MISSING_LARGE_BLOBS), so the joint
     sets are the 20 en_1k_parsed files back to back in the same record format (written to a temporary
@@ -224,34 +278,16 @@ def gen_babi_joint(ref: Reference, per_task: int = 100, name: str = "babi_joint2
     assert n == 20 * n_test_per_task, n
     V, dict_n = di.value, dd.value
     fp = C.POINTER(C.c_float)
+    full = per_task is None
+    per_task = n_test_per_task if full else per_task
     take = [t * n_test_per_task + j for t in range(20) for j in range(per_task)]
-    n_sen = np.array([ref.L.ref_babi_nsen(i) for i in take], np.uint32)
-    W = 16
-    sw = np.full((int(n_sen.sum()), W), 0xFFFF, np.uint16)
-    qw = np.full((len(take), W), 0xFFFF, np.uint16)
-    ans = np.zeros(len(take), np.uint16)
-    off = 0
-    for k, i in enumerate(take):
-        s = np.zeros((int(n_sen[k]), V), np.float32); q = np.zeros(V, np.float32); a = np.zeros(V, np.float32)
-        ref.L.ref_babi_get(i, s.ctypes.data_as(fp), q.ctypes.data_as(fp), a.ctypes.data_as(fp))
-        for r, row in enumerate(s):
-            ent = [w for w in np.flatnonzero(row[:dict_n]) for _ in range(int(row[w]))]
-            t = np.flatnonzero(row[dict_n:])
-            assert len(t) == 1 and row[dict_n + t[0]] == 1.0       # one time bit per sentence (sample.c:474)
-            ent.append(dict_n + int(t[0]))
-            assert len(ent) <= W, len(ent)
-            sw[off + r, :len(ent)] = ent
-        ent = [w for w in np.flatnonzero(q) for _ in range(int(q[w]))]
-        assert len(ent) <= W
-        qw[k, :len(ent)] = ent
-        # a test answer that never occurs in the training files (e.g. an unseen item list in task 8) has no
-        # dictionary entry: sample.c leaves its vector all zero ("NO WORD IN DICT"); kept as 0xFFFF = no label
-        assert a.sum() in (0.0, 1.0)
-        ans[k] = int(a.argmax()) if a.sum() == 1.0 else 0xFFFF
-        off += int(n_sen[k])
-    np.savez_compressed(GOLD / name, story_words=sw, question_words=qw, answer=ans, n_sen=n_sen,
-                        dim_input=np.uint32(V), dim_dict=np.uint32(dict_n), max_line=np.uint32(ml.value),
-                        task=np.repeat(np.arange(1, 21, dtype=np.uint8), per_task))
+    sw, qw, ans, n_sen = words_of(ref, take, V, dict_n)
+    meta = dict(dim_input=np.uint32(V), dim_dict=np.uint32(dict_n), max_line=np.uint32(ml.value),
+                task=np.repeat(np.arange(1, 21, dtype=np.uint8), per_task))
+    if full:
+        save_words_u8(name, sw, qw, ans, n_sen, **meta)
+    else:
+        np.savez_compressed(GOLD / name, story_words=sw, question_words=qw, answer=ans, n_sen=n_sen, **meta)
     for f in tmp.iterdir():
         f.unlink()
     tmp.rmdir()
@@ -320,8 +356,12 @@ def main():
     # the joint dictionary (about 170 words) needs the reference's joint-task limits: a second build of its
     # dataset code with MAX_DICT_LEN 192 / MAX_SEN_LEN 64 (`make -C oracle joint`)
     import subprocess
-    subprocess.run(["make", "-C", str(ROOT / "oracle"), "joint", f"HIP_LIB={ROOT / 'q-mann_amd' / 'lib' / 'libqmann_hip.so'}"], check=True)
+    subprocess.run(["make", "-C", str(ROOT / "oracle"), "joint"], check=True, stdout=subprocess.DEVNULL)
     gen_babi_joint(Reference(ROOT / "oracle" / "_ref" / "libqmann_ref_joint.so"), max_sen_len=64)
+    # the full real-data sets of BASELINE configs 2 and 3: 1 000 qa1 test stories, 20 000 joint ones
+    gen_babi_full_words(Reference(), "en_10k_parsed", "qa1_single-supporting-fact", "babi_qa1_test1000_words.npz")
+    gen_babi_joint(Reference(ROOT / "oracle" / "_ref" / "libqmann_ref_joint.so"), per_task=None,
+                   name="babi_joint20_test20000_words.npz", max_sen_len=64)
     for p in sorted(GOLD.glob("*.npz")):
         print(f"{p.name:28s} {p.stat().st_size:8d} B")
 

@@ -351,3 +351,59 @@ class Reference:
         x = np.ascontiguousarray(x, np.float32); out = np.empty_like(x)
         self.L.ref_activation_fwd(_fp(x), _fp(out), x.size, act)
         return out
+
+
+class RefForward:
+    """oracle/ref_forward.c: the test-phase forward composed from the reference's LIVE C functions
+    (dense_mat_fwd, softmax_fwd, sum_vec_fwd, hamming_similarity*) plus the port for the ops whose CPU
+    bodies are dead -- bench.py's "reference+port" CPU baseline.  flags: "O0" (the reference's own
+    `gcc -w`) or "O2".  The model struct is Oracle.make_model's (softmax_variant must be a CPU form)."""
+
+    def __init__(self, flags: str = "O2"):
+        path = HERE / "_ref" / f"libqmann_refcpu_{flags}.so"
+        if not path.exists():
+            raise FileNotFoundError(f"{path} missing: run `make -C oracle refcpu` where /root/reference exists")
+        L = self.L = C.CDLL(str(path))
+        u = C.c_uint
+        pp = C.POINTER(_f32p)
+        L.rf_create.restype = C.c_void_p; L.rf_create.argtypes = [C.POINTER(QoModel), u]
+        L.rf_destroy.restype = None; L.rf_destroy.argtypes = [C.c_void_p]
+        L.rf_forward.restype = u; L.rf_forward.argtypes = [C.c_void_p, _f32p, u, _f32p, _f32p]
+        L.rf_forward_mem.restype = u; L.rf_forward_mem.argtypes = [C.c_void_p, _f32p, _f32p, u, _f32p, _f32p]
+        L.rf_time.restype = C.c_double
+        L.rf_time.argtypes = [C.POINTER(QoModel), u, pp, pp, pp, C.POINTER(u), u, u, C.c_double,
+                              C.POINTER(C.c_ulong), C.POINTER(C.c_double), C.POINTER(u)]
+        L.rf_build_flags.restype = C.c_char_p
+        self.flags = L.rf_build_flags().decode()
+
+    def forward(self, m, story, question, max_sen=None):
+        story = np.ascontiguousarray(story, np.float32); question = np.ascontiguousarray(question, np.float32)
+        ctx = self.L.rf_create(C.byref(m), max_sen or max(1, story.shape[0]))
+        u = np.empty(m.dim_emb, np.float32)
+        pred = self.L.rf_forward(ctx, _fp(story), story.shape[0], _fp(question), _fp(u))
+        self.L.rf_destroy(ctx)
+        return int(pred), u
+
+    def forward_mem(self, m, keys, vals, u0):
+        keys = np.ascontiguousarray(keys, np.float32); vals = np.ascontiguousarray(vals, np.float32)
+        u0 = np.ascontiguousarray(u0, np.float32)
+        ctx = self.L.rf_create(C.byref(m), max(1, keys.shape[1]))
+        u = np.empty(m.dim_emb, np.float32)
+        pred = self.L.rf_forward_mem(ctx, _fp(keys), _fp(vals), keys.shape[1], _fp(u0), _fp(u))
+        self.L.rf_destroy(ctx)
+        return int(pred), u
+
+    def time(self, m, pool, n_threads: int, seconds: float):
+        """pool: list of (story [n_sen][V], question [V]) or of (keys [H][S][D], vals [H][S][D], u0 [D]).
+        Returns dict(qps, n, secs, preds) -- a C pthread loop over the pool for about `seconds`."""
+        mem = len(pool[0]) == 3
+        keep = [[np.ascontiguousarray(x, np.float32) for x in item] for item in pool]
+        n = len(keep)
+        arr = lambda k: (_f32p * n)(*[_fp(item[k]) for item in keep])
+        a, b = arr(0), arr(1)
+        u0 = arr(2) if mem else None
+        ns = (C.c_uint * n)(*[(item[0].shape[1] if mem else item[0].shape[0]) for item in keep])
+        preds = (C.c_uint * n)(*([0xFFFFFFFF] * n))
+        done, wall = C.c_ulong(0), C.c_double(0.0)
+        qps = self.L.rf_time(C.byref(m), max(ns), a, b, u0, ns, n, n_threads, seconds, C.byref(done), C.byref(wall), preds)
+        return dict(qps=float(qps), n=int(done.value), secs=float(wall.value), preds=list(preds))
