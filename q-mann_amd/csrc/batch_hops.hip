@@ -27,7 +27,7 @@
 //   4. linear map H.u (int8 [D][Dp], L2-resident) and u' = Q(Q(Hu) + Q(o)).
 //
 // All integer work is exact; the only floating-point step is the softmax table.
-#include "hops_small.h"
+#include "hops_lean.h"
 
 namespace {
 
@@ -253,6 +253,11 @@ int qmann_hops_i8(const qmann_net *net, const int8_t *keys, const int8_t *vals, 
         return qmann_hops_float_impl(a, net->dim_emb_pad, max_slots, n_query, stream);
 
     hipStream_t st = (hipStream_t)stream;
+    if (lean_supported(a, max_slots, 64)) {                 // hops_lean.h
+        launch_lean<kModeFixed, 8>(a, max_slots, n_query, st);
+        QM_LAUNCH_CHECK();
+        return QMANN_OK;
+    }
     if (max_slots <= (uint32_t)kWave) {                     // hops_small.h
         if (net->dim_emb_pad == 64) k_hops_small<4, 4, kModeFixed, 8><<<n_query, kWave, 0, st>>>(a, 64);
         else if (net->dim_emb_pad == 128) k_hops_small<8, 8, kModeFixed, 8><<<n_query, kWave, 0, st>>>(a, 128);

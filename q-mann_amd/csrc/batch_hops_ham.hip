@@ -23,7 +23,7 @@
 // so they are kept as int16 in LDS.  V0 evaluates the softmax once per distinct count (histogram),
 // the other modes per slot (max, sum of exp in double, quotient), as lib/layer_cuda.cu:1969-2060 does.
 #include "ham_common.h"
-#include "hops_small.h"
+#include "hops_lean.h"
 
 namespace {
 
@@ -313,6 +313,11 @@ int qmann_hops_appx_impl(const qmann_net *net, const int8_t *keys, const int8_t 
     if (n_query == 0) return QMANN_OK;
     if (n_query >= (1u << 24)) return QMANN_ERANGE;      // one workgroup per query: a launch holds < 2^32 threads
     hipStream_t st = (hipStream_t)stream;
+    if (lean_supported(a, max_slots, 64)) {                 // hops_lean.h
+        launch_lean<kModeAppx, 8>(a, max_slots, n_query, st);
+        QM_LAUNCH_CHECK();
+        return QMANN_OK;
+    }
     if (max_slots <= (uint32_t)kWave) {                     // hops_small.h
         if (net->dim_emb_pad == 64) k_hops_small<4, 4, kModeAppx, 8><<<n_query, kWave, 0, st>>>(a, 64);
         else if (net->dim_emb_pad == 128) k_hops_small<8, 8, kModeAppx, 8><<<n_query, kWave, 0, st>>>(a, 128);
@@ -344,6 +349,14 @@ int qmann_hops_hambytes_impl(const qmann_net *net, const int8_t *keys, const int
     if (n_query == 0) return QMANN_OK;
     if (n_query >= (1u << 24)) return QMANN_ERANGE;      // one workgroup per query: a launch holds < 2^32 threads
     hipStream_t st = (hipStream_t)stream;
+    if (lean_supported(a, max_slots, Dp)) {                 // hops_lean.h
+        if (v1) { if (nb == 1) launch_lean<kModeV1Bytes, 1>(a, max_slots, n_query, st); else if (nb == 2) launch_lean<kModeV1Bytes, 2>(a, max_slots, n_query, st);
+                  else if (nb == 4) launch_lean<kModeV1Bytes, 4>(a, max_slots, n_query, st); else launch_lean<kModeV1Bytes, 8>(a, max_slots, n_query, st); }
+        else { if (nb == 1) launch_lean<kModeV0Bytes, 1>(a, max_slots, n_query, st); else if (nb == 2) launch_lean<kModeV0Bytes, 2>(a, max_slots, n_query, st);
+               else if (nb == 4) launch_lean<kModeV0Bytes, 4>(a, max_slots, n_query, st); else launch_lean<kModeV0Bytes, 8>(a, max_slots, n_query, st); }
+        QM_LAUNCH_CHECK();
+        return QMANN_OK;
+    }
 #define QM_HAMB(DP, NB)                                                                                   \
     do {                                                                                                  \
         constexpr int L = DP / 16;                                                                        \

@@ -1,0 +1,380 @@
+// hops_lean.h -- every hop of a query whose memory has at most 64 slots and whose rows are 64 bytes (bAbI
+// width: D <= 64), one wavefront per query, written for instruction count: at these sizes the chip is bound by
+// VALU issue (SQ_INSTS_VALU x 4 cycles accounts for the whole run time of hops_small.h), not by memory.
+//
+// Same arithmetic, stage by stage, as hops_small.h / the streaming kernels (which remain the reference
+// implementation inside this library and the path for taps); what changes is where the work sits:
+//   * the hop state u lives in a register (lane c owns column c), never in LDS as floats;
+//   * the per-lane constants of the packed multiply (ScanConst: 16 columns per lane) are not rebuilt by every lane
+//     from 16 codes (~200 VALU per hop): lane c prepares column c once (magnitude pre-shifted, sign byte) and
+//     stores it into an LDS image laid out so that a lane's ue / uo / s7 words are three 16-byte loads;
+//   * value rows go from global memory straight into the wavefront's LDS tile (global_load_lds_dwordx4), keys and
+//     linear-map rows are requested a hop ahead into registers;
+//   * the read-out and the hop update work on integer codes (no float round trips);
+//   * workgroups are persistent (a wavefront walks queries q, q + stride, ...), so per-workgroup tables -- exp of
+//     the 255 possible score differences per hop, the linear maps -- are built once.
+// Selected by qmann_hops_i8 when no taps are requested (see lean_supported()).
+#pragma once
+#include "hops_small.h"
+
+#include <stdlib.h>
+
+namespace {
+
+constexpr int kLeanWaves = 8;                       // wavefronts (= queries in flight) per workgroup
+constexpr int kLeanBlock = kLeanWaves * kWave;
+
+// per-workgroup LDS: exp tables [n_hop][256] float, linear maps [n_hop][64][64] sign-magnitude bytes
+// per-wavefront LDS slice: value tile [rows_pad][64], then the small arrays below
+constexpr uint32_t kLwE = 0;            // u16 [32]  pre-shifted |u| of even columns (ScanConst::ue image)
+constexpr uint32_t kLwO = 64;           // u16 [32]  odd columns (ScanConst::uo image)
+constexpr uint32_t kLwS = 128;          // u8  [64]  0x80 where u < 0 (ScanConst::s7 image)
+constexpr uint32_t kLwUb = 192;         // u8  [64]  sign-magnitude Q_att(u) bytes (Hamming forms)
+constexpr uint32_t kLwUn = 0;           // f32 [64]  new u (row-group layout -> column layout); reuses the four images above,
+                                        //            which are dead once the linear map's constants sit in registers
+constexpr uint32_t kLwSc = 256;         // i16 [64]  scores, slot r
+constexpr uint32_t kLwOc = 384;         // i16 [64]  read-out codes o[c]
+constexpr uint32_t kLwBytes = 512;
+
+struct LeanArgs {
+    uint32_t rows_pad;        // value-tile rows per wavefront (max_slots rounded up to 16)
+    uint32_t exp_table;       // 1: fixed-point scores, e^x base, no scale layer: exp(-d . unit) comes from a table
+    uint32_t lm_in_lds;       // 1: the linear maps are staged in LDS
+};
+
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// lane c publishes column c of the packed-multiply constants for operand code k (word length wl of the matrix
+// format, frac fv of the vector format): see ScanConst / make_scan_const in hops_common.h
+__device__ __forceinline__ void publish_scan_const(uint8_t *lw, uint32_t lane, int k, uint32_t wl, int fv)
+{
+    const int pre = (int)(16u - wl) - fv;
+    const uint32_t a = (uint32_t)(k < 0 ? -k : k) << pre;
+    const uint16_t m = (uint16_t)(a > 0xFFFFu ? 0xFFFFu : a);
+    *(uint16_t *)(lw + ((lane & 1u) ? kLwO : kLwE) + (lane >> 1) * 2) = m;
+    lw[kLwS + lane] = (uint8_t)(k < 0 ? 0x80u : 0u);
+}
+__device__ __forceinline__ uint32_t fetch_scan_const(ScanConst &c, const uint8_t *lw, uint32_t chunk, uint32_t wl)
+{
+    const i32x4 e = *(const i32x4 *)(lw + kLwE + chunk * 16);
+    const i32x4 o = *(const i32x4 *)(lw + kLwO + chunk * 16);
+    const i32x4 s = *(const i32x4 *)(lw + kLwS + chunk * 16);
+#pragma unroll
+    for (int d = 0; d < 4; d++) { c.ue[d] = (uint32_t)e[d]; c.uo[d] = (uint32_t)o[d]; c.s7[d] = (uint32_t)s[d]; }
+    return 16u - wl;
+}
+
+// Word length 7 (every 8-bit configuration): the per-product clamp at 127 is the SIGNED 16-bit saturation of
+// |k| . (|u| << (8 - frac_v)) (32767 >> 8 = 127), and the quotient is then the product's high byte: no shift, and
+// one v_perm_b32 gathers the four high bytes.  9 VALU operations per 4 key bytes instead of 11.
+__device__ __forceinline__ uint32_t pk_mul_sat_i16(uint32_t a, uint32_t b)
+{
+    uint32_t d;
+    asm("v_pk_mad_i16 %0, %1, %2, 0 clamp" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ int lane_row_sum7(const i32x4 x, const ScanConst &c)
+{
+    int acc = 0;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const uint32_t w = (uint32_t)x[d];
+        const uint32_t pe = pk_mul_sat_i16(w & 0x007F007Fu, c.ue[d]);           // bytes 0 and 2
+        const uint32_t po = pk_mul_sat_i16((w >> 8) & 0x007F007Fu, c.uo[d]);    // bytes 1 and 3
+        const uint32_t tb = __builtin_amdgcn_perm(po, pe, 0x07030501u);         // the four high bytes, in column order
+        const uint32_t sb = (w ^ c.s7[d]) & 0x80808080u;
+        const uint32_t sg = __builtin_amdgcn_perm(0x01010101u, 0x01010101u, sb);
+        acc = __builtin_amdgcn_sdot4((int)tb, (int)sg, acc, false);
+    }
+    return acc;
+}
+// W7: every matrix format of the launch (attention and linear-map weights) has word length 7
+template <bool W7>
+__device__ __forceinline__ void publish_const(uint8_t *lw, uint32_t lane, int k, uint32_t wl, int fv)
+{
+    if (!W7) { publish_scan_const(lw, lane, k, wl, fv); return; }
+    const uint32_t a = (uint32_t)(k < 0 ? -k : k) << (8 - fv);                  // fv <= 7
+    *(uint16_t *)(lw + ((lane & 1u) ? kLwO : kLwE) + (lane >> 1) * 2) = (uint16_t)(a > 0x7FFFu ? 0x7FFFu : a);
+    lw[kLwS + lane] = (uint8_t)(k < 0 ? 0x80u : 0u);
+}
+template <bool W7>
+__device__ __forceinline__ int lane_sum_w(const i32x4 x, const ScanConst &c, uint32_t sh)
+{
+    return W7 ? lane_row_sum7(x, c) : lane_row_sum(x, c, sh);
+}
+
+template <int MODE, int NB, bool W7>
+__global__ void __launch_bounds__(kLeanBlock)
+k_hops_lean(const HopArgs a, const LeanArgs la)
+{
+    constexpr uint32_t Dp = 64, LPR = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const uint32_t sub = lane >> 2, chunk = lane & 3u;
+    const uint32_t D = a.D, H = a.n_hop;
+    float *etab = (float *)smem;                                        // [H][256]
+    uint8_t *lmap = smem + (la.exp_table ? H * 1024u : 0u);             // [H][64][64]
+    uint8_t *wbase = lmap + (la.lm_in_lds ? H * 4096u : 0u);
+    const uint32_t wslice = la.rows_pad * 64u + kLwBytes;
+    uint8_t *vt = wbase + wave * wslice;                                // value tile
+    uint8_t *lw = vt + la.rows_pad * 64u;                               // small arrays
+
+    // ---- per-workgroup tables -------------------------------------------------------------------
+    if (la.exp_table) {
+        for (uint32_t i = tid; i < H * 256u; i += kLeanBlock) {
+            const uint32_t h = i >> 8, d = i & 255u;
+            // score - max on the score grid: -(d . 2^-frac_att), exact; the same call the per-slot form makes
+            etab[i] = sm_exp(-qm_scale_down((float)d, a.att[h].frac), SmCfg{a.softmax_base, false, false, 1.0f});
+        }
+    }
+    if (la.lm_in_lds) {
+        for (uint32_t h = 0; h < H; h++) {
+            const i32x4 *src = (const i32x4 *)a.lin_map[h];
+            for (uint32_t i = tid; i < 256u; i += kLeanBlock) {
+                i32x4 x = {0, 0, 0, 0};
+                if (i * 16u < D * Dp) x = src[i];
+                *(i32x4 *)(lmap + h * 4096u + i * 16u) = x;
+            }
+        }
+    }
+    __syncthreads();
+
+    const size_t q_stride = (size_t)gridDim.x * kLeanWaves, n_query = a.rows_total;   // (rows_total carries the query count, see launcher)
+    // The next query's first key tile and its u0 are requested during the current query's last hop (its row offsets
+    // a query earlier still), so a wavefront does not sit through a cold HBM round trip at every query start.
+    size_t q = (size_t)blockIdx.x * kLeanWaves + wave;
+    if (q >= n_query) return;
+    uint32_t r0 = a.row_off[q], S;
+    {
+        const uint32_t S_in = a.row_off[q + 1] - r0;
+        S = S_in < (uint32_t)kWave ? S_in : (uint32_t)kWave;
+    }
+    i32x4 kq[4];
+    float u_next;
+    // keys of hop h of the query whose rows start at `base` (S_ rows)
+    auto load_keys_of = [&](uint32_t h, uint32_t base, uint32_t S_) {
+        const uint8_t *kb = (const uint8_t *)a.keys + (size_t)h * a.key_hop_stride + (size_t)base * Dp + chunk * 16;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t r = j * 16 + sub;
+            kq[j] = i32x4{0, 0, 0, 0};
+            if (r < S_) kq[j] = *(const i32x4 *)(kb + (size_t)r * Dp);
+        }
+    };
+    load_keys_of(0, r0, S);
+    u_next = (lane < D) ? a.u0[q * D + lane] : 0.0f;
+    for (; q < n_query; q += q_stride) {
+        const size_t qn = q + q_stride;
+        uint32_t r0n = 0, Sn = 0;
+        if (qn < n_query) {
+            r0n = a.row_off[qn];
+            const uint32_t S_in = a.row_off[qn + 1] - r0n;
+            Sn = S_in < (uint32_t)kWave ? S_in : (uint32_t)kWave;
+        }
+
+        // a hop's value rows: global memory -> this wavefront's LDS tile, 1 KiB (16 rows) per instruction
+        auto load_vals = [&](uint32_t h) {
+            const uint8_t *vb = (const uint8_t *)a.vals + (size_t)h * a.hop_stride + (size_t)r0 * Dp + chunk * 16;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t r = j * 16 + sub;
+                if (j * 16 < (int)S) {                                    // wavefront-uniform
+                    if (r < S)
+                        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(vb + (size_t)r * Dp),
+                                                         (void __attribute__((address_space(3))) *)(vt + j * 1024), 16, 0, 0);
+                }
+            }
+        };
+        float u = u_next;
+
+        for (uint32_t h = 0; h < H; h++) {
+            const QFmt fa = a.act[h], fm = a.att[h], fb = a.bin, fw = a.w[h];
+            const int maxa = (1 << (fa.iwl + fa.frac)) - 1;
+            const bool relu = hop_relu(a, h);
+            load_vals(h);
+            i32x4 hq[4];
+            if (a.en_lin_map && !la.lm_in_lds) {
+                const uint8_t *hb = (const uint8_t *)a.lin_map[h] + chunk * 16;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t r = j * 16 + sub;
+                    hq[j] = i32x4{0, 0, 0, 0};
+                    if (r < D) hq[j] = *(const i32x4 *)(hb + (size_t)r * Dp);
+                }
+            }
+            // ---- column c: operand codes ---------------------------------------------------------
+            const int kb_code = (lane < D) ? qm_code_or_sign(u, fb.iwl, fb.frac) : 0;        // Q_bin(u): linear map (and fixed scores)
+            const uint32_t wl_m = fm.iwl + fm.frac, wl_w = fw.iwl + fw.frac;
+            if (MODE == kModeFixed) {
+                int ka = kb_code;
+                if (relu && ka < 0) ka = (fb.iwl + fb.frac == 0) ? 1 : 0;                    // see make_scan_const
+                publish_const<W7>(lw, lane, ka, wl_m, (int)fb.frac);
+            } else {
+                const float ua = relu_if(u, relu);
+                const int kc = (lane < D) ? qm_code(ua, fm.iwl, fm.frac) : 0;
+                lw[kLwUb + lane] = (uint8_t)((uint32_t)(kc < 0 ? -kc : kc) | ((lane < D && !(ua >= 0.0f)) ? 0x80u : 0u));
+            }
+            wave_sync();
+
+            // ---- scores ----------------------------------------------------------------------------
+            ScanConst csc;
+            uint32_t csh = 0;
+            float unit = 1.0f;
+            auto scan = [&](auto lane_sum, int lim) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (j * 16 < (int)S) {                                // wavefront-uniform
+                        const int v = row_lanes_sum<LPR>(lane_sum(kq[j]));
+                        if (chunk == 0) *(int16_t *)(lw + kLwSc + (j * 16 + sub) * 2) = (int16_t)(v > lim ? lim : (v < -lim ? -lim : v));
+                    }
+                }
+            };
+            if (MODE == kModeFixed) {
+                unit = qm_scale_down(1.0f, fm.frac);
+                csh = fetch_scan_const(csc, lw, chunk, wl_m);
+                scan([&](const i32x4 x) { return lane_sum_w<W7>(x, csc, csh); }, (1 << wl_m) - 1);
+            } else if (MODE == kModeAppx) {
+                unit = 1.0f / 1024.0f;
+                AppxConst c;
+                make_appx_const(c, lw + kLwUb, chunk * 16, D);
+                scan([&](const i32x4 x) { return appx_lane_sum(x, c); }, 1 << (fm.iwl + 10));
+            } else {
+                if (MODE == kModeV1Bytes) unit = qm_scale_down(1.0f, NB);
+                HamByteConst c;
+                make_hambyte_const<MODE, NB>(c, lw + kLwUb, chunk * 16, D);
+                scan([&](const i32x4 x) { return hambyte_lane_sum<MODE, NB>(x, c); }, 32767);
+            }
+            wave_sync();
+
+            // ---- softmax over slots, slot r in lane r ----------------------------------------------
+            const bool live = lane < S;
+            const int code = live ? (int)*(const int16_t *)(lw + kLwSc + lane * 2) : 0;
+            const SmCfg smc = sm_cfg(a, h);
+            float e;
+            double total;
+            if (MODE == kModeFixed && la.exp_table) {
+                int mxc = live ? code : -32768;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(mxc, o); mxc = t > mxc ? t : mxc; }
+                e = live ? etab[h * 256u + (uint32_t)(mxc - code)] : 0.0f;
+            } else {
+                const float xs = live ? sm_scaled((float)code * unit, smc) : -INFINITY;
+                float mx = xs;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+                e = live ? sm_exp(xs - mx, smc) : 0.0f;
+            }
+            total = (double)e;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+            const float p = live ? sm_quot(e, total, smc) : 0.0f;
+            // Q(p) for 0 <= p <= 1: trunc(p . 2^frac), saturated (qm_code without the cases a probability cannot reach)
+            int kp = (int)__builtin_ldexpf(p, (int)fa.frac);
+            kp = kp > maxa ? maxa : kp;
+
+            // ---- read-out over the rows whose weight code is non-zero (lane c owns column c) ---------
+            __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0): the value tile has landed
+            wave_sync();
+            // in flight during the read-out and the linear map: the next hop's keys, or the next query's first keys
+            if (h + 1 < H) load_keys_of(h + 1, r0, S);
+            else if (qn < n_query) {
+                load_keys_of(0, r0n, Sn);
+                u_next = (lane < D) ? a.u0[qn * D + lane] : 0.0f;
+            }
+            int acc = 0;
+            for (uint64_t m = __ballot(kp != 0); m; m &= m - 1) {
+                const int r = __builtin_ctzll(m);
+                const int kpr = __builtin_amdgcn_readlane(kp, r);
+                const uint32_t b = vt[(uint32_t)r * Dp + lane];
+                uint32_t t = ((uint32_t)kpr * (b & 0x7Fu)) >> fa.frac;   // |Q(p) . v| / 2^frac toward zero
+                t = t > (uint32_t)maxa ? (uint32_t)maxa : t;
+                acc += (b & 0x80u) ? -(int)t : (int)t;
+            }
+            acc = acc > maxa ? maxa : (acc < -maxa ? -maxa : acc);
+            *(int16_t *)(lw + kLwOc + lane * 2) = (int16_t)acc;
+
+            // ---- linear map + hop update -------------------------------------------------------------
+            if (a.en_lin_map) {
+                const bool reuse = MODE == kModeFixed && wl_w == wl_m && !relu;
+                if (!reuse) {
+                    wave_sync();                                          // every lane is done with the previous image
+                    publish_const<W7>(lw, lane, kb_code, wl_w, (int)fb.frac);
+                }
+                wave_sync();
+                if (!reuse) csh = fetch_scan_const(csc, lw, chunk, wl_w);
+                const int maxw = (1 << wl_w) - 1;
+                const uint32_t n_it = (D + 15u) / 16u;
+                int keep = 0;
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    if ((uint32_t)t < n_it) {                             // wavefront-uniform
+                        i32x4 x;
+                        if (la.lm_in_lds) x = *(const i32x4 *)(lmap + h * 4096u + (t * 16 + sub) * 64u + chunk * 16u);
+                        else x = hq[t];
+                        const int s = row_lanes_sum<LPR>(lane_sum_w<W7>(x, csc, csh));
+                        if (chunk == (uint32_t)t) keep = s;
+                    }
+                }
+                // lane (sub, chunk) now holds the sum of row o = 16 . chunk + sub
+                const uint32_t o_i = chunk * 16u + sub;
+                const int kw = keep > maxw ? maxw : (keep < -maxw ? -maxw : keep);       // Qw of the row sum
+                const uint32_t mag = (uint32_t)(kw < 0 ? -kw : kw);
+                const uint32_t ma = fa.frac >= fw.frac ? mag << (fa.frac - fw.frac) : mag >> (fw.frac - fa.frac);
+                const int lam = ma > (uint32_t)maxa ? maxa : (int)ma;                  // Qa of that value
+                int un = (kw < 0 ? -lam : lam) + (int)*(const int16_t *)(lw + kLwOc + o_i * 2);
+                un = un > maxa ? maxa : (un < -maxa ? -maxa : un);
+                *(float *)(lw + kLwUn + o_i * 4) = qm_scale_down((float)un, fa.frac);
+                wave_sync();
+                u = (lane < D) ? *(const float *)(lw + kLwUn + lane * 4) : 0.0f;
+            } else {
+                int un = ((lane < D) ? qm_code(u, fa.iwl, fa.frac) : 0) + acc;
+                un = un > maxa ? maxa : (un < -maxa ? -maxa : un);
+                u = qm_scale_down((float)un, fa.frac);
+            }
+            wave_sync();                                                  // the next hop rewrites the images
+        }
+        if (lane < D) a.u_out[q * D + lane] = relu_if(u, a.en_non_lin != 0);
+        r0 = r0n; S = Sn;
+    }
+}
+
+// what the lean kernel covers (everything else keeps the general kernels)
+inline bool lean_supported(const HopArgs &a, uint32_t max_slots, uint32_t key_row_bytes)
+{
+    return a.Dp == 64 && key_row_bytes == 64 && max_slots <= (uint32_t)kWave && !a.tap_codes && !a.tap_scores && !a.tap_probs &&
+           !a.tap_o && !a.tap_u && getenv("QMANN_NO_LEAN") == nullptr;
+}
+
+template <int MODE, int NB, bool W7>
+inline void launch_lean_w(HopArgs a, uint32_t max_slots, uint32_t n_query, hipStream_t st)
+{
+    LeanArgs la{};
+    la.rows_pad = ((max_slots ? max_slots : 1u) + 15u) & ~15u;
+    la.exp_table = (MODE == kModeFixed && a.softmax_base == QMANN_SOFTMAX_EXP && !a.softmax_shift && !a.en_att_scale) ? 1u : 0u;
+    la.lm_in_lds = a.en_lin_map ? 1u : 0u;
+    a.rows_total = n_query;                                               // (the kernel has no taps: the field carries the query count)
+    const size_t lds = (la.exp_table ? a.n_hop * 1024u : 0u) + (la.lm_in_lds ? a.n_hop * 4096u : 0u) +
+                       (size_t)kLeanWaves * (la.rows_pad * 64u + kLwBytes);
+    if (lds > kLdsDefaultLimit)
+        QM_HIP(hipFuncSetAttribute((const void *)k_hops_lean<MODE, NB, W7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const uint32_t need = (n_query + kLeanWaves - 1) / kLeanWaves;
+    const uint32_t resident = 256u * (uint32_t)(160u * 1024u / (lds + 256u) > 8 ? 8 : 160u * 1024u / (lds + 256u));
+    k_hops_lean<MODE, NB, W7><<<need < resident ? need : resident, kLeanBlock, lds, st>>>(a, la);
+}
+
+template <int MODE, int NB>
+inline void launch_lean(const HopArgs &a, uint32_t max_slots, uint32_t n_query, hipStream_t st)
+{
+    bool w7 = true;
+    for (uint32_t h = 0; h < a.n_hop; h++)
+        w7 = w7 && (MODE != kModeFixed || a.att[h].iwl + a.att[h].frac == 7) && (!a.en_lin_map || a.w[h].iwl + a.w[h].frac == 7);
+    if (w7) launch_lean_w<MODE, NB, true>(a, max_slots, n_query, st);
+    else launch_lean_w<MODE, NB, false>(a, max_slots, n_query, st);
+}
+
+}  // namespace

@@ -1,0 +1,152 @@
+"""The instruction-lean hop kernel for bAbI-sized memories (csrc/hops_lean.h: <= 64 slots, 64-byte rows, no taps)
+against the general one-wavefront kernel (csrc/hops_small.h, itself checked against the oracle in test_gpu_batch.py):
+the hop outputs must be identical bit for bit, for every score mode, format combination and option the reference has.
+A request with taps always takes the general kernel, one without takes the lean kernel when it applies."""
+import numpy as np
+import pytest
+
+from conftest import load_pkg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    assert torch.cuda.is_available()
+    load_pkg()
+    import qmann_amd.model as model
+
+    class Env:
+        pass
+    e = Env()
+    e.torch, e.model, e.dev = torch, model, torch.device("cuda:0")
+    return e
+
+
+def both_paths(env, cfg, B, S_list, seed, sigma_k=30.0, sigma_u=20.0, sigma_h=1.0):
+    torch, model = env.torch, env.model
+    H, D, V = cfg["n_hop"], cfg["dim_emb"], cfg["dim_input"]
+    rng = np.random.default_rng(seed)
+    wts = {"w_h": [rng.normal(0, sigma_h, (D, D)).astype(np.float32) for _ in range(H)],
+           "w_ans": rng.normal(0, 0.1, (V, D)).astype(np.float32)}
+    net = model.QNet(cfg, wts, device="cuda:0")
+    Dp = net.Dp
+    assert Dp == 64
+    n_slots = np.array([S_list[i % len(S_list)] for i in range(B)], np.int64)
+    rng.shuffle(n_slots)
+    row_off = np.concatenate([[0], np.cumsum(n_slots)]).astype(np.int32)
+    R = max(int(row_off[-1]), 1)
+    keys = np.zeros((H, R, Dp), np.int8); vals = np.zeros((H, R, Dp), np.int8)
+    keys[:, :, :D] = np.clip(np.rint(rng.normal(0, sigma_k, (H, R, D))), -127, 127)
+    vals[:, :, :D] = np.clip(np.rint(rng.normal(0, sigma_k, (H, R, D))), -127, 127)
+    keys[:, 1::5, ::4] = 0
+    for h in range(H):
+        mk = (1 << sum(cfg["fmt_att"][h])) - 1; mv = (1 << sum(cfg["fmt"][h])) - 1
+        keys[h] = np.clip(keys[h], -mk, mk); vals[h] = np.clip(vals[h], -mv, mv)
+    w0 = cfg["fmt_w"][0]
+    m0 = (1 << sum(w0)) - 1
+    u0 = (np.clip(np.rint(rng.normal(0, sigma_u, (B, D))), -m0, m0) / (1 << w0[1])).astype(np.float32)
+    sk = model.to_signmag(keys)
+    sk[:, ::11, 3] = np.int8(-128)                      # "minus zero" bytes (0x80) are legal memory codes
+    dk = torch.from_numpy(sk).to(env.dev); dv = torch.from_numpy(model.to_signmag(vals)).to(env.dev)
+    dro = torch.from_numpy(row_off).to(env.dev); du0 = torch.from_numpy(u0).to(env.dev)
+    ms = int(n_slots.max())
+    u_lean = net.hops(dk, dv, dro, ms, du0)                     # no taps: lean kernel
+    u_gen, _ = net.hops(dk, dv, dro, ms, du0, taps=True)        # taps: general kernel
+    torch.cuda.synchronize()
+    a, b = u_lean.cpu().numpy(), u_gen.cpu().numpy()
+    bad = np.flatnonzero((a != b).any(1))
+    assert bad.size == 0, f"{bad.size} of {B} queries differ, first {bad[:5]}, slots {n_slots[bad[:5]]}"
+    assert np.abs(b).sum() > 0
+    return net
+
+
+def cfg_of(mode, D=60, H=3, iwl=5, base=0, nb=8, **kw):
+    frac = 7 - iwl
+    fmt = [(iwl, frac)] * H
+    c = dict(n_hop=H, dim_emb=D, dim_input=40, attention_mode=mode, softmax_variant=base, f_fixed=True, en_lin_map=True,
+             fmt=fmt, fmt_w=list(fmt), fmt_att=list(fmt), fmt_bin=(iwl, frac), num_bit=nb)
+    c.update(kw)
+    return c
+
+
+@pytest.mark.parametrize("mode,nb", [(2, 8), (3, 8), (10, 8), (10, 2), (10, 1), (11, 8), (11, 4), (11, 1)])
+@pytest.mark.parametrize("D", [60, 64, 17])
+def test_lean_equals_general_all_modes(env, mode, nb, D):
+    both_paths(env, cfg_of(mode, D=D, nb=nb), B=300, S_list=[0, 1, 2, 3, 9, 10, 16, 17, 33, 50, 63, 64], seed=100 + mode * 7 + D)
+
+
+@pytest.mark.parametrize("iwl", [2, 3, 6])
+@pytest.mark.parametrize("mode", [2, 3, 11])
+def test_lean_other_word_splits(env, mode, iwl):
+    both_paths(env, cfg_of(mode, iwl=iwl), B=120, S_list=[1, 5, 31, 64], seed=200 + iwl)
+
+
+def test_lean_persistent_grid_many_queries(env):
+    """more queries than resident wavefronts: every wavefront walks several queries"""
+    both_paths(env, cfg_of(2), B=60000, S_list=[2, 6, 10], seed=300)
+    both_paths(env, cfg_of(11), B=30000, S_list=[7, 50], seed=301)
+
+
+VARIANTS = {
+    "pow2": dict(softmax_variant=1), "exp_plan": dict(softmax_variant=2),
+    "pow2_shift": dict(softmax_variant=1, softmax_shift_based=True),
+    "exp_shift_scaled": dict(softmax_variant=0, softmax_shift_based=True, att_scale=[0.02, 0.015, 0.03]),
+    "scale_negative": dict(softmax_variant=0, att_scale=[-0.5, 0.25, -0.125]),
+    "relu": dict(en_non_lin=True), "no_lin_map": dict(en_lin_map=False),
+    "binary": dict(fmt_bin=(0, 0)), "binary_relu": dict(fmt_bin=(0, 0), en_non_lin=True),
+    "en_mq": dict(fmt_w=[(6, 1), (5, 2), (4, 3)]), "one_hop": dict(n_hop=1), "five_hops": dict(n_hop=5),
+}
+
+
+@pytest.mark.parametrize("variant", sorted(VARIANTS))
+@pytest.mark.parametrize("mode", [2, 3, 10])
+def test_lean_options(env, mode, variant):
+    extra = dict(VARIANTS[variant])
+    H = extra.pop("n_hop", 3)
+    if mode != 2 and variant == "exp_shift_scaled":
+        extra["att_scale"] = [0.002, 0.001, 0.0015]
+    cfg = cfg_of(mode, H=H)
+    if "fmt_w" in extra and mode != 2:
+        extra["fmt_w"] = [(5, 2), (6, 1), (4, 3)]       # the Hamming byte forms need u0's grid inside the attention grid
+    cfg.update(extra)
+    if "att_scale" in cfg:
+        cfg["att_scale"] = (cfg["att_scale"] * 2)[:H]
+    both_paths(env, cfg, B=96, S_list=[1, 2, 9, 50, 64], seed=400 + mode)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_lean_random_formats_fixed(env, seed):
+    rng = np.random.default_rng(9000 + seed)
+
+    def fmt(lo=2, hi=7):
+        wl = int(rng.integers(lo, hi + 1)); iwl = int(rng.integers(0, wl + 1))
+        return (iwl, wl - iwl)
+    H = int(rng.integers(1, 5))
+    cfg = dict(n_hop=H, dim_emb=int(rng.choice([20, 60, 64])), dim_input=40, attention_mode=2,
+               softmax_variant=int(rng.integers(0, 3)), f_fixed=True, en_lin_map=bool(rng.integers(0, 4)),
+               fmt=[fmt() for _ in range(H)], fmt_w=[fmt() for _ in range(H)], fmt_att=[fmt() for _ in range(H)],
+               fmt_bin=fmt(1, 7), en_non_lin=bool(rng.integers(0, 2)))
+    both_paths(env, cfg, B=64, S_list=[1, 3, 9, 33, 64], seed=9100 + seed, sigma_k=25.0)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_lean_random_formats_hamming(env, seed):
+    rng = np.random.default_rng(9500 + seed)
+    ia = int(rng.integers(1, 7)); att = (ia, 7 - ia)
+
+    def inside():
+        i = int(rng.integers(0, ia + 1)); f = int(rng.integers(0, 7 - ia + 1))
+        if i + f < 2:
+            i, f = min(ia, 1), max(1, min(7 - ia, 1))
+        return (i, f)
+
+    def free():
+        wl = int(rng.integers(2, 8)); i = int(rng.integers(0, wl + 1))
+        return (i, wl - i)
+    H = 3
+    cfg = cfg_of([3, 10, 11][seed % 3], nb=int(rng.choice([1, 2, 4, 8])))
+    cfg.update(fmt=[inside() for _ in range(H)], fmt_w=[inside()] + [free() for _ in range(H - 1)], fmt_att=[att] * H,
+               fmt_bin=free(), en_lin_map=bool(rng.integers(0, 5)))
+    both_paths(env, cfg, B=64, S_list=[1, 5, 33, 64], seed=9600 + seed, sigma_k=40.0, sigma_u=40.0)
