@@ -96,7 +96,8 @@ def gauss_i8(shape, sigma, gen, dev, pad_from=None):
 
 def make_params(cfg, D, V, seed):
     rng = np.random.default_rng(seed)
-    return {"w_h": [rng.normal(0, 1.0, (D, D)).astype(np.float32) for _ in range(cfg["n_hop"])],
+    sig = float(os.environ.get("QMANN_BENCH_WH_SIGMA", "1.0"))      # (experiments: how dense the per-product clamps of the linear map are)
+    return {"w_h": [rng.normal(0, sig, (D, D)).astype(np.float32) for _ in range(cfg["n_hop"])],
             "w_ans": rng.normal(0, 0.1, (V, D)).astype(np.float32)}
 
 

@@ -52,8 +52,8 @@ def both_paths(env, cfg, B, S_list, seed, sigma_k=30.0, sigma_u=20.0, sigma_h=1.
     dk = torch.from_numpy(sk).to(env.dev); dv = torch.from_numpy(model.to_signmag(vals)).to(env.dev)
     dro = torch.from_numpy(row_off).to(env.dev); du0 = torch.from_numpy(u0).to(env.dev)
     ms = int(n_slots.max())
-    u_lean = net.hops(dk, dv, dro, ms, du0)                     # no taps: lean kernel
     u_gen, _ = net.hops(dk, dv, dro, ms, du0, taps=True)        # taps: general kernel
+    u_lean = net.hops(dk, dv, dro, ms, du0)                     # no taps: lean kernel
     torch.cuda.synchronize()
     a, b = u_lean.cpu().numpy(), u_gen.cpu().numpy()
     bad = np.flatnonzero((a != b).any(1))
@@ -81,6 +81,18 @@ def test_lean_equals_general_all_modes(env, mode, nb, D):
 @pytest.mark.parametrize("mode", [2, 3, 11])
 def test_lean_other_word_splits(env, mode, iwl):
     both_paths(env, cfg_of(mode, iwl=iwl), B=120, S_list=[1, 5, 31, 64], seed=200 + iwl)
+
+
+@pytest.mark.parametrize("mode", [2, 11])
+@pytest.mark.parametrize("bin_fmt", [(5, 2), (6, 1), (7, 0), (0, 0), (4, 2), (2, 2)])
+def test_lean_linear_map_clamp_corrections(env, mode, bin_fmt):
+    """large linear-map codes against large operands: many per-product clamps, for operand formats with 0, 1 and 2
+    fractional bits and the binarised operand"""
+    cfg = cfg_of(mode, nb=4)
+    cfg["fmt_bin"] = bin_fmt
+    both_paths(env, cfg, B=200, S_list=[1, 4, 20, 64], seed=700 + bin_fmt[0] * 8 + bin_fmt[1], sigma_u=80.0, sigma_h=12.0)
+    cfg["fmt_w"] = [(2, 5) if mode == 2 else (5, 2), (4, 3), (3, 3)]   # (the byte forms need u0's grid inside the attention grid)
+    both_paths(env, cfg, B=100, S_list=[3, 30], seed=750 + bin_fmt[0], sigma_u=80.0, sigma_h=1.5)
 
 
 def test_lean_persistent_grid_many_queries(env):
