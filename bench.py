@@ -258,14 +258,13 @@ def run_bow(args, name, wl, net, cfg, wts, dev, rank, world, model):
         sw = torch.from_numpy(np.tile(to_words(g["story"], dd, 8, True), (rep, 1)).view(np.int16)).to(dev)
         qw = torch.from_numpy(np.tile(to_words(g["question"], cfg["dim_input"], 8, False), (rep, 1)).view(np.int16)).to(dev)
         net.make_tables()
+        hm = model.HostModel(cfg, wts, device=str(dev))          # the library's own host object: one call per batch
     torch.cuda.synchronize()
 
     def step():
         if not use_idx:
             return net.forward_bow(story, ques, row_off, max_slots, answer=ans)
-        keys, vals, u0 = net.embed_idx(sw, qw)
-        u = net.hops(keys, vals, row_off, max_slots, u0)
-        pred, _, cost, match = net.answer(u, ans)
+        pred, cost, match = hm.forward_words(sw, qw, row_off, max_slots, ans)
         return dict(pred=pred, cost=cost, match=match)
 
     for _ in range(args.warmup):
@@ -298,7 +297,8 @@ def run_bow(args, name, wl, net, cfg, wts, dev, rank, world, model):
         "data": "bAbI qa1 test stories (64-story fixture from the reference's sample.c, replicated), seeded random weights",
         "config": {"workload": name, "slots": "2..10 (mean 5.9)", "dim_emb": 60, "dim_input": cfg["dim_input"],
                    "hops": 3, "queries_per_gpu": B, "format": "Q5.2 + EN_MQ weight formats", "attention_mode": 2,
-                   "stages": "embed_story + embed_query + hops + answer",
+                   "stages": ("one qmann_model_forward_words call: embedding, hops and answer layer in ONE kernel (fwd_lean.hip)" if use_idx
+                              else "embed_story + embed_query + hops + answer"),
                    "input": "uint16 word indices" if use_idx else "float bag-of-words",
                    "parallelism": f"replicas x{world}, query-sharded"},
         "roofline": {"bound": "hbm", "kernel": "whole forward (latency bound at these sizes)",
@@ -328,9 +328,7 @@ def run_bow(args, name, wl, net, cfg, wts, dev, rank, world, model):
             # the same with the copy of batch i+1 overlapping the compute of batch i: two HIP streams, two
             # input buffers, events in both directions (every entry point of the library takes a stream)
             cs, ks = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
-            net2 = model.QNet(cfg, wts, device=str(dev), stream=ks.cuda_stream)
-            with torch.cuda.stream(ks):
-                net2.make_tables()
+            hm2 = model.HostModel(cfg, wts, device=str(dev), stream=ks.cuda_stream)
             bufs = [[torch.empty_like(t, device=dev) for t in srcs] for _ in range(2)]
             copied = [torch.cuda.Event() for _ in range(2)]
             done = [torch.cuda.Event() for _ in range(2)]
@@ -347,9 +345,7 @@ def run_bow(args, name, wl, net, cfg, wts, dev, rank, world, model):
                     with torch.cuda.stream(ks):
                         ks.wait_event(copied[b])
                         sw_, qw_, ro_, an_ = bufs[b]
-                        keys, vals, u0 = net2.embed_idx(sw_, qw_)
-                        u = net2.hops(keys, vals, ro_, max_slots, u0)
-                        o2 = net2.answer(u, an_)
+                        o2 = hm2.forward_words(sw_, qw_, ro_, max_slots, an_)
                         done[b].record(ks)
                 torch.cuda.synchronize()
                 return o2
@@ -428,7 +424,7 @@ def run_joint(args, name, wl, cfg, wts, dev, rank, world, model):
         "config": {"workload": name, "slots": f"2..{max_slots} (mean {n_sen.mean():.1f})", "dim_emb": cfg["dim_emb"],
                    "dim_input": cfg["dim_input"], "hops": cfg["n_hop"], "queries_per_gpu": B, "format": "Q5.2",
                    "attention_mode": cfg["attention_mode"], "num_bit": cfg.get("num_bit", 8),
-                   "stages": "embed (word indices) + pack planes + hops + answer, one qmann_model_forward_words call",
+                   "stages": "one qmann_model_forward_words call: embedding + hops in one kernel (fwd_lean.hip), answer layer in a second",
                    "parallelism": f"replicas x{world}, query-sharded"},
         "roofline": {"bound": "hbm", "kernel": "whole forward (issue / latency bound at these sizes)",
                      "achieved": bytes_in * args.steps / elapsed / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -108,11 +108,201 @@ __device__ __forceinline__ int lane_sum_w(const i32x4 x, const ScanConst &c, uin
     return W7 ? lane_row_sum7(x, c) : lane_row_sum(x, c, sh);
 }
 
+// exp tables [n_hop][256] and linear maps [n_hop][64][64] of a (persistent) workgroup; ends WITHOUT a barrier
+__device__ __forceinline__ void lean_stage_tables(const HopArgs &a, const LeanArgs &la, float *etab, uint8_t *lmap, uint32_t tid,
+                                                  uint32_t nthreads)
+{
+    const uint32_t H = a.n_hop;
+    if (la.exp_table) {
+        for (uint32_t i = tid; i < H * 256u; i += nthreads) {
+            const uint32_t h = i >> 8, d = i & 255u;
+            // score - max on the score grid: -(d . 2^-frac_att), exact; the same call the per-slot form makes
+            etab[i] = sm_exp(-qm_scale_down((float)d, a.att[h].frac), SmCfg{a.softmax_base, false, false, 1.0f});
+        }
+    }
+    if (la.lm_in_lds) {
+        for (uint32_t h = 0; h < H; h++) {
+            const i32x4 *src = (const i32x4 *)a.lin_map[h];
+            for (uint32_t i = tid; i < 256u; i += nthreads) {
+                i32x4 x = {0, 0, 0, 0};
+                if (i * 16u < a.D * 64u) x = src[i];
+                *(i32x4 *)(lmap + h * 4096u + i * 16u) = x;
+            }
+        }
+    }
+}
+
+// One hop of one query on one wavefront.  u: the hop state, lane c owns column c (updated in place).
+//   key_of(j)         this lane's 16-byte piece (chunk = lane & 3) of key row 16 j + (lane >> 2), j = 0..3
+//   before_readout()  called once the read-out weights are known, before the value tile `vt` is read
+//                     (wait for / produce the tile; must leave the wavefront synchronised)
+// `lw`: this wavefront's small arrays (kLwBytes); `lmap` / `etab`: the workgroup's tables.
+template <int MODE, int NB, bool W7, typename KeyOf, typename BeforeReadout>
+__device__ __forceinline__ void lean_hop(const HopArgs &a, const LeanArgs &la, uint32_t h, uint32_t S, uint32_t lane, const uint8_t *vt,
+                                         uint8_t *lw, const uint8_t *lmap, const float *etab, float &u, KeyOf key_of,
+                                         BeforeReadout before_readout)
+{
+    constexpr uint32_t Dp = 64, LPR = 4;
+    const uint32_t sub = lane >> 2, chunk = lane & 3u, D = a.D;
+    const QFmt fa = a.act[h], fm = a.att[h], fb = a.bin, fw = a.w[h];
+    const int maxa = (1 << (fa.iwl + fa.frac)) - 1;
+    const bool relu = hop_relu(a, h);
+    // ---- column c: operand codes -----------------------------------------------------------------
+    const int kb_code = (lane < D) ? qm_code_or_sign(u, fb.iwl, fb.frac) : 0;        // Q_bin(u): linear map (and fixed scores)
+    const uint32_t wl_m = fm.iwl + fm.frac, wl_w = fw.iwl + fw.frac;
+    if (MODE == kModeFixed) {
+        int ka = kb_code;
+        if (relu && ka < 0) ka = (fb.iwl + fb.frac == 0) ? 1 : 0;                    // see make_scan_const
+        publish_const<W7>(lw, lane, ka, wl_m, (int)fb.frac);
+    } else {
+        const float ua = relu_if(u, relu);
+        const int kc = (lane < D) ? qm_code(ua, fm.iwl, fm.frac) : 0;
+        lw[kLwUb + lane] = (uint8_t)((uint32_t)(kc < 0 ? -kc : kc) | ((lane < D && !(ua >= 0.0f)) ? 0x80u : 0u));
+    }
+    wave_sync();
+
+    // ---- scores ------------------------------------------------------------------------------------
+    ScanConst csc;
+    uint32_t csh = 0;
+    float unit = 1.0f;
+    auto scan = [&](auto lane_sum, int lim) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (j * 16 < (int)S) {                                // wavefront-uniform
+                const int v = row_lanes_sum<LPR>(lane_sum(key_of(j)));
+                if (chunk == 0) *(int16_t *)(lw + kLwSc + (j * 16 + sub) * 2) = (int16_t)(v > lim ? lim : (v < -lim ? -lim : v));
+            }
+        }
+    };
+    if (MODE == kModeFixed) {
+        unit = qm_scale_down(1.0f, fm.frac);
+        csh = fetch_scan_const(csc, lw, chunk, wl_m);
+        scan([&](const i32x4 x) { return lane_sum_w<W7>(x, csc, csh); }, (1 << wl_m) - 1);
+    } else if (MODE == kModeAppx) {
+        unit = 1.0f / 1024.0f;
+        AppxConst c;
+        make_appx_const(c, lw + kLwUb, chunk * 16, D);
+        scan([&](const i32x4 x) { return appx_lane_sum(x, c); }, 1 << (fm.iwl + 10));
+    } else {
+        if (MODE == kModeV1Bytes) unit = qm_scale_down(1.0f, NB);
+        HamByteConst c;
+        make_hambyte_const<MODE, NB>(c, lw + kLwUb, chunk * 16, D);
+        scan([&](const i32x4 x) { return hambyte_lane_sum<MODE, NB>(x, c); }, 32767);
+    }
+    wave_sync();
+
+    // ---- softmax over slots, slot r in lane r ------------------------------------------------------
+    const bool live = lane < S;
+    const int code = live ? (int)*(const int16_t *)(lw + kLwSc + lane * 2) : 0;
+    const SmCfg smc = sm_cfg(a, h);
+    float e;
+    double total;
+    if (MODE == kModeFixed && la.exp_table) {
+        int mxc = live ? code : -32768;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(mxc, o); mxc = t > mxc ? t : mxc; }
+        e = live ? etab[h * 256u + (uint32_t)(mxc - code)] : 0.0f;
+    } else {
+        const float xs = live ? sm_scaled((float)code * unit, smc) : -INFINITY;
+        float mx = xs;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        e = live ? sm_exp(xs - mx, smc) : 0.0f;
+    }
+    total = (double)e;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+    const float p = live ? sm_quot(e, total, smc) : 0.0f;
+    // Q(p) for 0 <= p <= 1: trunc(p . 2^frac), saturated (qm_code without the cases a probability cannot reach)
+    int kp = (int)__builtin_ldexpf(p, (int)fa.frac);
+    kp = kp > maxa ? maxa : kp;
+
+    // ---- read-out over the rows whose weight code is non-zero (lane c owns column c) -----------------
+    before_readout();
+    int acc = 0;
+    for (uint64_t m = __ballot(kp != 0); m; m &= m - 1) {
+        const int r = __builtin_ctzll(m);
+        const int kpr = __builtin_amdgcn_readlane(kp, r);
+        const uint32_t b = vt[(uint32_t)r * Dp + lane];
+        uint32_t t = ((uint32_t)kpr * (b & 0x7Fu)) >> fa.frac;   // |Q(p) . v| / 2^frac toward zero
+        t = t > (uint32_t)maxa ? (uint32_t)maxa : t;
+        acc += (b & 0x80u) ? -(int)t : (int)t;
+    }
+    acc = acc > maxa ? maxa : (acc < -maxa ? -maxa : acc);
+    *(int16_t *)(lw + kLwOc + lane * 2) = (int16_t)acc;
+
+    // ---- linear map + hop update ---------------------------------------------------------------------
+    if (a.en_lin_map && a.lm_lut[h]) {
+        // Table form: lu[o] = sum_i T[i][u_i][o] (per-product truncation and clamp are in the table).  Row i's address is
+        // wavefront-uniform (lane i's code through v_readlane), the 64 lanes read its 64 bytes: one byte load and half an
+        // add per term instead of the packed multiply -- lane o ends with its own row sum, in place.
+        const int8_t *lut = a.lm_lut[h];
+        const int roff = ((int)lane * 256 + kb_code + 128) * 64;         // lane i: byte offset of row (i, u_i)
+        // all 64 rows, no branches (so that every load is in flight before the first add): a column beyond D has code 0 and
+        // its table rows are zero
+        int part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int i0 = 0; i0 < 64; i0 += 16) {
+            int t[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) t[i] = (int)lut[(size_t)__builtin_amdgcn_readlane(roff, i0 + i) + lane];
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) part[i >> 1] += t[i] + t[i + 1];
+        }
+        const int s0 = (part[0] + part[1]) + (part[2] + part[3]), s1 = (part[4] + part[5]) + (part[6] + part[7]);
+        const int keep = s0 + s1;
+        const int maxw = (1 << wl_w) - 1;
+        const int kw = keep > maxw ? maxw : (keep < -maxw ? -maxw : keep);       // Qw of the row sum
+        const uint32_t mag = (uint32_t)(kw < 0 ? -kw : kw);
+        const uint32_t ma = fa.frac >= fw.frac ? mag << (fa.frac - fw.frac) : mag >> (fw.frac - fa.frac);
+        const int lam = ma > (uint32_t)maxa ? maxa : (int)ma;                  // Qa of that value
+        int un = (kw < 0 ? -lam : lam) + acc;
+        un = un > maxa ? maxa : (un < -maxa ? -maxa : un);
+        u = (lane < D) ? qm_scale_down((float)un, fa.frac) : 0.0f;
+    } else if (a.en_lin_map) {
+        const bool reuse = MODE == kModeFixed && wl_w == wl_m && !relu;
+        if (!reuse) {
+            wave_sync();                                          // every lane is done with the previous image
+            publish_const<W7>(lw, lane, kb_code, wl_w, (int)fb.frac);
+        }
+        wave_sync();
+        if (!reuse) csh = fetch_scan_const(csc, lw, chunk, wl_w);
+        const int maxw = (1 << wl_w) - 1;
+        const uint32_t n_it = (D + 15u) / 16u;
+        int keep = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            if ((uint32_t)t < n_it) {                             // wavefront-uniform
+                const i32x4 x = *(const i32x4 *)(lmap + h * 4096u + (t * 16 + sub) * 64u + chunk * 16u);
+                const int s = row_lanes_sum<LPR>(lane_sum_w<W7>(x, csc, csh));
+                if (chunk == (uint32_t)t) keep = s;
+            }
+        }
+        // lane (sub, chunk) now holds the sum of row o = 16 . chunk + sub
+        const uint32_t o_i = chunk * 16u + sub;
+        const int kw = keep > maxw ? maxw : (keep < -maxw ? -maxw : keep);       // Qw of the row sum
+        const uint32_t mag = (uint32_t)(kw < 0 ? -kw : kw);
+        const uint32_t ma = fa.frac >= fw.frac ? mag << (fa.frac - fw.frac) : mag >> (fw.frac - fa.frac);
+        const int lam = ma > (uint32_t)maxa ? maxa : (int)ma;                  // Qa of that value
+        int un = (kw < 0 ? -lam : lam) + (int)*(const int16_t *)(lw + kLwOc + o_i * 2);
+        un = un > maxa ? maxa : (un < -maxa ? -maxa : un);
+        wave_sync();                                              // (kLwUn shares its bytes with the constant images)
+        *(float *)(lw + kLwUn + o_i * 4) = qm_scale_down((float)un, fa.frac);
+        wave_sync();
+        u = (lane < D) ? *(const float *)(lw + kLwUn + lane * 4) : 0.0f;
+    } else {
+        int un = ((lane < D) ? qm_code(u, fa.iwl, fa.frac) : 0) + acc;
+        un = un > maxa ? maxa : (un < -maxa ? -maxa : un);
+        u = qm_scale_down((float)un, fa.frac);
+    }
+    wave_sync();                                                  // the next hop rewrites the images
+}
+
 template <int MODE, int NB, bool W7>
 __global__ void __launch_bounds__(kLeanBlock)
 k_hops_lean(const HopArgs a, const LeanArgs la)
 {
-    constexpr uint32_t Dp = 64, LPR = 4;
+    constexpr uint32_t Dp = 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     const uint32_t sub = lane >> 2, chunk = lane & 3u;
@@ -123,25 +313,7 @@ k_hops_lean(const HopArgs a, const LeanArgs la)
     const uint32_t wslice = la.rows_pad * 64u + kLwBytes;
     uint8_t *vt = wbase + wave * wslice;                                // value tile
     uint8_t *lw = vt + la.rows_pad * 64u;                               // small arrays
-
-    // ---- per-workgroup tables -------------------------------------------------------------------
-    if (la.exp_table) {
-        for (uint32_t i = tid; i < H * 256u; i += kLeanBlock) {
-            const uint32_t h = i >> 8, d = i & 255u;
-            // score - max on the score grid: -(d . 2^-frac_att), exact; the same call the per-slot form makes
-            etab[i] = sm_exp(-qm_scale_down((float)d, a.att[h].frac), SmCfg{a.softmax_base, false, false, 1.0f});
-        }
-    }
-    if (la.lm_in_lds) {
-        for (uint32_t h = 0; h < H; h++) {
-            const i32x4 *src = (const i32x4 *)a.lin_map[h];
-            for (uint32_t i = tid; i < 256u; i += kLeanBlock) {
-                i32x4 x = {0, 0, 0, 0};
-                if (i * 16u < D * Dp) x = src[i];
-                *(i32x4 *)(lmap + h * 4096u + i * 16u) = x;
-            }
-        }
-    }
+    lean_stage_tables(a, la, etab, lmap, tid, kLeanBlock);
     __syncthreads();
 
     const size_t q_stride = (size_t)gridDim.x * kLeanWaves, n_query = a.rows_total;   // (rows_total carries the query count, see launcher)
@@ -176,9 +348,9 @@ k_hops_lean(const HopArgs a, const LeanArgs la)
             const uint32_t S_in = a.row_off[qn + 1] - r0n;
             Sn = S_in < (uint32_t)kWave ? S_in : (uint32_t)kWave;
         }
-
-        // a hop's value rows: global memory -> this wavefront's LDS tile, 1 KiB (16 rows) per instruction
-        auto load_vals = [&](uint32_t h) {
+        float u = u_next;
+        for (uint32_t h = 0; h < H; h++) {
+            // this hop's value rows: global memory -> this wavefront's LDS tile, 1 KiB (16 rows) per instruction
             const uint8_t *vb = (const uint8_t *)a.vals + (size_t)h * a.hop_stride + (size_t)r0 * Dp + chunk * 16;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -189,154 +361,16 @@ k_hops_lean(const HopArgs a, const LeanArgs la)
                                                          (void __attribute__((address_space(3))) *)(vt + j * 1024), 16, 0, 0);
                 }
             }
-        };
-        float u = u_next;
-
-        for (uint32_t h = 0; h < H; h++) {
-            const QFmt fa = a.act[h], fm = a.att[h], fb = a.bin, fw = a.w[h];
-            const int maxa = (1 << (fa.iwl + fa.frac)) - 1;
-            const bool relu = hop_relu(a, h);
-            load_vals(h);
-            i32x4 hq[4];
-            if (a.en_lin_map && !la.lm_in_lds) {
-                const uint8_t *hb = (const uint8_t *)a.lin_map[h] + chunk * 16;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t r = j * 16 + sub;
-                    hq[j] = i32x4{0, 0, 0, 0};
-                    if (r < D) hq[j] = *(const i32x4 *)(hb + (size_t)r * Dp);
-                }
-            }
-            // ---- column c: operand codes ---------------------------------------------------------
-            const int kb_code = (lane < D) ? qm_code_or_sign(u, fb.iwl, fb.frac) : 0;        // Q_bin(u): linear map (and fixed scores)
-            const uint32_t wl_m = fm.iwl + fm.frac, wl_w = fw.iwl + fw.frac;
-            if (MODE == kModeFixed) {
-                int ka = kb_code;
-                if (relu && ka < 0) ka = (fb.iwl + fb.frac == 0) ? 1 : 0;                    // see make_scan_const
-                publish_const<W7>(lw, lane, ka, wl_m, (int)fb.frac);
-            } else {
-                const float ua = relu_if(u, relu);
-                const int kc = (lane < D) ? qm_code(ua, fm.iwl, fm.frac) : 0;
-                lw[kLwUb + lane] = (uint8_t)((uint32_t)(kc < 0 ? -kc : kc) | ((lane < D && !(ua >= 0.0f)) ? 0x80u : 0u));
-            }
-            wave_sync();
-
-            // ---- scores ----------------------------------------------------------------------------
-            ScanConst csc;
-            uint32_t csh = 0;
-            float unit = 1.0f;
-            auto scan = [&](auto lane_sum, int lim) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    if (j * 16 < (int)S) {                                // wavefront-uniform
-                        const int v = row_lanes_sum<LPR>(lane_sum(kq[j]));
-                        if (chunk == 0) *(int16_t *)(lw + kLwSc + (j * 16 + sub) * 2) = (int16_t)(v > lim ? lim : (v < -lim ? -lim : v));
-                    }
-                }
-            };
-            if (MODE == kModeFixed) {
-                unit = qm_scale_down(1.0f, fm.frac);
-                csh = fetch_scan_const(csc, lw, chunk, wl_m);
-                scan([&](const i32x4 x) { return lane_sum_w<W7>(x, csc, csh); }, (1 << wl_m) - 1);
-            } else if (MODE == kModeAppx) {
-                unit = 1.0f / 1024.0f;
-                AppxConst c;
-                make_appx_const(c, lw + kLwUb, chunk * 16, D);
-                scan([&](const i32x4 x) { return appx_lane_sum(x, c); }, 1 << (fm.iwl + 10));
-            } else {
-                if (MODE == kModeV1Bytes) unit = qm_scale_down(1.0f, NB);
-                HamByteConst c;
-                make_hambyte_const<MODE, NB>(c, lw + kLwUb, chunk * 16, D);
-                scan([&](const i32x4 x) { return hambyte_lane_sum<MODE, NB>(x, c); }, 32767);
-            }
-            wave_sync();
-
-            // ---- softmax over slots, slot r in lane r ----------------------------------------------
-            const bool live = lane < S;
-            const int code = live ? (int)*(const int16_t *)(lw + kLwSc + lane * 2) : 0;
-            const SmCfg smc = sm_cfg(a, h);
-            float e;
-            double total;
-            if (MODE == kModeFixed && la.exp_table) {
-                int mxc = live ? code : -32768;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(mxc, o); mxc = t > mxc ? t : mxc; }
-                e = live ? etab[h * 256u + (uint32_t)(mxc - code)] : 0.0f;
-            } else {
-                const float xs = live ? sm_scaled((float)code * unit, smc) : -INFINITY;
-                float mx = xs;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-                e = live ? sm_exp(xs - mx, smc) : 0.0f;
-            }
-            total = (double)e;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
-            const float p = live ? sm_quot(e, total, smc) : 0.0f;
-            // Q(p) for 0 <= p <= 1: trunc(p . 2^frac), saturated (qm_code without the cases a probability cannot reach)
-            int kp = (int)__builtin_ldexpf(p, (int)fa.frac);
-            kp = kp > maxa ? maxa : kp;
-
-            // ---- read-out over the rows whose weight code is non-zero (lane c owns column c) ---------
-            __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0): the value tile has landed
-            wave_sync();
-            // in flight during the read-out and the linear map: the next hop's keys, or the next query's first keys
-            if (h + 1 < H) load_keys_of(h + 1, r0, S);
-            else if (qn < n_query) {
-                load_keys_of(0, r0n, Sn);
-                u_next = (lane < D) ? a.u0[qn * D + lane] : 0.0f;
-            }
-            int acc = 0;
-            for (uint64_t m = __ballot(kp != 0); m; m &= m - 1) {
-                const int r = __builtin_ctzll(m);
-                const int kpr = __builtin_amdgcn_readlane(kp, r);
-                const uint32_t b = vt[(uint32_t)r * Dp + lane];
-                uint32_t t = ((uint32_t)kpr * (b & 0x7Fu)) >> fa.frac;   // |Q(p) . v| / 2^frac toward zero
-                t = t > (uint32_t)maxa ? (uint32_t)maxa : t;
-                acc += (b & 0x80u) ? -(int)t : (int)t;
-            }
-            acc = acc > maxa ? maxa : (acc < -maxa ? -maxa : acc);
-            *(int16_t *)(lw + kLwOc + lane * 2) = (int16_t)acc;
-
-            // ---- linear map + hop update -------------------------------------------------------------
-            if (a.en_lin_map) {
-                const bool reuse = MODE == kModeFixed && wl_w == wl_m && !relu;
-                if (!reuse) {
-                    wave_sync();                                          // every lane is done with the previous image
-                    publish_const<W7>(lw, lane, kb_code, wl_w, (int)fb.frac);
-                }
+            lean_hop<MODE, NB, W7>(a, la, h, S, lane, vt, lw, lmap, etab, u, [&](int j) { return kq[j]; }, [&]() {
+                __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0): the value tile has landed
                 wave_sync();
-                if (!reuse) csh = fetch_scan_const(csc, lw, chunk, wl_w);
-                const int maxw = (1 << wl_w) - 1;
-                const uint32_t n_it = (D + 15u) / 16u;
-                int keep = 0;
-#pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    if ((uint32_t)t < n_it) {                             // wavefront-uniform
-                        i32x4 x;
-                        if (la.lm_in_lds) x = *(const i32x4 *)(lmap + h * 4096u + (t * 16 + sub) * 64u + chunk * 16u);
-                        else x = hq[t];
-                        const int s = row_lanes_sum<LPR>(lane_sum_w<W7>(x, csc, csh));
-                        if (chunk == (uint32_t)t) keep = s;
-                    }
+                // in flight during the read-out and the linear map: the next hop's keys, or the next query's first keys
+                if (h + 1 < H) load_keys_of(h + 1, r0, S);
+                else if (qn < n_query) {
+                    load_keys_of(0, r0n, Sn);
+                    u_next = (lane < D) ? a.u0[qn * D + lane] : 0.0f;
                 }
-                // lane (sub, chunk) now holds the sum of row o = 16 . chunk + sub
-                const uint32_t o_i = chunk * 16u + sub;
-                const int kw = keep > maxw ? maxw : (keep < -maxw ? -maxw : keep);       // Qw of the row sum
-                const uint32_t mag = (uint32_t)(kw < 0 ? -kw : kw);
-                const uint32_t ma = fa.frac >= fw.frac ? mag << (fa.frac - fw.frac) : mag >> (fw.frac - fa.frac);
-                const int lam = ma > (uint32_t)maxa ? maxa : (int)ma;                  // Qa of that value
-                int un = (kw < 0 ? -lam : lam) + (int)*(const int16_t *)(lw + kLwOc + o_i * 2);
-                un = un > maxa ? maxa : (un < -maxa ? -maxa : un);
-                *(float *)(lw + kLwUn + o_i * 4) = qm_scale_down((float)un, fa.frac);
-                wave_sync();
-                u = (lane < D) ? *(const float *)(lw + kLwUn + lane * 4) : 0.0f;
-            } else {
-                int un = ((lane < D) ? qm_code(u, fa.iwl, fa.frac) : 0) + acc;
-                un = un > maxa ? maxa : (un < -maxa ? -maxa : un);
-                u = qm_scale_down((float)un, fa.frac);
-            }
-            wave_sync();                                                  // the next hop rewrites the images
+            });
         }
         if (lane < D) a.u_out[q * D + lane] = relu_if(u, a.en_non_lin != 0);
         r0 = r0n; S = Sn;

@@ -2,6 +2,7 @@
 // runs the whole test-phase forward of a batch through the batched kernels.  No kernels here.
 #include "qfmt.h"
 #include "rt.h"
+#include "fwd_lean.h"
 #include "../../include/qmann_model.h"
 
 #include <new>
@@ -15,6 +16,7 @@ struct qmann_model {
     float *w_q = nullptr, *w_ans = nullptr;
     float *w_a[QMANN_MAX_HOP] = {}, *w_c[QMANN_MAX_HOP] = {};
     int8_t *lin_map[QMANN_MAX_HOP] = {};
+    int8_t *lin_map_lut[QMANN_MAX_HOP] = {};
     int8_t *t_q = nullptr, *t_a[QMANN_MAX_HOP] = {}, *t_c[QMANN_MAX_HOP] = {};
     // workspace, grown on demand
     int8_t *keys = nullptr, *vals = nullptr;
@@ -126,12 +128,19 @@ int qmann_model_create(qmann_model **out, const qmann_net *net, const qmann_weig
         rc = qmann_quantize_table_i8(m->w_a[h], m->t_a[h], m->D, m->Dp, m->V, net->w[h], stream);
         if (rc == QMANN_OK) rc = qmann_quantize_table_i8(m->w_c[h], m->t_c[h], m->D, m->Dp, m->V, net->w[h], stream);
         m->net.lin_map[h] = nullptr;
+        m->net.lin_map_lut[h] = nullptr;
         if (rc == QMANN_OK && net->en_lin_map) {
             float *wh = upload(w->w_h[h], DD, st);
             staged.push_back(wh);
             QM_HIP(hipMalloc((void **)&m->lin_map[h], (size_t)m->D * m->Dp));
             rc = qmann_quantize_i8(wh, m->lin_map[h], m->D, m->D, m->Dp, net->w[h], QMANN_CODE_SIGNMAG, stream);
             m->net.lin_map[h] = m->lin_map[h];
+            // product table of the linear map for the short-memory kernels (1 MiB per hop)
+            if (rc == QMANN_OK && m->Dp == 64 && !getenv("QMANN_NO_LM_LUT")) {
+                QM_HIP(hipMalloc((void **)&m->lin_map_lut[h], qmann_linmap_lut_bytes(&m->net)));
+                rc = qmann_linmap_lut_build(&m->net, h, m->lin_map_lut[h], stream);
+                m->net.lin_map_lut[h] = m->lin_map_lut[h];
+            }
         }
     }
     QM_HIP(hipStreamSynchronize(st));        // the host arrays and the staged floats are free again
@@ -146,7 +155,7 @@ void qmann_model_destroy(qmann_model *m)
     if (!m) return;
     auto drop = [](void *p) { if (p) QM_HIP(hipFree(p)); };
     drop(m->w_q); drop(m->w_ans); drop(m->t_q);
-    for (uint32_t h = 0; h < QMANN_MAX_HOP; h++) { drop(m->w_a[h]); drop(m->w_c[h]); drop(m->lin_map[h]); drop(m->t_a[h]); drop(m->t_c[h]); }
+    for (uint32_t h = 0; h < QMANN_MAX_HOP; h++) { drop(m->w_a[h]); drop(m->w_c[h]); drop(m->lin_map[h]); drop(m->lin_map_lut[h]); drop(m->t_a[h]); drop(m->t_c[h]); }
     drop(m->keys); drop(m->vals); drop(m->planes); drop(m->u0); drop(m->u);
     delete m;
 }
@@ -158,7 +167,23 @@ int qmann_model_forward_words(qmann_model *m, const uint16_t *story_words, uint3
 {
     if (!m || !story_words || !question_words || !row_off || !pred) return QMANN_EINVAL;
     if (n_query == 0) return QMANN_OK;
-    int rc = ensure(m, rows_total, n_query, use_planes(m, max_slots));
+    // bAbI-sized stories: the whole forward in one kernel, memories built in LDS and never written to HBM (fwd_lean.hip)
+    int rc = ensure(m, 0, n_query, false);
+    if (rc) return rc;
+    {
+        qmann::FwdArgs f{};
+        f.story_words = story_words; f.question_words = question_words; f.row_off = row_off;
+        f.t_q = m->t_q;
+        for (uint32_t h = 0; h < m->H; h++) { f.t_a[h] = m->t_a[h]; f.t_c[h] = m->t_c[h]; }
+        f.w_ans = m->w_ans; f.answer = answer; f.pred = pred; f.cost = cost; f.match = match;
+        f.n_query = n_query; f.max_words = max_words; f.max_q_words = max_q_words; f.time_last = 1;
+        int answer_done = 0;
+        rc = qmann::fwd_lean(&m->net, &m->emb_net, f, max_slots, m->u, &answer_done, stream);
+        if (rc == QMANN_OK)
+            return answer_done ? QMANN_OK : qmann_answer_f32(&m->net, m->w_ans, m->u, answer, pred, nullptr, cost, match, n_query, stream);
+        if (rc != QMANN_EUNSUPPORTED) return rc;
+    }
+    rc = ensure(m, rows_total, n_query, use_planes(m, max_slots));
     if (rc) return rc;
     rc = qmann_embed_story_idx(&m->emb_net, story_words, rows_total, max_words, 1, m->t_a, m->t_c, m->keys, m->vals,
                                (size_t)rows_total * m->Dp, stream);

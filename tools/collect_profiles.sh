@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 # only the small summaries travel back (gpurun merges at most 64 MiB): per-dispatch traces are dropped and
 # counter files are cut down to our kernels' rows
 prune() { find "$1" -type f ! -name '*kernel_stats.csv' ! -name '*counter_collection.csv' -delete; 
-          for c in $(find "$1" -name '*counter_collection.csv'); do { head -1 "$c"; grep -E 'k_hops|k_answer|k_embed|k_logits' "$c" || true; } > "$c.tmp"; mv "$c.tmp" "$c"; done; }
+          for c in $(find "$1" -name '*counter_collection.csv'); do { head -1 "$c"; grep -E 'k_hops|k_answer|k_embed|k_logits|k_fwd' "$c" || true; } > "$c.tmp"; mv "$c.tmp" "$c"; done; }
 rocprofv3 --kernel-trace --stats --output-format csv -d $P/${tag}_stats -- python3 $R/bench.py --workload $wl --steps 10 --no-cpu-baseline --no-secondary > $P/${tag}_stats.log 2>&1
 prune $P/${tag}_stats
 for pass in "$@"; do

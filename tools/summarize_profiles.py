@@ -8,7 +8,7 @@ ROOT = Path(__file__).resolve().parent.parent
 tag, workload, alg = sys.argv[1], sys.argv[2], float(sys.argv[3])
 src = ROOT / "gpurun_out" / "prof"
 out = ROOT / "profiles"; out.mkdir(exist_ok=True)
-kernel = "k_hops"
+kernel = sys.argv[4] if len(sys.argv) > 4 else "k_hops"
 
 st = glob.glob(str(src / f"{tag}_stats" / "*" / "*kernel_stats.csv"))
 if st:
