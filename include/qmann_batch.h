@@ -86,12 +86,6 @@ typedef struct qmann_net {
     uint32_t en_non_linearity;      /* EN_NON_LINEARITY (define.h): RELU layers non_lin[h] (MemN2N.c:894-896, 2668-2671): the attention of
                                      * hop h >= 1 and the answer layer read RELU(sv), lin_map keeps reading sv (:2435-2437, 2471-2473, 2535-2537);
                                      * u_out is then RELU(sv[n_hop-1]) */
-    /* optional, may be NULL: per-hop product tables of the linear map made by qmann_linmap_lut_build (device,
-     * qmann_linmap_lut_bytes() each): T[i][v + 128][o] = Qw(Qw(H[o][i]) . v) for every operand code v, so that
-     * lin_map . u is the sum of dim_emb table rows gathered from L2 (per-product truncation and clamp included, results
-     * identical).  Used by the kernels for memories of at most 64 slots, where the linear map is otherwise the largest
-     * single cost; without it they use the packed vector arithmetic of the key scan. */
-    const int8_t *lin_map_lut[QMANN_MAX_HOP];
 } qmann_net;
 
 /* optional per-query taps for parity tests; any pointer may be NULL */
@@ -180,11 +174,6 @@ int qmann_embed_story_idx(const qmann_net *net, const uint16_t *words, uint32_t 
                           int8_t *vals, size_t hop_stride, void *stream);
 int qmann_embed_query_idx(const qmann_net *net, const uint16_t *words, uint32_t max_words, const int8_t *t_q,
                           float *u0, uint32_t n_query, void *stream);
-
-/* Product table of hop `hop`'s linear map (see qmann_net.lin_map_lut): reads net->lin_map[hop] and the formats w[hop], bin;
- * fills `lut` (device, qmann_linmap_lut_bytes(net) bytes: 64 . 256 . 64 = 1 MiB).  dim_emb_pad must be 64. */
-size_t qmann_linmap_lut_bytes(const qmann_net *net);
-int qmann_linmap_lut_build(const qmann_net *net, uint32_t hop, int8_t *lut, void *stream);
 
 /* bytes of LDS one workgroup of qmann_hops_i8 needs for `max_slots` slots (for sizing checks) */
 size_t qmann_hops_lds_bytes(uint32_t max_slots);

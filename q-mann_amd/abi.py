@@ -38,7 +38,6 @@ class Net(C.Structure):
         ("lin_map", _vp * QMANN_MAX_HOP),
         ("softmax_shift_based", C.c_uint32), ("en_att_scale", C.c_uint32), ("att_scale", C.c_float * QMANN_MAX_HOP),
         ("en_non_linearity", C.c_uint32),
-        ("lin_map_lut", _vp * QMANN_MAX_HOP),
     ]
 
 
@@ -122,8 +121,6 @@ _proto("qmann_abi_symbol_count", _u, [])
 
 # ---- batched int8 API (include/qmann_batch.h) ----
 _proto("qmann_hops_lds_bytes", C.c_size_t, [C.c_uint32])
-_proto("qmann_linmap_lut_bytes", C.c_size_t, [C.POINTER(Net)])
-_proto("qmann_linmap_lut_build", C.c_int, [C.POINTER(Net), C.c_uint32, _vp, _vp])
 _proto("qmann_quantize_i8", C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, C.c_uint32, Fmt, C.c_int, _vp])
 _proto("qmann_hops_i8", C.c_int, [C.POINTER(Net), _vp, _vp, C.c_size_t, _vp, C.c_uint32, _vp, _vp,
                                   C.POINTER(Taps), C.c_uint32, _vp])

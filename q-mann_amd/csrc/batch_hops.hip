@@ -170,26 +170,6 @@ __global__ void k_quantize_i8(const float *__restrict__ src, int8_t *__restrict_
 
 inline bool fmt8(qmann_fmt f) { return f.iwl + f.frac >= 1 && f.iwl + f.frac <= 7; }
 
-// qmann_linmap_lut_build: T[i][v + 128][o] = Qw(Qw(H[o][i]) . v) as an int8 code of the weight format -- the term the
-// linear map adds for operand code v in column i (lib/layer_cuda.cu:71: sign . min(floor(|H| |v| / 2^frac_v), max_w)).
-__global__ void __launch_bounds__(256)
-k_linmap_lut(const uint8_t *__restrict__ lin_map, int8_t *__restrict__ lut, uint32_t D, uint32_t Dp, uint32_t f, int maxw, int v_max)
-{
-    const size_t n = (size_t)64u * 256u * 64u;                            // all 64 column blocks (zero beyond D)
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const uint32_t o = (uint32_t)(i & 63u), col = (uint32_t)(i >> 14);
-        const int v = (int)((i >> 6) & 255u) - 128;
-        int t = 0;
-        if (o < D && col < D && v >= -v_max && v <= v_max) {
-            const uint32_t b = lin_map[(size_t)o * Dp + col];
-            const int mag = (int)(((b & 0x7Fu) * (uint32_t)(v < 0 ? -v : v)) >> f);
-            const int m = mag > maxw ? maxw : mag;
-            t = (((b & 0x80u) != 0u) != (v < 0)) ? -m : m;
-        }
-        lut[i] = (int8_t)t;
-    }
-}
-
 }  // namespace
 
 extern "C" {
@@ -203,21 +183,6 @@ int qmann_hops_hambytes_impl(const qmann_net *net, const int8_t *keys, const int
                              const qmann_taps *taps, uint32_t n_query, void *stream);   // batch_hops_ham.hip
 
 int qmann_hops_float_impl(const HopArgs &a, uint32_t Dp, uint32_t max_slots, uint32_t n_query, void *stream);  // batch_hops_float.hip
-
-size_t qmann_linmap_lut_bytes(const qmann_net *net) { return net ? (size_t)64u * 256u * 64u : 0; }
-
-int qmann_linmap_lut_build(const qmann_net *net, uint32_t hop, int8_t *lut, void *stream)
-{
-    if (!net || !lut || hop >= net->n_hop || hop >= QMANN_MAX_HOP || !net->lin_map[hop]) return QMANN_EINVAL;
-    if (net->dim_emb_pad != 64 || net->dim_emb == 0 || net->dim_emb > 64) return QMANN_EUNSUPPORTED;   // the kernels that use it
-    const qmann_fmt fw = net->w[hop], fb = net->bin;
-    if (!fmt8(fw) || (!fmt8(fb) && fb.iwl + fb.frac != 0)) return QMANN_ERANGE;
-    const int v_max = fb.iwl + fb.frac == 0 ? 1 : (1 << (fb.iwl + fb.frac)) - 1;            // the binarised operand is +-1
-    k_linmap_lut<<<1024, 256, 0, (hipStream_t)stream>>>((const uint8_t *)net->lin_map[hop], lut, net->dim_emb, net->dim_emb_pad, fb.frac,
-                                                      (1 << (fw.iwl + fw.frac)) - 1, v_max);
-    QM_LAUNCH_CHECK();
-    return QMANN_OK;
-}
 
 size_t qmann_hops_lds_bytes(uint32_t max_slots)
 {
@@ -278,7 +243,6 @@ int qmann_hops_i8(const qmann_net *net, const int8_t *keys, const int8_t *vals, 
     for (uint32_t h = 0; h < net->n_hop; h++) {
         a.att_scale[h] = net->att_scale[h];
         a.lin_map[h] = net->lin_map[h];
-        a.lm_lut[h] = net->lin_map_lut[h];
         a.act[h] = QFmt{net->act[h].iwl, net->act[h].frac};
         a.w[h] = QFmt{net->w[h].iwl, net->w[h].frac};
         a.att[h] = QFmt{net->att[h].iwl, net->att[h].frac};

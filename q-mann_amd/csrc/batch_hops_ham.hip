@@ -259,7 +259,6 @@ int fill_args(HopArgs &a, const qmann_net *net, const void *keys, const int8_t *
     for (uint32_t h = 0; h < net->n_hop; h++) {
         a.att_scale[h] = net->att_scale[h];
         a.lin_map[h] = net->lin_map[h];
-        a.lm_lut[h] = net->lin_map_lut[h];
         a.act[h] = QFmt{net->act[h].iwl, net->act[h].frac};
         a.w[h] = QFmt{net->w[h].iwl, net->w[h].frac};
         a.att[h] = QFmt{net->att[h].iwl, net->att[h].frac};

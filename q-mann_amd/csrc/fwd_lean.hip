@@ -396,7 +396,6 @@ int fwd_lean(const qmann_net *net, const qmann_net *emb_net, FwdArgs f, uint32_t
         }
         a.att_scale[h] = net->att_scale[h];
         a.lin_map[h] = net->lin_map[h];
-        a.lm_lut[h] = net->lin_map_lut[h];
         a.act[h] = QFmt{net->act[h].iwl, net->act[h].frac};
         a.w[h] = QFmt{net->w[h].iwl, net->w[h].frac};
         a.att[h] = QFmt{net->att[h].iwl, net->att[h].frac};

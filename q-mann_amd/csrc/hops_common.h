@@ -23,7 +23,6 @@ struct HopArgs {
     float *tap_o;
     float *tap_u;
     const int8_t *lin_map[QMANN_MAX_HOP];
-    const int8_t *lm_lut[QMANN_MAX_HOP];    // qmann_net.lin_map_lut (may be NULL)
     uint32_t rows_total;
     uint32_t max_slots;      // the caller's bound on slots per query: LDS is sized by it, longer stories are cut to it
     uint32_t n_hop, D, Dp, softmax_base, en_lin_map;

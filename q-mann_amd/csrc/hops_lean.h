@@ -232,34 +232,7 @@ __device__ __forceinline__ void lean_hop(const HopArgs &a, const LeanArgs &la, u
     *(int16_t *)(lw + kLwOc + lane * 2) = (int16_t)acc;
 
     // ---- linear map + hop update ---------------------------------------------------------------------
-    if (a.en_lin_map && a.lm_lut[h]) {
-        // Table form: lu[o] = sum_i T[i][u_i][o] (per-product truncation and clamp are in the table).  Row i's address is
-        // wavefront-uniform (lane i's code through v_readlane), the 64 lanes read its 64 bytes: one byte load and half an
-        // add per term instead of the packed multiply -- lane o ends with its own row sum, in place.
-        const int8_t *lut = a.lm_lut[h];
-        const int roff = ((int)lane * 256 + kb_code + 128) * 64;         // lane i: byte offset of row (i, u_i)
-        // all 64 rows, no branches (so that every load is in flight before the first add): a column beyond D has code 0 and
-        // its table rows are zero
-        int part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int i0 = 0; i0 < 64; i0 += 16) {
-            int t[16];
-#pragma unroll
-            for (int i = 0; i < 16; i++) t[i] = (int)lut[(size_t)__builtin_amdgcn_readlane(roff, i0 + i) + lane];
-#pragma unroll
-            for (int i = 0; i < 16; i += 2) part[i >> 1] += t[i] + t[i + 1];
-        }
-        const int s0 = (part[0] + part[1]) + (part[2] + part[3]), s1 = (part[4] + part[5]) + (part[6] + part[7]);
-        const int keep = s0 + s1;
-        const int maxw = (1 << wl_w) - 1;
-        const int kw = keep > maxw ? maxw : (keep < -maxw ? -maxw : keep);       // Qw of the row sum
-        const uint32_t mag = (uint32_t)(kw < 0 ? -kw : kw);
-        const uint32_t ma = fa.frac >= fw.frac ? mag << (fa.frac - fw.frac) : mag >> (fw.frac - fa.frac);
-        const int lam = ma > (uint32_t)maxa ? maxa : (int)ma;                  // Qa of that value
-        int un = (kw < 0 ? -lam : lam) + acc;
-        un = un > maxa ? maxa : (un < -maxa ? -maxa : un);
-        u = (lane < D) ? qm_scale_down((float)un, fa.frac) : 0.0f;
-    } else if (a.en_lin_map) {
+    if (a.en_lin_map) {
         const bool reuse = MODE == kModeFixed && wl_w == wl_m && !relu;
         if (!reuse) {
             wave_sync();                                          // every lane is done with the previous image

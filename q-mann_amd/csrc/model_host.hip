@@ -16,7 +16,6 @@ struct qmann_model {
     float *w_q = nullptr, *w_ans = nullptr;
     float *w_a[QMANN_MAX_HOP] = {}, *w_c[QMANN_MAX_HOP] = {};
     int8_t *lin_map[QMANN_MAX_HOP] = {};
-    int8_t *lin_map_lut[QMANN_MAX_HOP] = {};
     int8_t *t_q = nullptr, *t_a[QMANN_MAX_HOP] = {}, *t_c[QMANN_MAX_HOP] = {};
     // workspace, grown on demand
     int8_t *keys = nullptr, *vals = nullptr;
@@ -128,19 +127,12 @@ int qmann_model_create(qmann_model **out, const qmann_net *net, const qmann_weig
         rc = qmann_quantize_table_i8(m->w_a[h], m->t_a[h], m->D, m->Dp, m->V, net->w[h], stream);
         if (rc == QMANN_OK) rc = qmann_quantize_table_i8(m->w_c[h], m->t_c[h], m->D, m->Dp, m->V, net->w[h], stream);
         m->net.lin_map[h] = nullptr;
-        m->net.lin_map_lut[h] = nullptr;
         if (rc == QMANN_OK && net->en_lin_map) {
             float *wh = upload(w->w_h[h], DD, st);
             staged.push_back(wh);
             QM_HIP(hipMalloc((void **)&m->lin_map[h], (size_t)m->D * m->Dp));
             rc = qmann_quantize_i8(wh, m->lin_map[h], m->D, m->D, m->Dp, net->w[h], QMANN_CODE_SIGNMAG, stream);
             m->net.lin_map[h] = m->lin_map[h];
-            // product table of the linear map for the short-memory kernels (1 MiB per hop)
-            if (rc == QMANN_OK && m->Dp == 64 && !getenv("QMANN_NO_LM_LUT")) {
-                QM_HIP(hipMalloc((void **)&m->lin_map_lut[h], qmann_linmap_lut_bytes(&m->net)));
-                rc = qmann_linmap_lut_build(&m->net, h, m->lin_map_lut[h], stream);
-                m->net.lin_map_lut[h] = m->lin_map_lut[h];
-            }
         }
     }
     QM_HIP(hipStreamSynchronize(st));        // the host arrays and the staged floats are free again
@@ -155,7 +147,7 @@ void qmann_model_destroy(qmann_model *m)
     if (!m) return;
     auto drop = [](void *p) { if (p) QM_HIP(hipFree(p)); };
     drop(m->w_q); drop(m->w_ans); drop(m->t_q);
-    for (uint32_t h = 0; h < QMANN_MAX_HOP; h++) { drop(m->w_a[h]); drop(m->w_c[h]); drop(m->lin_map[h]); drop(m->lin_map_lut[h]); drop(m->t_a[h]); drop(m->t_c[h]); }
+    for (uint32_t h = 0; h < QMANN_MAX_HOP; h++) { drop(m->w_a[h]); drop(m->w_c[h]); drop(m->lin_map[h]); drop(m->t_a[h]); drop(m->t_c[h]); }
     drop(m->keys); drop(m->vals); drop(m->planes); drop(m->u0); drop(m->u);
     delete m;
 }

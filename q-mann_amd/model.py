@@ -130,7 +130,7 @@ class QNet:
     weights: float32 numpy arrays w_q [D][V], w_a[h]/w_c[h] [D][V], w_h[h] [D][D], w_ans [V][D];
     w_q / w_a / w_c may be absent for nets that start from ready-made memories."""
 
-    def __init__(self, cfg: dict, weights: dict, device="cuda:0", stream=None, lin_map_lut=True):
+    def __init__(self, cfg: dict, weights: dict, device="cuda:0", stream=None):
         self.cfg = cfg
         self.dev = torch.device(device)
         self.H, self.D, self.V = cfg["n_hop"], cfg["dim_emb"], cfg["dim_input"]
@@ -150,14 +150,6 @@ class QNet:
                 wf = up(weights["w_h"][h])
                 self.lin_map_i8.append(self.quantize_i8(wf, cfg["fmt_w"][h], abi.CODE_SIGNMAG))
                 n.lin_map[h] = self.lin_map_i8[h].data_ptr()
-            # product tables of the linear maps for the short-memory kernels (1 MiB per hop, include/qmann_batch.h)
-            self.lin_map_lut = []
-            if lin_map_lut and self.Dp == 64:
-                for h in range(self.H):
-                    lut = torch.empty(abi.lib.qmann_linmap_lut_bytes(C.byref(n)), dtype=torch.int8, device=self.dev)
-                    abi.check(abi.lib.qmann_linmap_lut_build(C.byref(n), h, _ptr(lut), self._s()), "qmann_linmap_lut_build")
-                    self.lin_map_lut.append(lut)
-                    n.lin_map_lut[h] = lut.data_ptr()
 
     # ---- helpers -------------------------------------------------------------------------
     def _s(self):
