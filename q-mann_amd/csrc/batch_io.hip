@@ -3,6 +3,8 @@
 // (projection, softmax, arg-max, test-phase bookkeeping).
 #include "hops_common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 // ---------------------------------------------------------------------------
@@ -425,44 +427,43 @@ __device__ __forceinline__ int count_code(uint32_t c, uint32_t frac, int maxw)
     const uint64_t k = (uint64_t)c << frac;
     return k > (uint64_t)maxw ? maxw : (int)k;
 }
-// 16 lanes per story row (a lane owns 4 adjacent columns = one dword of a table row), 4 rows per
-// wavefront, persistent workgroups.  Duplicate words are found lane-parallel: lane i holds entry i,
-// compares with the row's other entries by shuffles, and the first occurrence carries the count.
-// TAB_LDS: all 2.n_hop tables staged in LDS once per workgroup (bAbI: 11.5 KB).
-enum { kTabGlobal = 0, kTabLdsAll = 1 };
-template <int TAB>
-__global__ void __launch_bounds__(kBlock)
-k_embed_story_idx(const EmbedIdxArgs a)
+// 16 lanes per story row (a lane owns 4 adjacent columns = one dword of a table row), 4 rows per wavefront step,
+// persistent workgroups.  The kernel is bound by VALU issue, so the work per word slot is kept small:
+//   * which slot adds what (word, count, first occurrence) is settled once per row group: the usual case -- no word
+//     twice in a row -- is found with one LDS atomic per lane on a 256-bit hash bitmap per row; only a group with a
+//     possible repeat compares its slots pairwise;
+//   * the 8 (16) slots of a row are read back as one (two) 16-byte LDS loads and the table reads of all slots are in
+//     flight together, for the A and the C table of a hop at once;
+//   * small dictionaries: all 2.n_hop tables sit in LDS expanded to int16 (one ds_read_b64 per slot and table, no
+//     unpacking; row V is zero so that an empty slot needs no predicate).  Large ones are gathered from L2 as int8.
+constexpr uint32_t kEwWords = 16;                       // word slots per row
+// per-wavefront LDS: wd u16 [4][16], ct u8 [4][16], duplicate-detection bitmaps u32 [4][8]
+constexpr uint32_t kEwWd = 0, kEwCt = 128, kEwBm = 192, kEwWaveBytes = 320;
+
+// One row group (4 rows, 16 lanes each): returns word | count << 16 for a slot that adds, 0xFFFF for one that does not
+// (unused, out of range, or a repeat of a word an earlier slot of the row carries with its count).
+__device__ __forceinline__ uint32_t ew_pack_row(uint32_t w, uint32_t V, bool time_last, uint32_t nw, uint32_t lane, uint32_t *bm)
 {
-    constexpr bool TAB_LDS = TAB != kTabGlobal;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), sub = lane & 15u, grp = lane >> 4;
-    const uint32_t dw = a.Dp / 4;                        // dwords per table row
-    const uint32_t tab_dw = a.V * dw;
-    uint32_t *tabs = (uint32_t *)smem;                   // [n_hop][2][V][dw]
-    if (TAB == kTabLdsAll) {
-        for (uint32_t h = 0; h < a.n_hop; h++)
-            for (uint32_t i = tid; i < tab_dw; i += kBlock) {
-                tabs[(2 * h) * tab_dw + i] = ((const uint32_t *)a.t_a[h])[i];
-                tabs[(2 * h + 1) * tab_dw + i] = ((const uint32_t *)a.t_c[h])[i];
-            }
-        __syncthreads();
+    const uint32_t sub = lane & 15u, grp = lane >> 4;
+    const uint32_t m16 = (uint32_t)(__ballot(w != 0xFFFFu) >> (16 * grp)) & 0xFFFFu;
+    const uint32_t n_valid = 32u - (uint32_t)__clz(m16);
+    const bool valid = w != 0xFFFFu && w < V;
+    const bool is_time = time_last && valid && (sub + 1 == n_valid);
+    if (lane < 32u) bm[lane] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    bool clash = false;
+    if (valid) {
+        const uint32_t bit = 1u << (w & 31u);
+        clash = (atomicOr(&bm[grp * 8u + ((w >> 5) & 7u)], bit) & bit) != 0u;
     }
-    const size_t rows_per_pass = (size_t)gridDim.x * kWaves * 4;
-    const uint32_t h_lo = 0u, h_hi = a.n_hop;
-    for (size_t s0 = ((size_t)blockIdx.x * kWaves + tid / kWave) * 4; s0 < a.rows; s0 += rows_per_pass) {
-        const size_t s = s0 + grp;
-        const bool row_ok = s < a.rows;
-        uint32_t w = 0xFFFFu;
-        if (row_ok && sub < a.max_words) w = a.words[s * a.max_words + sub];
-        const uint32_t m16 = (uint32_t)(__ballot(w != 0xFFFFu) >> (16 * grp)) & 0xFFFFu;
-        const uint32_t n_valid = 32u - (uint32_t)__clz(m16);
-        const bool valid = w != 0xFFFFu && w < a.V;
-        const bool is_time = a.time_last && valid && (sub + 1 == n_valid);
+    uint32_t cnt = 1;
+    bool dup = false;
+    if (__any(clash)) {                                  // a row of this group may hold a word twice: the exact, slow way
         const uint32_t me = w | (valid ? 1u << 16 : 0u) | (is_time ? 1u << 17 : 0u);
-        uint32_t cnt = 0;
-        bool dup = false, timed = false;
-        for (uint32_t j = 0; j < a.max_words; j++) {
+        bool timed = false;
+        cnt = 0;
+        for (uint32_t j = 0; j < nw; j++) {
             const uint32_t o = (uint32_t)__shfl((int)me, (int)j, 16);
             const bool same = (((o ^ me) & 0xFFFFu) == 0u) && ((o >> 16) & 1u);
             const bool o_time = (o >> 17) & 1u;
@@ -471,70 +472,332 @@ k_embed_story_idx(const EmbedIdxArgs a)
             dup |= same && j < sub;
         }
         if (timed) cnt = 1;
-        const uint32_t pack = (w & 0xFFFFu) | (cnt << 16) | ((valid && !dup) ? 1u << 24 : 0u);
+    }
+    return (valid && !dup) ? (w | (cnt << 16)) : 0xFFFFu;
+}
 
-        for (uint32_t c0 = 0; c0 < dw; c0 += 16) {
-            const uint32_t c4 = c0 + sub;
-            const bool col_ok = c4 < dw;
-            for (uint32_t h = h_lo; h < h_hi; h++) {
-                const uint32_t tb = 2u * h;                              // table slot of hop h in LDS
-                const QFmt fw = a.w[h];
-                const int maxw = (1 << (fw.iwl + fw.frac)) - 1;
-                // Sums of <= 16 codes fit 16 bits: columns 0/2 and 1/3 of the dword are kept as packed
-                // int16 pairs (v_pk_* arithmetic).  Codes in units of 2^-frac_w.
-                s16x2 ae = {0, 0}, ao = {0, 0}, ce_ = {0, 0}, co = {0, 0};
-                for (uint32_t e = 0; e < a.max_words; e++) {
-                    const uint32_t pe = (uint32_t)__shfl((int)pack, (int)e, 16);
-                    if (!((pe >> 24) & 1u) || !col_ok) continue;
-                    const uint32_t we = pe & 0xFFFFu, ce = (pe >> 16) & 0xFFu;
-                    uint32_t ta, tc;
-                    if (TAB_LDS) {
-                        ta = tabs[tb * tab_dw + we * dw + c4];
-                        tc = tabs[(tb + 1) * tab_dw + we * dw + c4];
-                    } else {
-                        ta = ((const uint32_t *)a.t_a[h])[(size_t)we * dw + c4];
-                        tc = ((const uint32_t *)a.t_c[h])[(size_t)we * dw + c4];
-                    }
-                    // sign-extended bytes: even columns (0, 2) and odd columns (1, 3)
-                    s16x2 ea = (__builtin_bit_cast(s16x2, ta) << 8) >> 8, oa = __builtin_bit_cast(s16x2, ta) >> 8;
-                    s16x2 ec = (__builtin_bit_cast(s16x2, tc) << 8) >> 8, oc = __builtin_bit_cast(s16x2, tc) >> 8;
-                    // Qw(1 . kw) = kw needs 1.0 to be a value of the format (iwl >= 1); a purely fractional
-                    // format saturates the count itself, like a repeated word: Qw(Qw(count) . kw) per column (rare)
-                    if (ce != 1u || (1 << fw.frac) > maxw) {
-                        const int cc = count_code(ce, fw.frac, maxw);
-#pragma unroll
-                        for (int k = 0; k < 2; k++) {
-                            ea[k] = (short)qm_mul_code(cc, ea[k], fw.frac, maxw); oa[k] = (short)qm_mul_code(cc, oa[k], fw.frac, maxw);
-                            ec[k] = (short)qm_mul_code(cc, ec[k], fw.frac, maxw); oc[k] = (short)qm_mul_code(cc, oc[k], fw.frac, maxw);
-                        }
-                    }                                    // else Qw(1 . kw) = kw
-                    ae += ea; ao += oa; ce_ += ec; co += oc;
-                }
-                // Qw of the sum, then the memory byte: magnitude moved to the target grid (toward zero),
-                // clamped, sign bit from the VALUE (a negative sum that truncates to zero is "minus zero")
-                auto to_bytes = [&](s16x2 x, QFmt dst) {
-                    const short mw = (short)maxw;
-                    x = __builtin_elementwise_min(__builtin_elementwise_max(x, s16x2{(short)-mw, (short)-mw}), s16x2{mw, mw});
-                    u16x2 mag = __builtin_bit_cast(u16x2, __builtin_elementwise_max(x, (s16x2)(-x)));
-                    mag = dst.frac >= fw.frac ? (u16x2)(mag << (unsigned short)(dst.frac - fw.frac))
-                                              : (u16x2)(mag >> (unsigned short)(fw.frac - dst.frac));
-                    const unsigned short md = (unsigned short)((1u << (dst.iwl + dst.frac)) - 1u);
-                    mag = __builtin_elementwise_min(mag, u16x2{md, md});
-                    const u16x2 sgn = __builtin_bit_cast(u16x2, (s16x2)(x >> 8)) & (unsigned short)0x0080;
-                    return __builtin_bit_cast(uint32_t, (u16x2)(mag | sgn));
-                };
-                uint32_t colmask = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) colmask |= (4 * c4 + (uint32_t)k < a.D ? 0xFFu : 0u) << (8 * k);
-                const uint32_t kw = (to_bytes(ae, a.att[h]) | (to_bytes(ao, a.att[h]) << 8)) & colmask;
-                const uint32_t vw = (to_bytes(ce_, a.act[h]) | (to_bytes(co, a.act[h]) << 8)) & colmask;
-                if (row_ok && col_ok) {
-                    *(uint32_t *)(a.keys + (size_t)h * a.hop_stride + s * a.Dp + 4 * c4) = kw;
-                    *(uint32_t *)(a.vals + (size_t)h * a.hop_stride + s * a.Dp + 4 * c4) = vw;
-                }
+// Qw of the sum, then the memory byte: magnitude moved to the target grid (toward zero), clamped, sign bit from the
+// VALUE (a negative sum that truncates to zero is "minus zero")
+__device__ __forceinline__ uint32_t ew_to_bytes(s16x2 x, int maxw, QFmt fw, QFmt dst)
+{
+    const short mw = (short)maxw;
+    x = __builtin_elementwise_min(__builtin_elementwise_max(x, s16x2{(short)-mw, (short)-mw}), s16x2{mw, mw});
+    u16x2 mag = __builtin_bit_cast(u16x2, __builtin_elementwise_max(x, (s16x2)(-x)));
+    mag = dst.frac >= fw.frac ? (u16x2)(mag << (unsigned short)(dst.frac - fw.frac)) : (u16x2)(mag >> (unsigned short)(fw.frac - dst.frac));
+    const unsigned short md = (unsigned short)((1u << (dst.iwl + dst.frac)) - 1u);
+    mag = __builtin_elementwise_min(mag, u16x2{md, md});
+    const u16x2 sgn = __builtin_bit_cast(u16x2, (s16x2)(x >> 8)) & (unsigned short)0x0080;
+    return __builtin_bit_cast(uint32_t, (u16x2)(mag | sgn));
+}
+
+template <bool TAB16>
+__global__ void __launch_bounds__(kBlock)
+k_embed_story_idx(const EmbedIdxArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave, sub = lane & 15u, grp = lane >> 4;
+    const uint32_t V = a.V, H = a.n_hop, nw = a.max_words;
+    const uint32_t dw = a.Dp / 4;                                        // dwords (4 columns) per row: 16, 32 or 64
+    const uint32_t dw_sh = 31u - (uint32_t)__clz(dw);                    // (a full 32-bit multiply costs four plain operations)
+    const uint32_t tab_bytes = TAB16 ? (V + 1u) * dw * 8u : 0u;          // int16 [V + 1][dw]{even-columns pair, odd-columns pair}
+    uint8_t *tabs = smem;                                                // [H][2] tables (A, C)
+    uint8_t *ws = smem + 2u * H * tab_bytes + wave * kEwWaveBytes;
+    uint16_t *wd = (uint16_t *)(ws + kEwWd);
+    uint8_t *ct = ws + kEwCt;
+    uint32_t *bm = (uint32_t *)(ws + kEwBm);
+    if (TAB16) {
+        for (uint32_t t = 0; t < 2u * H; t++) {
+            const uint32_t *src = (const uint32_t *)((t & 1u) ? a.t_c[t >> 1] : a.t_a[t >> 1]);
+            uint2 *dst = (uint2 *)(tabs + t * tab_bytes);
+            for (uint32_t i = tid; i < (V + 1u) * dw; i += kBlock) {
+                const uint32_t x = i < V * dw ? src[i] : 0u;
+                const s16x2 ev = (__builtin_bit_cast(s16x2, x) << 8) >> 8, od = __builtin_bit_cast(s16x2, x) >> 8;
+                dst[i] = uint2{__builtin_bit_cast(uint32_t, ev), __builtin_bit_cast(uint32_t, od)};
             }
         }
+        __syncthreads();
     }
+
+    const size_t rows_per_pass = (size_t)gridDim.x * kWaves * 4;
+    for (size_t s0 = ((size_t)blockIdx.x * kWaves + wave) * 4; s0 < a.rows; s0 += rows_per_pass) {
+        const size_t s = s0 + grp;
+        const bool row_ok = s < a.rows;
+        uint32_t w = 0xFFFFu;
+        if (row_ok && sub < nw) w = a.words[s * nw + sub];
+        const uint32_t pk = ew_pack_row(w, V, a.time_last != 0, nw, lane, bm);
+        wd[grp * kEwWords + sub] = (uint16_t)pk;
+        ct[grp * kEwWords + sub] = (uint8_t)(pk >> 16);
+        const bool multi = __any((pk >> 16) > 1u);
+        // slots 8..15 matter only when some row of the group uses them
+        const uint32_t n_pass = __any(sub >= 8u && (pk & 0xFFFFu) != 0xFFFFu) ? 2u : 1u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        for (uint32_t c0 = 0; c0 < dw; c0 += 16)                          // 64 columns per round (one round at bAbI width)
+        for (uint32_t h = 0; h < H; h++) {
+            const uint32_t c4 = c0 + sub;                                 // (dw is a multiple of 16: Dp is 64, 128 or 256)
+            uint32_t colmask = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) colmask |= (4 * c4 + (uint32_t)k < a.D ? 0xFFu : 0u) << (8 * k);
+            const QFmt fw = a.w[h];
+            const int maxw = (1 << (fw.iwl + fw.frac)) - 1;
+            // Qw(1 . kw) = kw needs 1.0 to be a value of the format (iwl >= 1); a purely fractional format saturates the
+            // count itself, like a repeated word: then every term is Qw(Qw(count) . kw) per column (rare)
+            const bool slow = multi || (1 << fw.frac) > maxw;
+            const void *ta = TAB16 ? (const void *)(tabs + (2u * h) * tab_bytes) : (const void *)a.t_a[h];
+            const void *tc = TAB16 ? (const void *)(tabs + (2u * h + 1u) * tab_bytes) : (const void *)a.t_c[h];
+            s16x2 ae = {0, 0}, ao = {0, 0}, ce = {0, 0}, co = {0, 0};
+            for (uint32_t pass = 0; pass < n_pass; pass++) {
+                const i32x4 wv = *(const i32x4 *)(wd + grp * kEwWords + pass * 8u);
+                s16x2 xa_e[8], xa_o[8], xc_e[8], xc_o[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const uint32_t we = ((uint32_t)wv[e >> 1] >> (16 * (e & 1))) & 0xFFFFu;
+                    if (TAB16) {
+                        const uint32_t off = (((we < V ? we : V) << dw_sh) + c4) * 8u;
+                        const uint2 t1 = *(const uint2 *)((const uint8_t *)ta + off), t2 = *(const uint2 *)((const uint8_t *)tc + off);
+                        xa_e[e] = __builtin_bit_cast(s16x2, t1.x); xa_o[e] = __builtin_bit_cast(s16x2, t1.y);
+                        xc_e[e] = __builtin_bit_cast(s16x2, t2.x); xc_o[e] = __builtin_bit_cast(s16x2, t2.y);
+                    } else {
+                        const bool ok = we < V;
+                        const uint32_t off = ((ok ? we : 0u) << dw_sh) + c4;
+                        const uint32_t t1 = ok ? ((const uint32_t *)ta)[off] : 0u, t2 = ok ? ((const uint32_t *)tc)[off] : 0u;
+                        // sign-extended bytes: even columns (0, 2) and odd columns (1, 3)
+                        xa_e[e] = (__builtin_bit_cast(s16x2, t1) << 8) >> 8; xa_o[e] = __builtin_bit_cast(s16x2, t1) >> 8;
+                        xc_e[e] = (__builtin_bit_cast(s16x2, t2) << 8) >> 8; xc_o[e] = __builtin_bit_cast(s16x2, t2) >> 8;
+                    }
+                }
+                if (slow) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const uint32_t c1 = ct[grp * kEwWords + pass * 8u + e];
+                        const int cc = count_code(c1 ? c1 : 1u, fw.frac, maxw);
+#pragma unroll
+                        for (int k = 0; k < 2; k++) {
+                            xa_e[e][k] = (short)qm_mul_code(cc, xa_e[e][k], fw.frac, maxw); xa_o[e][k] = (short)qm_mul_code(cc, xa_o[e][k], fw.frac, maxw);
+                            xc_e[e][k] = (short)qm_mul_code(cc, xc_e[e][k], fw.frac, maxw); xc_o[e][k] = (short)qm_mul_code(cc, xc_o[e][k], fw.frac, maxw);
+                        }
+                    }
+                }
+                // Sums of <= 16 codes fit 16 bits: columns 0/2 and 1/3 of the dword are kept as packed int16 pairs
+#pragma unroll
+                for (int e = 0; e < 8; e++) { ae += xa_e[e]; ao += xa_o[e]; ce += xc_e[e]; co += xc_o[e]; }
+            }
+            if (row_ok) {
+                *(uint32_t *)(a.keys + (size_t)h * a.hop_stride + s * a.Dp + 4 * c4) = (ew_to_bytes(ae, maxw, fw, a.att[h]) | (ew_to_bytes(ao, maxw, fw, a.att[h]) << 8)) & colmask;
+                *(uint32_t *)(a.vals + (size_t)h * a.hop_stride + s * a.Dp + 4 * c4) = (ew_to_bytes(ce, maxw, fw, a.act[h]) | (ew_to_bytes(co, maxw, fw, a.act[h]) << 8)) & colmask;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                                 // the next group rewrites wd / ct
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The same embedding on the int8 matrix cores, for dictionaries of up to 256 entries (every bAbI configuration).
+// A tile of 16 story rows is a bag-of-words matrix X [16][K] of small counts (K = dictionary size padded to 64) and
+//     E^T [columns][rows] = T^T [columns][K] . X^T
+// is one v_mfma_i32_16x16x64_i8 per 16 columns and 64 dictionary entries, exact in int32.  The operands fall out of the
+// wire format: X is built in LDS with one byte-add per word slot (the time entry is stored as 1 afterwards: it SETS its
+// slot), T^T is staged once per workgroup.  The accumulator layout hands every lane 4 adjacent columns of one row -- one
+// output dword -- so the quantisation epilogue (ew_to_bytes) runs on 2 packed registers per 16 x 16 tile and table.
+// Per 16 rows and hop: ~200 vector instructions instead of ~2 000 for the gather-sum above (that kernel is bound by VALU
+// issue: SQ_INSTS_VALU x 4.2 cycles is 70 % of its run time).
+// What the product cannot express is the per-product clamp of a REPEATED word, Qw(Qw(count) . kw) != count . kw when
+// |count . kw| exceeds the format: the second occurrence of a word in a row is noticed by the byte-add itself (it returns
+// the old count) and those few (row, word) pairs get a per-column correction.  Purely fractional weight formats
+// (1.0 not representable, so even a single word is Qw(Qw(1) . kw)) keep the gather-sum kernel.
+// Grid: x = workgroups over tiles (persistent), y = hop.
+// ---------------------------------------------------------------------------
+constexpr uint32_t kEmRows = 16;                        // story rows per tile
+constexpr uint32_t kEmDupCap = 128;                     // repeated (row, word) pairs a tile can hold: 16 rows x 16 slots / 2
+
+template <int KS, int NW>                               // K / 64: 1, 2 or 4; wavefronts per workgroup (they share T^T)
+__global__ void __launch_bounds__(NW * kWave)
+k_embed_story_mfma(const EmbedIdxArgs a)
+{
+    constexpr uint32_t kBlockEm = NW * kWave;
+    constexpr uint32_t K = 64u * KS;
+    constexpr uint32_t KP = K + 16u;                    // row pitch of T^T and X in LDS: 16 rows 4 banks apart, no conflicts on the fragment loads
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    constexpr uint32_t Dp = 64;                         // bAbI width (wider embeddings take the gather-sum kernel): the product loops
+                                                        // unroll, so a tile's fragment loads and MFMAs are in flight together
+    const uint32_t h = blockIdx.y, V = a.V, nw = a.max_words;
+    int8_t *tt = (int8_t *)smem;                                         // [2][Dp][KP]: A then C of this hop, transposed
+    constexpr uint32_t SP = Dp + 16u;                                    // row pitch of the output staging tile (conflict-free dword writes)
+    uint8_t *ws = smem + 2u * Dp * KP + wave * (kEmRows * KP + kEmRows * SP + kEmDupCap * 4u + 16u);
+    uint32_t *X = (uint32_t *)ws;                                        // [16][KP] bytes
+    uint8_t *stage = ws + kEmRows * KP;                                  // [16][SP] one table's output rows
+    uint32_t *dup = (uint32_t *)(stage + kEmRows * SP);                  // [kEmDupCap] row << 16 | word
+    uint32_t *n_dup = dup + kEmDupCap;
+
+    // ---- T^T of the hop's two tables ------------------------------------------------------------------------------
+    for (uint32_t t = 0; t < 2; t++) {
+        const uint32_t *src = (const uint32_t *)(t ? a.t_c[h] : a.t_a[h]);       // [V][Dp] two's complement
+        int8_t *dst = tt + t * Dp * KP;
+        for (uint32_t i = tid; i < K * (Dp / 4); i += kBlockEm) {
+            const uint32_t k = i / (Dp / 4), c4 = i % (Dp / 4);
+            const uint32_t x = k < V ? src[(size_t)k * (Dp / 4) + c4] : 0u;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) dst[(4 * c4 + j) * KP + k] = (int8_t)(x >> (8 * j));
+        }
+    }
+    __syncthreads();
+
+    const QFmt fw = a.w[h], f_att = a.att[h], f_act = a.act[h];
+    const int maxw = (1 << (fw.iwl + fw.frac)) - 1;
+    const uint32_t r4 = lane >> 2, qd = lane & 3u;                       // word phase: row r4 of the tile, slots 4 qd .. 4 qd + 3
+    const uint32_t nrow = lane & 15u, kq = lane >> 4;                    // matrix phase: story row nrow, K bytes 16 kq .. / columns 4 kq ..
+    const size_t n_tiles = ((size_t)a.rows + kEmRows - 1) / kEmRows;
+    // This lane's 4 word slots of a tile (row r4, slots 4 qd ..): one 8-byte load (the launcher sends word lists whose
+    // pitch is not a multiple of 4 slots to the gather-sum kernel).  Requested one tile ahead so that a wavefront does
+    // not start every tile with a round trip to HBM: the load is unconditional (address clamped into the array) and its
+    // result is not touched before the next iteration -- a predicated load, or any use of the value, makes the compiler
+    // wait for it on the spot.
+    const uint32_t slot0 = 4 * qd < nw ? 4 * qd : 0u;
+    uint2 raw_next = {0u, 0u};
+    auto request_words = [&](size_t tile_) {
+        size_t row = tile_ * kEmRows + r4;
+        row = row < a.rows ? row : a.rows - 1;
+        raw_next = *(const uint2 *)(a.words + row * nw + slot0);
+    };
+    auto take_words = [&](size_t tile_, uint32_t (&w_)[4]) {
+        const bool in = tile_ * kEmRows + r4 < a.rows;
+        w_[0] = raw_next.x & 0xFFFFu; w_[1] = raw_next.x >> 16; w_[2] = raw_next.y & 0xFFFFu; w_[3] = raw_next.y >> 16;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) w_[i] = (in && 4 * qd + i < nw) ? w_[i] : 0xFFFFu;
+    };
+    const size_t tile_step = (size_t)gridDim.x * NW;
+    request_words((size_t)blockIdx.x * NW + wave);
+    // A tile's finished rows (16 bytes per lane and table) are stored at the START of the next iteration, behind that
+    // iteration's word request: vector loads and stores retire in order through one counter, so waiting for the words
+    // of a tile also waits for every older store -- stores issued a whole iteration earlier have long completed, stores
+    // issued just before the wait would put their full latency in front of every tile.
+    i32x4 pend[2];
+    size_t pend_row0 = 0;
+    bool pending = false;
+    auto flush_pending = [&]() {
+        if (!pending) return;
+        const uint32_t r = lane / (Dp / 16u);
+        if (pend_row0 + r < a.rows) {
+            *(i32x4 *)(a.keys + (size_t)h * a.hop_stride + pend_row0 * Dp + (size_t)lane * 16u) = pend[0];
+            *(i32x4 *)(a.vals + (size_t)h * a.hop_stride + pend_row0 * Dp + (size_t)lane * 16u) = pend[1];
+        }
+        pending = false;
+    };
+    for (size_t tile = (size_t)blockIdx.x * NW + wave; tile < n_tiles; tile += tile_step) {
+        const size_t row0 = tile * kEmRows;
+        // ---- X: counts per (row, word) -----------------------------------------------------------------------------
+        for (uint32_t i = lane; i < kEmRows * KP / 16u; i += kWave) *(i32x4 *)((uint8_t *)X + i * 16u) = i32x4{0, 0, 0, 0};
+        if (lane == 0) *n_dup = 0u;
+        uint32_t w[4];
+        take_words(tile, w);
+        request_words(tile + tile_step);
+        flush_pending();                                                 // the previous tile's rows (see below)
+        uint32_t last = 0;                                               // 1 + this row's last non-empty slot
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) last = w[i] != 0xFFFFu ? 4 * qd + i + 1 : last;
+        {   // maximum over the 4 lanes of the row
+            uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)last, 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]
+            last = o > last ? o : last;
+            o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)last, 0x4E, 0xF, 0xF, true);                // quad_perm [2,3,0,1]
+            last = o > last ? o : last;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t time_w = 0xFFFFu;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) {
+            if (w[i] >= V) continue;                                     // empty (0xFFFF) or out of range: ignored
+            if (a.time_last && 4 * qd + i + 1 == last) { time_w = w[i]; continue; }
+            const uint32_t sh = 8u * (w[i] & 3u);
+            const uint32_t old = atomicAdd(&X[r4 * (KP / 4) + (w[i] >> 2)], 1u << sh);
+            if (((old >> sh) & 0xFFu) == 1u) {                           // the second occurrence announces the repeat, once
+                const uint32_t n = atomicAdd(n_dup, 1u);
+                if (n < kEmDupCap) dup[n] = (r4 << 16) | w[i];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (time_w != 0xFFFFu) ((uint8_t *)X)[r4 * KP + time_w] = 1;      // the time entry SETS its slot (sample.c:474)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        i32x4 bx[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) bx[ks] = *(const i32x4 *)((const uint8_t *)X + nrow * KP + ks * 64 + kq * 16);
+
+        // ---- repeated words: does any product Qw(Qw(count) . kw) differ from count . kw?  (it does only when the product
+        // leaves the format: |count . kw| > max_w -- rare; lane = column) ------------------------------------------------
+        const uint32_t nd = *n_dup < kEmDupCap ? *n_dup : kEmDupCap;
+        uint32_t fix_rows = 0;                                           // rows to be summed term by term (wavefront-uniform)
+        for (uint32_t d = 0; d < nd; d++) {
+            const uint32_t e = dup[d], r = e >> 16, wd = e & 0xFFFFu;
+            const int c = (int)((const uint8_t *)X)[r * KP + wd];
+            const int cc = count_code((uint32_t)c, fw.frac, maxw);
+            const int ka = (int)tt[lane * KP + wd], kc = (int)tt[(Dp + lane) * KP + wd];
+            if (__any(qm_mul_code(cc, ka, fw.frac, maxw) != c * ka || qm_mul_code(cc, kc, fw.frac, maxw) != c * kc)) fix_rows |= 1u << r;
+        }
+
+        // ---- the products, the epilogue, the stores ---------------------------------------------------------------
+        // A lane's 4 columns are one dword; the 16 rows of a tile are contiguous in memory, so the tile leaves through an
+        // LDS staging tile as whole rows, 16 bytes per lane (a store of 64 scattered dwords per 16 columns ran at the
+        // rate of one cache line per lane group: the kernel was bound by it).
+        i32x4 acc[2][4];
+#pragma unroll
+        for (uint32_t t = 0; t < 2; t++)
+#pragma unroll
+            for (uint32_t cb = 0; cb < 4; cb++) {
+                acc[t][cb] = i32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < KS; ks++) {
+                    const i32x4 am = *(const i32x4 *)(tt + ((t * Dp + cb * 16u + nrow) * KP + ks * 64 + kq * 16));
+                    acc[t][cb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(am, bx[ks], acc[t][cb], 0, 0, 0);
+                }
+            }
+#pragma unroll
+        for (uint32_t t = 0; t < 2; t++) {
+            const QFmt dstf = t ? f_act : f_att;
+#pragma unroll
+            for (uint32_t cb = 0; cb < 4; cb++) {
+                const i32x4 v = acc[t][cb];                              // v[r]: story row nrow, column 16 cb + 4 kq + r
+                const s16x2 x01 = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm((uint32_t)v[1], (uint32_t)v[0], 0x05040100u));
+                const s16x2 x23 = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm((uint32_t)v[3], (uint32_t)v[2], 0x05040100u));
+                const uint32_t b01 = ew_to_bytes(x01, maxw, fw, dstf), b23 = ew_to_bytes(x23, maxw, fw, dstf);
+                *(uint32_t *)(stage + nrow * SP + cb * 16u + kq * 4u) = __builtin_amdgcn_perm(b23, b01, 0x06040200u);
+            }
+            // a row whose repeated word leaves the format: its sums term by term, Qw(Qw(count) . kw) over the row's distinct
+            // words (the non-zero bytes of its X row), lane = column; replaces the row in the staging tile
+            for (uint32_t m = fix_rows; m; m &= m - 1) {
+                const uint32_t r = (uint32_t)__builtin_ctz(m);
+                const uint32_t xr = lane < K / 4 ? X[r * (KP / 4) + lane] : 0u;
+                int sum = 0;
+                for (uint64_t nz = __ballot(xr != 0u); nz; nz &= nz - 1) {
+                    const uint32_t j = (uint32_t)__builtin_ctzll(nz);
+                    const uint32_t xv = (uint32_t)__builtin_amdgcn_readlane((int)xr, (int)j);
+#pragma unroll
+                    for (uint32_t b = 0; b < 4; b++) {
+                        const uint32_t c = (xv >> (8 * b)) & 0xFFu;
+                        if (c) sum += qm_mul_code(count_code(c, fw.frac, maxw), (int)tt[(t * Dp + lane) * KP + 4 * j + b], fw.frac, maxw);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();                         // (every lane's dword of this row is written)
+                stage[r * SP + lane] = (uint8_t)ew_to_bytes(s16x2{(short)sum, (short)0}, maxw, fw, dstf);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // whole rows, 16 bytes per lane: lane i holds piece i % 4 of row i / 4 (16 rows x 64 bytes = 64 lanes x 16 bytes)
+            pend[t] = *(const i32x4 *)(stage + (lane / (Dp / 16u)) * SP + (lane % (Dp / 16u)) * 16u);
+            __builtin_amdgcn_wave_barrier();                             // the second table reuses the staging tile
+        }
+        pend_row0 = row0;
+        pending = true;
+        __builtin_amdgcn_wave_barrier();                                 // the next tile rewrites X
+    }
+    flush_pending();
 }
 
 // question: word entries only (no time entry, sample.c:557-565); u0[j] = Qw0(sum_k Qw0(Qw0(W[j][k]) . Qw0(c_k))),
@@ -744,16 +1007,48 @@ int qmann_embed_story_idx(const qmann_net *net, const uint16_t *words, uint32_t 
     }
     if (rows_total == 0) return QMANN_OK;
     if ((net->dim_emb_pad & 3u) || (hop_stride & 3u) || ((uintptr_t)keys & 3u) || ((uintptr_t)vals & 3u)) return QMANN_EINVAL;
+    if (net->dim_emb_pad % 64 != 0) return QMANN_EUNSUPPORTED;          // 16 lanes x 4 columns per round
+    // dictionaries of up to 256 entries with 1.0 representable in every weight format: the matrix-core kernel
+    bool mfma_ok = net->dim_input <= 256 && net->dim_emb_pad == 64 && (max_words & 3u) == 0u && ((uintptr_t)words & 7u) == 0u &&
+                   !getenv("QMANN_EMBED_VALU");
+    for (uint32_t h = 0; h < net->n_hop; h++) mfma_ok = mfma_ok && net->w[h].iwl >= 1;
+    if (mfma_ok) {
+        const uint32_t K = net->dim_input <= 64 ? 64u : (net->dim_input <= 128 ? 128u : 256u), Dp = net->dim_emb_pad;
+        // T^T (2 x 64 x (K + 16) bytes) is per workgroup: large dictionaries share it among 16 wavefronts
+        const uint32_t nwv = K == 64 ? 8u : 16u;
+        const size_t lds = 2u * (size_t)Dp * (K + 16u) + (size_t)nwv * (kEmRows * (K + 16u) + kEmRows * (Dp + 16u) + kEmDupCap * 4u + 16u);
+        const size_t tiles = ((size_t)rows_total + kEmRows - 1) / kEmRows;
+        const uint32_t per_cu_l = (uint32_t)(160u * 1024u / (lds + 256u)), per_cu_w = 32u / nwv;
+        const uint32_t per_cu = per_cu_l < per_cu_w ? (per_cu_l ? per_cu_l : 1u) : per_cu_w;
+        const uint32_t cap = 256u * per_cu / net->n_hop + 1u;
+        const uint32_t nx = (uint32_t)((tiles + nwv - 1) / nwv < cap ? (tiles + nwv - 1) / nwv : cap);
+        const dim3 grid(nx, net->n_hop);
+        hipStream_t st = (hipStream_t)stream;
+#define QM_EM_GO(KS_, NW_)                                                                                                       \
+        do {                                                                                                                     \
+            if (lds > 48 * 1024) QM_HIP(hipFuncSetAttribute((const void *)k_embed_story_mfma<KS_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            k_embed_story_mfma<KS_, NW_><<<grid, NW_ * kWave, lds, st>>>(a);                                                      \
+        } while (0)
+        if (K == 64) QM_EM_GO(1, 8); else if (K == 128) QM_EM_GO(2, 16); else QM_EM_GO(4, 16);
+#undef QM_EM_GO
+        QM_LAUNCH_CHECK();
+        return QMANN_OK;
+    }
     const uint32_t need = (rows_total + kWaves * 4 - 1) / (kWaves * 4);
-    const uint32_t blocks = need < 2048u ? need : 2048u;
-    const size_t tab_lds = (size_t)net->n_hop * 2 * net->dim_input * net->dim_emb_pad;
-    // (for dictionaries whose tables exceed 48 KB both alternatives to L2 gathers were measured on the 20-task joint
-    // set and are slower than the 1.4 ms of the gathers: staging one hop's tables at a time (three passes over the
-    // rows, 2.1 ms) and one 91 KB copy per CU shared by a 1024-thread workgroup (1.6 ms))
-    if (tab_lds <= 48 * 1024)
-        k_embed_story_idx<kTabLdsAll><<<blocks, kBlock, tab_lds, (hipStream_t)stream>>>(a);
-    else
-        k_embed_story_idx<kTabGlobal><<<blocks, kBlock, 0, (hipStream_t)stream>>>(a);
+    // small dictionaries: all tables in LDS as int16; larger ones are gathered from L2 (for dictionaries whose tables
+    // exceed LDS both alternatives to L2 gathers were measured on the 20-task joint set in round 1 and were slower:
+    // staging one hop's tables at a time, and one copy per CU shared by a 1024-thread workgroup)
+    const size_t tab_lds = (size_t)net->n_hop * 2 * (net->dim_input + 1u) * net->dim_emb_pad * 2u;
+    const size_t wave_lds = (size_t)kWaves * kEwWaveBytes;
+    if (tab_lds + wave_lds <= 64 * 1024) {
+        const size_t lds = tab_lds + wave_lds;
+        const uint32_t per_cu = (uint32_t)(160u * 1024u / (lds + 256u));
+        const uint32_t cap = 256u * (per_cu < 8u ? per_cu : 8u);
+        if (lds > 48 * 1024) QM_HIP(hipFuncSetAttribute((const void *)k_embed_story_idx<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_embed_story_idx<true><<<need < cap ? need : cap, kBlock, lds, (hipStream_t)stream>>>(a);
+    } else {
+        k_embed_story_idx<false><<<need < 2048u ? need : 2048u, kBlock, wave_lds, (hipStream_t)stream>>>(a);
+    }
     QM_LAUNCH_CHECK();
     return QMANN_OK;
 }

@@ -468,8 +468,9 @@ def test_embedding_from_word_indices_equals_bag_of_words_path(env, gold, name):
     assert k1.abs().sum().item() > 0
 
 
-@pytest.mark.parametrize("V,D,rows", [(500, 70, 203), (40, 60, 57), (120, 128, 33)])
-def test_word_index_embedding_duplicates_large_tables_ragged(env, V, D, rows):
+@pytest.mark.parametrize("V,D,rows,sigma", [(500, 70, 203, 1.5), (40, 60, 57, 1.5), (120, 128, 33, 1.5), (40, 60, 333, 25.0), (200, 64, 1000, 25.0),
+                                             (256, 60, 170, 6.0), (64, 17, 99, 40.0)])
+def test_word_index_embedding_duplicates_large_tables_ragged(env, V, D, rows, sigma):
     """Shuffled repeated words (counts up to 5), empty rows, out-of-range indices, a row count that is
     not a multiple of 4, D that does not fill 16 dwords, tables too large for LDS: all equal the
     bag-of-words path (itself pinned to the oracle above)."""
@@ -501,7 +502,8 @@ def test_word_index_embedding_duplicates_large_tables_ragged(env, V, D, rows):
             ques[q, k] += 1.0
         qw[q, :len(ws)] = ws
     cfg = model.babi_cfg(V, 2, 0, D=D)
-    net = model.QNet(cfg, weights(V * 3 + D, 3, D, V, 1.5))
+    # (sigma 25 .. 40: table codes saturate, so a repeated word's product count . kw leaves the format -- the per-product clamp)
+    net = model.QNet(cfg, weights(V * 3 + D, 3, D, V, sigma))
     net.make_tables()
     k1, v1, u1 = net.embed(torch.from_numpy(story).to(env.dev), torch.from_numpy(ques).to(env.dev))
     k2, v2, u2 = net.embed_idx(torch.from_numpy(sw.view(np.int16)).to(env.dev), torch.from_numpy(qw.view(np.int16)).to(env.dev))
