@@ -297,7 +297,7 @@ def run_bow(args, name, wl, net, cfg, wts, dev, rank, world, model):
         "data": "bAbI qa1 test stories (64-story fixture from the reference's sample.c, replicated), seeded random weights",
         "config": {"workload": name, "slots": "2..10 (mean 5.9)", "dim_emb": 60, "dim_input": cfg["dim_input"],
                    "hops": 3, "queries_per_gpu": B, "format": "Q5.2 + EN_MQ weight formats", "attention_mode": 2,
-                   "stages": ("one qmann_model_forward_words call: embedding, hops and answer layer in ONE kernel (fwd_lean.hip)" if use_idx
+                   "stages": ("one qmann_model_forward_words call: story embedding (int8 MFMA) + question embedding + hops + answer layer" if use_idx
                               else "embed_story + embed_query + hops + answer"),
                    "input": "uint16 word indices" if use_idx else "float bag-of-words",
                    "parallelism": f"replicas x{world}, query-sharded"},
@@ -424,7 +424,7 @@ def run_joint(args, name, wl, cfg, wts, dev, rank, world, model):
         "config": {"workload": name, "slots": f"2..{max_slots} (mean {n_sen.mean():.1f})", "dim_emb": cfg["dim_emb"],
                    "dim_input": cfg["dim_input"], "hops": cfg["n_hop"], "queries_per_gpu": B, "format": "Q5.2",
                    "attention_mode": cfg["attention_mode"], "num_bit": cfg.get("num_bit", 8),
-                   "stages": "one qmann_model_forward_words call: embedding + hops in one kernel (fwd_lean.hip), answer layer in a second",
+                   "stages": "one qmann_model_forward_words call: story embedding (int8 MFMA) + question embedding + hops + answer layer",
                    "parallelism": f"replicas x{world}, query-sharded"},
         "roofline": {"bound": "hbm", "kernel": "whole forward (issue / latency bound at these sizes)",
                      "achieved": bytes_in * args.steps / elapsed / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

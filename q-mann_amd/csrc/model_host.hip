@@ -2,7 +2,6 @@
 // runs the whole test-phase forward of a batch through the batched kernels.  No kernels here.
 #include "qfmt.h"
 #include "rt.h"
-#include "fwd_lean.h"
 #include "../../include/qmann_model.h"
 
 #include <new>
@@ -159,23 +158,7 @@ int qmann_model_forward_words(qmann_model *m, const uint16_t *story_words, uint3
 {
     if (!m || !story_words || !question_words || !row_off || !pred) return QMANN_EINVAL;
     if (n_query == 0) return QMANN_OK;
-    // bAbI-sized stories: the whole forward in one kernel, memories built in LDS and never written to HBM (fwd_lean.hip)
-    int rc = ensure(m, 0, n_query, false);
-    if (rc) return rc;
-    {
-        qmann::FwdArgs f{};
-        f.story_words = story_words; f.question_words = question_words; f.row_off = row_off;
-        f.t_q = m->t_q;
-        for (uint32_t h = 0; h < m->H; h++) { f.t_a[h] = m->t_a[h]; f.t_c[h] = m->t_c[h]; }
-        f.w_ans = m->w_ans; f.answer = answer; f.pred = pred; f.cost = cost; f.match = match;
-        f.n_query = n_query; f.max_words = max_words; f.max_q_words = max_q_words; f.time_last = 1;
-        int answer_done = 0;
-        rc = qmann::fwd_lean(&m->net, &m->emb_net, f, max_slots, m->u, &answer_done, stream);
-        if (rc == QMANN_OK)
-            return answer_done ? QMANN_OK : qmann_answer_f32(&m->net, m->w_ans, m->u, answer, pred, nullptr, cost, match, n_query, stream);
-        if (rc != QMANN_EUNSUPPORTED) return rc;
-    }
-    rc = ensure(m, rows_total, n_query, use_planes(m, max_slots));
+    int rc = ensure(m, rows_total, n_query, use_planes(m, max_slots));
     if (rc) return rc;
     rc = qmann_embed_story_idx(&m->emb_net, story_words, rows_total, max_words, 1, m->t_a, m->t_c, m->keys, m->vals,
                                (size_t)rows_total * m->Dp, stream);
