@@ -86,6 +86,11 @@ typedef struct qmann_net {
     uint32_t en_non_linearity;      /* EN_NON_LINEARITY (define.h): RELU layers non_lin[h] (MemN2N.c:894-896, 2668-2671): the attention of
                                      * hop h >= 1 and the answer layer read RELU(sv), lin_map keeps reading sv (:2435-2437, 2471-2473, 2535-2537);
                                      * u_out is then RELU(sv[n_hop-1]) */
+    uint32_t en_pe;                 /* EN_PE (define.h:298): position encoding.  In the reference it changes the QUESTION's bag-of-words
+                                     * row only (the story lines are commented out, sample.c:529-541): entry of word w at slot j is SET to
+                                     * pe_w[w][j] = 1 + 4 (w / dim_input - 0.5)(j / dim_word - 0.5) (MemN2N.c:606-616, sample.c:559-560).
+                                     * qmann_embed_query_idx applies it to word-index questions; bag-of-words callers pass such rows themselves */
+    uint32_t pe_dim_word;           /* dim_word of that formula: longest sentence + 1 with the time entry (MemN2N.c:575-580) */
 } qmann_net;
 
 /* optional per-query taps for parity tests; any pointer may be NULL */
@@ -166,7 +171,8 @@ int qmann_embed_query(const qmann_net *net, const float *question, const float *
  * last valid entry of a row is its time-encoding index (bag-of-words entry SET to 1; word entries
  * COUNT occurrences -- MemN2N/sample.c:466-475, 544-548).  Tables: int8 [V][Dp] two's-complement
  * codes of Q(w[h]) made by qmann_quantize_table_i8 from the float [D][V] matrices.  Results are
- * bit-identical to qmann_embed_story / qmann_embed_query on the equivalent bag-of-words input. */
+ * bit-identical to qmann_embed_story / qmann_embed_query on the equivalent bag-of-words input (with net->en_pe: on the
+ * question row that carries the position weights). */
 int qmann_quantize_table_i8(const float *w, int8_t *table, uint32_t dim_emb, uint32_t dim_emb_pad,
                             uint32_t dim_input, qmann_fmt fmt, void *stream);
 int qmann_embed_story_idx(const qmann_net *net, const uint16_t *words, uint32_t rows_total, uint32_t max_words,

@@ -15,6 +15,8 @@ What is written (all small .npz files; inputs AND the reference's outputs):
   ref_dense_mat.npz  dense_mat_fwd CPU branch                           (lib/layer.c:2671-2696)
   ref_cross_entropy.npz, ref_activation.npz                             (lib/layer.c:3190-3208, 4226-4244)
   babi_qa1_test64.npz, babi_qa3_test16.npz, babi_joint20_test2000.npz (20-task joint set, word-index form),
+  babi_qa1_test64_pe.npz
+                     question rows of the same 64 stories with EN_PE (position weights, sample.c:559-560)
   babi_qa1_test1000_words.npz, babi_joint20_test20000_words.npz (the FULL test sets of BASELINE configs 2 / 3,
                      word indices as bytes)
                      bag-of-words vectors produced by MemN2N/sample.c from the reference's
@@ -247,6 +249,25 @@ def gen_babi_full_words(ref: Reference, sub: str, task: str, name: str, max_sen_
                   max_line=np.uint32(ml.value))
 
 
+def gen_babi_pe(ref: Reference, sub: str, task: str, n_take: int, name: str, max_sen_len=50):
+    """EN_PE (define.h:298): the question's bag-of-words entries are SET to position weights (sample.c:559-560).  The
+    fixture keeps the reference's float question rows and, from a second load without EN_PE, the word list of every
+    question in order (recovered from the sentence text through the same dictionary: the plain rows only give counts)."""
+    tr = str(DATA / sub / f"{task}_train_set").encode()
+    te = str(DATA / sub / f"{task}_test_set").encode()
+    di, dd, ml, dw = C.c_uint(), C.c_uint(), C.c_uint(), C.c_uint()
+    n = ref.L.ref_babi_load_pe(tr, te, max_sen_len, 200000, 20000, C.byref(di), C.byref(dd), C.byref(ml), C.byref(dw))
+    assert n > 0, n
+    V = di.value
+    n_take = min(n_take, n)
+    fp = C.POINTER(C.c_float)
+    q = np.zeros((n_take, V), np.float32)
+    for i in range(n_take):
+        s_ = np.zeros((ref.L.ref_babi_nsen(i), V), np.float32); a_ = np.zeros(V, np.float32)
+        ref.L.ref_babi_get(i, s_.ctypes.data_as(fp), q[i].ctypes.data_as(fp), a_.ctypes.data_as(fp))
+    np.savez_compressed(GOLD / name, question_pe=q, dim_input=np.uint32(V), dim_dict=np.uint32(dd.value), dim_word=np.uint32(dw.value))
+
+
 def gen_babi_joint(ref: Reference, per_task: int = 100, name: str = "babi_joint20_test2000.npz", max_sen_len=50):
     """BASELINE config 3 data: the reference's joint files are missing (.MISSING_LARGE_BLOBS), so the joint
     sets are the 20 en_1k_parsed files back to back in the same record format (written to a temporary
@@ -353,6 +374,7 @@ def main():
                                              "babi_qa1_test64.npz")
     gen_e2e(ora, story, q, a, n_sen, dim_input)
     gen_babi(ref, "en_1k_parsed", "qa3_three-supporting-facts", 16, "babi_qa3_test16.npz")
+    gen_babi_pe(Reference(), "en_10k_parsed", "qa1_single-supporting-fact", 64, "babi_qa1_test64_pe.npz")
     # the joint dictionary (about 170 words) needs the reference's joint-task limits: a second build of its
     # dataset code with MAX_DICT_LEN 192 / MAX_SEN_LEN 64 (`make -C oracle joint`)
     import subprocess

@@ -322,6 +322,9 @@ class Reference:
         L.ref_activation_fwd.restype = None; L.ref_activation_fwd.argtypes = [_f32p, _f32p, u, C.c_char_p]
         L.ref_babi_load.restype = C.c_int
         L.ref_babi_load.argtypes = [C.c_char_p, C.c_char_p, u, u, u, C.POINTER(u), C.POINTER(u), C.POINTER(u)]
+        if hasattr(L, "ref_babi_load_pe"):
+            L.ref_babi_load_pe.restype = C.c_int
+            L.ref_babi_load_pe.argtypes = [C.c_char_p, C.c_char_p, u, u, u, C.POINTER(u), C.POINTER(u), C.POINTER(u), C.POINTER(u)]
         L.ref_babi_nsen.restype = u; L.ref_babi_nsen.argtypes = [u]
         L.ref_babi_get.restype = None; L.ref_babi_get.argtypes = [u, _f32p, _f32p, _f32p]
 

@@ -110,8 +110,25 @@ void ref_activation_fwd(const float *in, float *out, unsigned dim, const char *t
 static sample *g_test = NULL;
 static unsigned g_n_test = 0, g_dim_input = 0;
 
+static int babi_load(const char *train_path, const char *test_path, unsigned max_sen_len, unsigned n_train_cap,
+                     unsigned n_test_cap, unsigned *dim_input, unsigned *dim_dict, unsigned *max_line_out, int en_pe, unsigned *dim_word_out);
+
 int ref_babi_load(const char *train_path, const char *test_path, unsigned max_sen_len, unsigned n_train_cap,
                   unsigned n_test_cap, unsigned *dim_input, unsigned *dim_dict, unsigned *max_line_out)
+{
+    return babi_load(train_path, test_path, max_sen_len, n_train_cap, n_test_cap, dim_input, dim_dict, max_line_out, 0, NULL);
+}
+
+/* the same with EN_PE (define.h:298): sample_vectorization then SETS a question word's bag-of-words entry to the position
+ * weight pe_w[word][position] (sample.c:559-560); pe_w as the program builds it (MemN2N.c:606-616) */
+int ref_babi_load_pe(const char *train_path, const char *test_path, unsigned max_sen_len, unsigned n_train_cap,
+                     unsigned n_test_cap, unsigned *dim_input, unsigned *dim_dict, unsigned *max_line_out, unsigned *dim_word_out)
+{
+    return babi_load(train_path, test_path, max_sen_len, n_train_cap, n_test_cap, dim_input, dim_dict, max_line_out, 1, dim_word_out);
+}
+
+static int babi_load(const char *train_path, const char *test_path, unsigned max_sen_len, unsigned n_train_cap,
+                     unsigned n_test_cap, unsigned *dim_input, unsigned *dim_dict, unsigned *max_line_out, int en_pe, unsigned *dim_word_out)
 {
     static dictionary dict;
     unsigned n_train = 0, i, j, max_line = 0, max_word = 0;
@@ -135,7 +152,20 @@ int ref_babi_load(const char *train_path, const char *test_path, unsigned max_se
     sample_init(g_test, g_n_test, 0, true);
     idx = (unsigned *)malloc(g_n_test * sizeof(unsigned));
     for (i = 0; i < g_n_test; i++) idx[i] = i;
-    sample_vectorization(g_test, &dict, idx, g_n_test, 0, true, 0, false, NULL, 0.0f);
+    if (en_pe) {
+        const unsigned dim_word = max_word + 1;
+        float **pe_w = (float **)malloc(g_dim_input * sizeof(float *));
+        pe_w[0] = (float *)malloc((size_t)g_dim_input * dim_word * sizeof(float));
+        for (i = 1; i < g_dim_input; i++) pe_w[i] = pe_w[i - 1] + dim_word;
+        for (i = 0; i < g_dim_input; i++)
+            for (j = 0; j < dim_word; j++)
+                pe_w[i][j] = 1.0 + 4.0 * ((float)i / (float)g_dim_input - 0.5) * ((float)j / (float)dim_word - 0.5);   /* MemN2N.c:615 */
+        sample_vectorization(g_test, &dict, idx, g_n_test, 0, true, 0, true, pe_w, 0.0f);
+        if (dim_word_out) *dim_word_out = dim_word;
+        free(pe_w[0]); free(pe_w);
+    } else {
+        sample_vectorization(g_test, &dict, idx, g_n_test, 0, true, 0, false, NULL, 0.0f);
+    }
     free(idx);
     *dim_input = g_dim_input;
     *dim_dict = dict.n;

@@ -38,6 +38,7 @@ class Net(C.Structure):
         ("lin_map", _vp * QMANN_MAX_HOP),
         ("softmax_shift_based", C.c_uint32), ("en_att_scale", C.c_uint32), ("att_scale", C.c_float * QMANN_MAX_HOP),
         ("en_non_linearity", C.c_uint32),
+        ("en_pe", C.c_uint32), ("pe_dim_word", C.c_uint32),
     ]
 
 

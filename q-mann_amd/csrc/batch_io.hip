@@ -805,7 +805,7 @@ k_embed_story_mfma(const EmbedIdxArgs a)
 template <bool TAB_LDS>
 __global__ void __launch_bounds__(kBlock)
 k_embed_query_idx(const uint16_t *__restrict__ words, const int8_t *__restrict__ t_q, float *__restrict__ u0,
-                  uint32_t n_query, uint32_t max_words, uint32_t D, uint32_t Dp, uint32_t V, QFmt fw)
+                  uint32_t n_query, uint32_t max_words, uint32_t D, uint32_t Dp, uint32_t V, QFmt fw, uint32_t pe_dim_word)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), sub = lane & 15u, grp = lane >> 4;
@@ -825,14 +825,24 @@ k_embed_query_idx(const uint16_t *__restrict__ words, const int8_t *__restrict__
         const bool valid = w != 0xFFFFu && w < V;
         const uint32_t me = w | (valid ? 1u << 16 : 0u);
         uint32_t cnt = 0;
-        bool dup = false;
+        bool dup = false, later = false;
         for (uint32_t j = 0; j < max_words; j++) {
             const uint32_t o = (uint32_t)__shfl((int)me, (int)j, 16);
             const bool same = (((o ^ me) & 0xFFFFu) == 0u) && ((o >> 16) & 1u);
             cnt += same ? 1u : 0u;
             dup |= same && j < sub;
+            later |= same && j > sub;
         }
-        const uint32_t pack = (w & 0xFFFFu) | (cnt << 16) | ((valid && !dup) ? 1u << 24 : 0u);
+        uint32_t pack = (w & 0xFFFFu) | (cnt << 16) | ((valid && !dup) ? 1u << 24 : 0u);
+        if (pe_dim_word) {
+            // EN_PE (MemN2N/define.h:298): the bag-of-words entry of a question word is SET to the position weight
+            // pe_w[word][slot] = 1 + 4 (word / dim_input - 0.5)(slot / dim_word - 0.5) (MemN2N.c:615, float quotients, the
+            // rest in double, stored as float; sample.c:559-560), so the last occurrence of a word decides; the term of
+            // the word is then Qw(Qw(W) . Qw(weight)).  The slot field carries the weight's code instead of a count.
+            const float pw = (float)(1.0 + (4.0 * ((double)((float)w / (float)V) - 0.5)) * ((double)((float)sub / (float)pe_dim_word) - 0.5));
+            const uint32_t kx = valid ? (uint32_t)qm_code(pw, fw.iwl, fw.frac) : 0u;
+            pack = (w & 0xFFFFu) | (kx << 16) | ((valid && !later) ? 1u << 24 : 0u);
+        }
         for (uint32_t c0 = 0; c0 < dw; c0 += 16) {
             const uint32_t c4 = c0 + sub;
             const bool col_ok = c4 < dw;
@@ -842,11 +852,11 @@ k_embed_query_idx(const uint16_t *__restrict__ words, const int8_t *__restrict__
                 if (!((pe >> 24) & 1u) || !col_ok) continue;
                 const uint32_t we = pe & 0xFFFFu, ce = (pe >> 16) & 0xFFu;
                 const uint32_t t = TAB_LDS ? tab[we * dw + c4] : ((const uint32_t *)t_q)[(size_t)we * dw + c4];
-                const int cc = count_code(ce, fw.frac, maxw);
+                const int cc = pe_dim_word ? (int)ce : count_code(ce, fw.frac, maxw);
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const int kw = (int)(int8_t)(t >> (8 * k));
-                    acc[k] += (ce == 1u && (1 << fw.frac) <= maxw) ? kw : qm_mul_code(cc, kw, fw.frac, maxw);   // see k_embed_story_idx
+                    acc[k] += (!pe_dim_word && ce == 1u && (1 << fw.frac) <= maxw) ? kw : qm_mul_code(cc, kw, fw.frac, maxw);   // see k_embed_story_idx
                 }
             }
             if (q_ok && col_ok) {
@@ -1065,12 +1075,14 @@ int qmann_embed_query_idx(const qmann_net *net, const uint16_t *words, uint32_t 
     const uint32_t blocks = need < 2048u ? need : 2048u;
     const size_t tab_lds = (size_t)net->dim_input * net->dim_emb_pad;
     const QFmt fw{net->w[0].iwl, net->w[0].frac};
+    if (net->en_pe && net->pe_dim_word == 0) return QMANN_EINVAL;
+    const uint32_t pe_dw = net->en_pe ? net->pe_dim_word : 0u;
     if (tab_lds <= 48 * 1024)
         k_embed_query_idx<true><<<blocks, kBlock, tab_lds, (hipStream_t)stream>>>(
-            words, t_q, u0, n_query, max_words, net->dim_emb, net->dim_emb_pad, net->dim_input, fw);
+            words, t_q, u0, n_query, max_words, net->dim_emb, net->dim_emb_pad, net->dim_input, fw, pe_dw);
     else
         k_embed_query_idx<false><<<blocks, kBlock, 0, (hipStream_t)stream>>>(
-            words, t_q, u0, n_query, max_words, net->dim_emb, net->dim_emb_pad, net->dim_input, fw);
+            words, t_q, u0, n_query, max_words, net->dim_emb, net->dim_emb_pad, net->dim_input, fw, pe_dw);
     QM_LAUNCH_CHECK();
     return QMANN_OK;
 }

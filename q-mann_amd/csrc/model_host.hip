@@ -44,8 +44,12 @@ float *upload(const float *host, size_t n, hipStream_t st)
 }
 
 // packed planes pay off when they are smaller than the bytes (num_bit < 8) and the memory is long enough for
-// bandwidth to matter; otherwise the same scores come straight from the int8 keys
-bool use_planes(const qmann_model *m, uint32_t max_slots) { return packed_mode(m->net) && m->net.num_bit < 8 && max_slots > 64; }
+// bandwidth to matter; otherwise the same scores come straight from the int8 keys.  A plane row must fill a 16-byte load
+// (qmann_hops_packed refuses Dp = 64 with a single plane: 8 bytes per row): that case takes the byte form too.
+bool use_planes(const qmann_model *m, uint32_t max_slots)
+{
+    return packed_mode(m->net) && m->net.num_bit < 8 && max_slots > 64 && (m->Dp / 64) * m->net.num_bit * 8 >= 16;
+}
 
 int ensure(qmann_model *m, size_t rows, uint32_t n_query, bool planes)
 {

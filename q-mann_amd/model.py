@@ -105,6 +105,8 @@ def _net_from_cfg(cfg: dict):
         for h in range(cfg["n_hop"]):
             n.att_scale[h] = float(np.float32(cfg["att_scale"][h]))
     n.en_non_linearity = 1 if cfg.get("en_non_lin") else 0
+    if cfg.get("en_pe"):                                # EN_PE: position weights on the question's word slots
+        n.en_pe, n.pe_dim_word = 1, int(cfg["pe_dim_word"])
     n.en_lin_map = 1 if cfg.get("en_lin_map", True) else 0
     n.num_bit = cfg.get("num_bit", 8)
     for h in range(cfg["n_hop"]):

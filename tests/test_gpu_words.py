@@ -36,6 +36,26 @@ def weights(seed, H, D, V, sigma=1.0):
             "w_ans": rng.normal(0, 0.1, (V, D)).astype(np.float32)}
 
 
+def pe_weight(i, j, dim_input, dim_word):
+    """MemN2N/MemN2N.c:615 -- float quotients, the rest in double, stored as float (pinned in test_oracle_golden.py)"""
+    a = np.float64(np.float32(i) / np.float32(dim_input)) - 0.5
+    b = np.float64(np.float32(j) / np.float32(dim_word)) - 0.5
+    return np.float32(1.0 + (4.0 * a) * b)
+
+
+def question_rows(qw, cfg):
+    """bag-of-words rows of word-index questions: counts, or -- EN_PE -- the position weight of a word's LAST slot"""
+    V = cfg["dim_input"]
+    if not cfg.get("en_pe"):
+        return words_to_bow(qw, V, False)
+    out = np.zeros((qw.shape[0], V), np.float32)
+    for r, row in enumerate(qw):
+        for j, w in enumerate(row):
+            if w != 0xFFFF and w < V:
+                out[r, w] = pe_weight(int(w), j, V, cfg["pe_dim_word"])
+    return out
+
+
 def run_both(env, cfg, wts, sw, qw, n_sen, ans=None, max_slots=None):
     """the host model's forward from word indices, and the same batch through bag-of-words rows -> k_embed_story ->
     general hop kernel -> answer layer; returns the host model's outputs"""
@@ -64,7 +84,7 @@ def run_both(env, cfg, wts, sw, qw, n_sen, ans=None, max_slots=None):
         q1 = min(B, q0 + step)
         r0, r1 = int(row_off[q0]), int(row_off[q1])
         story = torch.from_numpy(words_to_bow(sw[r0:r1], V, True)).to(env.dev) if r1 > r0 else torch.zeros((1, V), device=env.dev)
-        ques = torch.from_numpy(words_to_bow(qw[q0:q1], V, False)).to(env.dev)
+        ques = torch.from_numpy(question_rows(qw[q0:q1], cfg)).to(env.dev)
         ro = torch.from_numpy((row_off[q0:q1 + 1] - r0).astype(np.int32)).to(env.dev)
         keys, vals, u0 = net.embed(story, ques)
         u, _ = net.hops(keys, vals, ro, ms, u0, taps=True)       # taps: the general hop kernel
@@ -113,7 +133,7 @@ def oracle_sample(oracle, cfg, wts, sw, qw, n_sen, pred, u, pick):
     excused = 0
     for i in pick:
         st = words_to_bow(sw[offs[i]:offs[i + 1]], V, True)
-        qu = words_to_bow(qw[i:i + 1], V, False)[0]
+        qu = question_rows(qw[i:i + 1], cfg)[0]
         op, t = oracle.forward(m, st, qu, taps=("u", "probs", "out_probs"))
         if np.array_equal(u[i], t["u"][H - 1]):
             top2 = np.sort(t["out_probs"])[-2:]
@@ -218,3 +238,38 @@ def test_many_queries_persistent_grid(env):
     sw, qw, n_sen = random_stories(rng, 50000, V, 20, 8, [2, 4, 6, 8, 10], dup_every=50)
     cfg = env.model.babi_cfg(V, attention_mode=2, D=D)
     run_both(env, cfg, weights(3, 3, D, V), sw, qw, n_sen, rng.integers(0, V, 50000))
+
+
+def test_position_encoding_reference_rows(env, oracle):
+    """EN_PE on the reference's own data: the question rows the reference builds with position weights (fixture
+    babi_qa1_test64_pe.npz) give the ordered word lists back; the word-index path with qmann_net.en_pe must then equal the
+    bag-of-words path fed with exactly those rows, and the oracle."""
+    g = np.load(GOLD / "babi_qa1_test64_pe.npz")
+    w = np.load(GOLD / "babi_qa1_test1000_words.npz")
+    V, dw, n = int(g["dim_input"]), int(g["dim_word"]), 64
+    qw = np.full((n, 8), 0xFFFF, np.uint16)
+    for r, row in enumerate(g["question_pe"]):
+        for i in np.flatnonzero(row):
+            j = [j for j in range(dw) if pe_weight(i, j, V, dw) == row[i]]
+            qw[r, j[0]] = i
+    n_sen = w["n_sen"][:n].astype(np.int64)
+    sw = words16(w["story_words"][:int(n_sen.sum())], 8)
+    cfg = env.model.babi_cfg(V, attention_mode=2)
+    cfg.update(en_pe=True, pe_dim_word=dw)
+    assert np.array_equal(question_rows(qw, cfg), g["question_pe"])       # the test's restatement equals the reference's rows
+    wts = weights(21, 3, 60, V, 1.5)
+    pred, u = run_both(env, cfg, wts, sw, qw, n_sen, w["answer"][:n].astype(np.int64))
+    oracle_sample(oracle, cfg, wts, sw, qw, n_sen, pred, u, list(range(n)))
+
+
+@pytest.mark.parametrize("V,fmt_w0", [(30, (6, 1)), (238, (5, 2)), (70, (2, 5)), (500, (1, 6))])
+def test_position_encoding_random_questions(env, V, fmt_w0):
+    """EN_PE with repeated question words (the last slot decides), empty slots in the middle, out-of-range words, weight
+    formats from coarse to fine"""
+    rng = np.random.default_rng(V)
+    sw, qw, n_sen = random_stories(rng, 300, V, V - 12, 8, [1, 3, 7, 20])
+    qw[::3, 2] = 0xFFFF                                   # a hole: later slots keep their positions
+    cfg = env.model.babi_cfg(V, attention_mode=2, en_mq=False)
+    cfg["fmt_w"] = [fmt_w0] + cfg["fmt_w"][1:]
+    cfg.update(en_pe=True, pe_dim_word=9)
+    run_both(env, cfg, weights(V, 3, 60, V, 1.5), sw, qw, n_sen, rng.integers(0, V, 300))

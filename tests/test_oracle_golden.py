@@ -167,3 +167,24 @@ def test_oracle_e2e_regression(oracle, gold):
             preds.append(pred); us.append(t["u"])
         np.testing.assert_array_equal(np.array(preds), e[f"pred_m{mode}"][:16])
         np.testing.assert_array_equal(np.stack(us), e[f"u_m{mode}"][:16])
+
+
+def pe_weight(i, j, dim_input, dim_word):
+    """MemN2N/MemN2N.c:615 -- float quotients, the rest in double, stored as float"""
+    a = np.float64(np.float32(i) / np.float32(dim_input)) - 0.5
+    b = np.float64(np.float32(j) / np.float32(dim_word)) - 0.5
+    return np.float32(1.0 + (4.0 * a) * b)
+
+
+def test_position_encoding_weights_are_the_reference_s(gold):
+    """EN_PE: every non-zero entry of the reference's question rows (sample.c:559-560, fixture babi_qa1_test64_pe.npz) is
+    the position weight of that word at one slot of the question, bit for bit; distinct words sit at distinct slots."""
+    g = gold("babi_qa1_test64_pe.npz")
+    V, dw = int(g["dim_input"]), int(g["dim_word"])
+    for row in g["question_pe"]:
+        slots = []
+        for i in np.flatnonzero(row):
+            js = [j for j in range(dw) if pe_weight(i, j, V, dw) == row[i]]
+            assert len(js) == 1, (i, row[i], js)
+            slots.append(js[0])
+        assert len(set(slots)) == len(slots) and sorted(slots) == list(range(len(slots)))
