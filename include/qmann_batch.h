@@ -10,8 +10,9 @@
  * handle (hipStream_t passed as void*; NULL = the null stream).
  *
  * Return value of every function: 0 on success, a negative QMANN_E* code on a
- * caller error (nothing is launched); HIP runtime failures follow the
- * boundary's convention instead -- message on stderr and exit().
+ * caller error (nothing is launched) or QMANN_EHIP when the HIP runtime fails
+ * (message on stderr; unlike the drop-in cuda_* verbs, which exit() as the
+ * reference does, these calls return).
  *
  * Data layout ("memory" = the per-query story slots):
  *   keys, vals : int8 [n_hop][rows_total][Dp]    SIGN-MAGNITUDE codes: bit 7 = sign, bits 6..0 =
@@ -41,7 +42,8 @@ extern "C" {
 
 #define QMANN_MAX_HOP 8
 
-enum { QMANN_OK = 0, QMANN_EINVAL = -1, QMANN_ERANGE = -2, QMANN_EUNSUPPORTED = -3, QMANN_EIO = -4 };
+enum { QMANN_OK = 0, QMANN_EINVAL = -1, QMANN_ERANGE = -2, QMANN_EUNSUPPORTED = -3, QMANN_EIO = -4,
+       QMANN_EHIP = -5 /* a HIP runtime call failed (message on stderr); the process goes on */ };
 
 /* attention_mode: MemN2N/define.h:10-15 (1..3) plus the packed-code Hamming forms */
 enum {
@@ -108,7 +110,10 @@ int qmann_quantize_i8(const float *src, int8_t *dst, size_t rows, uint32_t cols,
                       qmann_fmt fmt, int layout, void *stream);
 
 /* The hot path: all hops of all queries in one launch (one workgroup per query).
- *   max_slots                  -- bound on row_off[q+1] - row_off[q]; sizes the per-query LDS, a longer story is cut to it
+ *   max_slots                  -- bound on row_off[q+1] - row_off[q]; sizes the per-query LDS.  A story longer than the bound
+ *                                 is CUT (to max_slots, or to 64 when the bound is below 64): the call still returns 0 and
+ *                                 the result is that of the shortened story -- pass the true maximum (qmann_check_slots below
+ *                                 verifies a bound on the device)
  *   u0    [n_query][D] float   -- question embedding (emb_q output)
  *   u_out [n_query][D] float   -- sv[n_hop-1] output, input of the answer layer
  * Replaces, per query and hop, the reference sequence dot_mat_vec_fwd -> softmax_fwd ->
@@ -180,6 +185,10 @@ int qmann_embed_story_idx(const qmann_net *net, const uint16_t *words, uint32_t 
                           int8_t *vals, size_t hop_stride, void *stream);
 int qmann_embed_query_idx(const qmann_net *net, const uint16_t *words, uint32_t max_words, const int8_t *t_q,
                           float *u0, uint32_t n_query, void *stream);
+
+/* Validation helper: *n_over (a device word, accumulated into) += the number of queries whose story is longer than
+ * max_slots, i.e. would be cut by the hop kernels. */
+int qmann_check_slots(const uint32_t *row_off, uint32_t n_query, uint32_t max_slots, uint32_t *n_over, void *stream);
 
 /* bytes of LDS one workgroup of qmann_hops_i8 needs for `max_slots` slots (for sizing checks) */
 size_t qmann_hops_lds_bytes(uint32_t max_slots);

@@ -122,6 +122,7 @@ _proto("qmann_abi_symbol_count", _u, [])
 
 # ---- batched int8 API (include/qmann_batch.h) ----
 _proto("qmann_hops_lds_bytes", C.c_size_t, [C.c_uint32])
+_proto("qmann_check_slots", C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp, _vp])
 _proto("qmann_quantize_i8", C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, C.c_uint32, Fmt, C.c_int, _vp])
 _proto("qmann_hops_i8", C.c_int, [C.POINTER(Net), _vp, _vp, C.c_size_t, _vp, C.c_uint32, _vp, _vp,
                                   C.POINTER(Taps), C.c_uint32, _vp])

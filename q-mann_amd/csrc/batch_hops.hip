@@ -170,6 +170,16 @@ __global__ void k_quantize_i8(const float *__restrict__ src, int8_t *__restrict_
 
 inline bool fmt8(qmann_fmt f) { return f.iwl + f.frac >= 1 && f.iwl + f.frac <= 7; }
 
+// qmann_check_slots: how many stories exceed the caller's bound (and would be cut by the hop kernels)
+__global__ void k_check_slots(const uint32_t *__restrict__ row_off, uint32_t n_query, uint32_t max_slots, uint32_t *n_over)
+{
+    uint32_t mine = 0;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_query; q += (size_t)gridDim.x * blockDim.x)
+        mine += (row_off[q + 1] - row_off[q] > max_slots) ? 1u : 0u;
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    if ((threadIdx.x & 63u) == 0 && mine) atomicAdd(n_over, mine);
+}
+
 }  // namespace
 
 extern "C" {
@@ -184,6 +194,17 @@ int qmann_hops_hambytes_impl(const qmann_net *net, const int8_t *keys, const int
 
 int qmann_hops_float_impl(const HopArgs &a, uint32_t Dp, uint32_t max_slots, uint32_t n_query, void *stream);  // batch_hops_float.hip
 
+int qmann_check_slots(const uint32_t *row_off, uint32_t n_query, uint32_t max_slots, uint32_t *n_over, void *stream)
+{
+    QmBatched qm_scope;
+    if (!row_off || !n_over) return QMANN_EINVAL;
+    if (n_query == 0) return QMANN_OK;
+    const uint32_t blocks = (n_query + 255u) / 256u;
+    k_check_slots<<<blocks < 1024u ? blocks : 1024u, 256, 0, (hipStream_t)stream>>>(row_off, n_query, max_slots, n_over);
+    QM_LAUNCH_CHECK();
+    return qm_scope.rc();
+}
+
 size_t qmann_hops_lds_bytes(uint32_t max_slots)
 {
     return (size_t)kOffScores + (((size_t)max_slots + 15) & ~(size_t)15);
@@ -192,6 +213,7 @@ size_t qmann_hops_lds_bytes(uint32_t max_slots)
 int qmann_quantize_i8(const float *src, int8_t *dst, size_t rows, uint32_t cols, uint32_t pitch, qmann_fmt fmt,
                       int layout, void *stream)
 {
+    QmBatched qm_scope;
     if (!src || !dst || pitch < cols) return QMANN_EINVAL;
     if (!fmt8(fmt)) return QMANN_ERANGE;
     if (layout != QMANN_CODE_TWOS && layout != QMANN_CODE_SIGNMAG) return QMANN_EINVAL;
@@ -201,13 +223,14 @@ int qmann_quantize_i8(const float *src, int8_t *dst, size_t rows, uint32_t cols,
     k_quantize_i8<<<(unsigned)(blocks < 262144 ? blocks : 262144), 256, 0, (hipStream_t)stream>>>(src, dst, rows, cols, pitch,
                                                                               QFmt{fmt.iwl, fmt.frac}, layout);
     QM_LAUNCH_CHECK();
-    return QMANN_OK;
+    return qm_scope.rc();
 }
 
 int qmann_hops_i8(const qmann_net *net, const int8_t *keys, const int8_t *vals, size_t hop_stride,
                   const uint32_t *row_off, uint32_t max_slots, const float *u0, float *u_out,
                   const qmann_taps *taps, uint32_t n_query, void *stream)
 {
+    QmBatched qm_scope;
     if (!net || !keys || !vals || !row_off || !u0 || !u_out) return QMANN_EINVAL;
     if (net->n_hop == 0 || net->n_hop > QMANN_MAX_HOP) return QMANN_EINVAL;
     if (net->dim_emb == 0 || net->dim_emb > net->dim_emb_pad) return QMANN_EINVAL;
@@ -256,14 +279,14 @@ int qmann_hops_i8(const qmann_net *net, const int8_t *keys, const int8_t *vals, 
     if (lean_supported(a, max_slots, 64)) {                 // hops_lean.h
         launch_lean<kModeFixed, 8>(a, max_slots, n_query, st);
         QM_LAUNCH_CHECK();
-        return QMANN_OK;
+        return qm_scope.rc();
     }
     if (max_slots <= (uint32_t)kWave) {                     // hops_small.h
         if (net->dim_emb_pad == 64) k_hops_small<4, 4, kModeFixed, 8><<<n_query, kWave, 0, st>>>(a, 64);
         else if (net->dim_emb_pad == 128) k_hops_small<8, 8, kModeFixed, 8><<<n_query, kWave, 0, st>>>(a, 128);
         else k_hops_small<16, 16, kModeFixed, 8><<<n_query, kWave, 0, st>>>(a, 256);
         QM_LAUNCH_CHECK();
-        return QMANN_OK;
+        return qm_scope.rc();
     }
     // memories of 65..256 slots run one wavefront per query with the histogram softmax: four times
     // as many queries resident per CU and no cross-wavefront barriers
@@ -281,7 +304,7 @@ int qmann_hops_i8(const qmann_net *net, const int8_t *keys, const int8_t *vals, 
     else QM_LAUNCH_HOPS(8, kUnrollDefault, true, 1);
 #undef QM_LAUNCH_HOPS
     QM_LAUNCH_CHECK();
-    return QMANN_OK;
+    return qm_scope.rc();
 }
 
 }  // extern "C"

@@ -214,6 +214,7 @@ void launch_float(const HopArgs &a, size_t lds, uint32_t n_query, hipStream_t st
 
 extern "C" int qmann_hops_float_impl(const HopArgs &a, uint32_t Dp, uint32_t max_slots, uint32_t n_query, void *stream)
 {
+    QmBatched qm_scope;
     static_assert(kOffHist + 1024 + kWaves * 256 * 4 <= kOffU, "partial sums must fit the histogram + p-table area");
     const size_t lds = (size_t)kOffScores + (((size_t)max_slots * 4 + 15) & ~(size_t)15);
     if (lds > 160 * 1024 - 1024) return QMANN_ERANGE;
@@ -222,5 +223,5 @@ extern "C" int qmann_hops_float_impl(const HopArgs &a, uint32_t Dp, uint32_t max
     else if (Dp == 128) launch_float<8>(a, lds, n_query, st);
     else launch_float<16>(a, lds, n_query, st);
     QM_LAUNCH_CHECK();
-    return QMANN_OK;
+    return qm_scope.rc();
 }

@@ -288,6 +288,7 @@ extern "C" {
 int qmann_pack_bitplanes(const int8_t *sm_codes, uint64_t *planes, size_t rows, uint32_t dim_emb_pad,
                          uint32_t num_bit, void *stream)
 {
+    QmBatched qm_scope;
     if (!sm_codes || !planes) return QMANN_EINVAL;
     if (dim_emb_pad % 64 != 0 || num_bit < 1 || num_bit > 8) return QMANN_EINVAL;
     const size_t items = rows * (dim_emb_pad / 64);
@@ -296,7 +297,7 @@ int qmann_pack_bitplanes(const int8_t *sm_codes, uint64_t *planes, size_t rows, 
     k_pack_planes<<<(unsigned)(blocks < 65536 ? blocks : 65536), kBlock, 0, (hipStream_t)stream>>>(
         (const uint8_t *)sm_codes, planes, rows, dim_emb_pad, num_bit);
     QM_LAUNCH_CHECK();
-    return QMANN_OK;
+    return qm_scope.rc();
 }
 
 // APPX on sign-magnitude int8 keys (called from qmann_hops_i8)
@@ -304,6 +305,7 @@ int qmann_hops_appx_impl(const qmann_net *net, const int8_t *keys, const int8_t 
                          const uint32_t *row_off, uint32_t max_slots, const float *u0, float *u_out,
                          const qmann_taps *taps, uint32_t n_query, void *stream)
 {
+    QmBatched qm_scope;
     HopArgs a;
     const int rc = fill_args(a, net, keys, vals, hop_stride, hop_stride, row_off, u0, u_out, taps);
     if (rc) return rc;
@@ -316,20 +318,20 @@ int qmann_hops_appx_impl(const qmann_net *net, const int8_t *keys, const int8_t 
     if (lean_supported(a, max_slots, 64)) {                 // hops_lean.h
         launch_lean<kModeAppx, 8>(a, max_slots, n_query, st);
         QM_LAUNCH_CHECK();
-        return QMANN_OK;
+        return qm_scope.rc();
     }
     if (max_slots <= (uint32_t)kWave) {                     // hops_small.h
         if (net->dim_emb_pad == 64) k_hops_small<4, 4, kModeAppx, 8><<<n_query, kWave, 0, st>>>(a, 64);
         else if (net->dim_emb_pad == 128) k_hops_small<8, 8, kModeAppx, 8><<<n_query, kWave, 0, st>>>(a, 128);
         else k_hops_small<16, 16, kModeAppx, 8><<<n_query, kWave, 0, st>>>(a, 256);
         QM_LAUNCH_CHECK();
-        return QMANN_OK;
+        return qm_scope.rc();
     }
     if (net->dim_emb_pad == 64) launch<4, 64, kModeAppx, 8>(a, 64, lds, max_slots, n_query, st);
     else if (net->dim_emb_pad == 128) launch<8, 128, kModeAppx, 8>(a, 128, lds, max_slots, n_query, st);
     else launch<16, 256, kModeAppx, 8>(a, 256, lds, max_slots, n_query, st);
     QM_LAUNCH_CHECK();
-    return QMANN_OK;
+    return qm_scope.rc();
 }
 
 // V0 / V1 straight from sign-magnitude int8 keys (called from qmann_hops_i8)
@@ -337,6 +339,7 @@ int qmann_hops_hambytes_impl(const qmann_net *net, const int8_t *keys, const int
                              const uint32_t *row_off, uint32_t max_slots, const float *u0, float *u_out,
                              const qmann_taps *taps, uint32_t n_query, void *stream)
 {
+    QmBatched qm_scope;
     const uint32_t nb = net->num_bit, Dp = net->dim_emb_pad;
     if (nb != 1 && nb != 2 && nb != 4 && nb != 8) return QMANN_EUNSUPPORTED;
     HopArgs a;
@@ -355,7 +358,7 @@ int qmann_hops_hambytes_impl(const qmann_net *net, const int8_t *keys, const int
         else { if (nb == 1) launch_lean<kModeV0Bytes, 1>(a, max_slots, n_query, st); else if (nb == 2) launch_lean<kModeV0Bytes, 2>(a, max_slots, n_query, st);
                else if (nb == 4) launch_lean<kModeV0Bytes, 4>(a, max_slots, n_query, st); else launch_lean<kModeV0Bytes, 8>(a, max_slots, n_query, st); }
         QM_LAUNCH_CHECK();
-        return QMANN_OK;
+        return qm_scope.rc();
     }
 #define QM_HAMB(DP, NB)                                                                                   \
     do {                                                                                                  \
@@ -372,13 +375,14 @@ int qmann_hops_hambytes_impl(const qmann_net *net, const int8_t *keys, const int
 #undef QM_HAMB_NB
 #undef QM_HAMB
     QM_LAUNCH_CHECK();
-    return QMANN_OK;
+    return qm_scope.rc();
 }
 
 int qmann_hops_packed(const qmann_net *net, const uint64_t *key_planes, size_t key_hop_stride, const int8_t *vals,
                       size_t val_hop_stride, const uint32_t *row_off, uint32_t max_slots, const float *u0,
                       float *u_out, const qmann_taps *taps, uint32_t n_query, void *stream)
 {
+    QmBatched qm_scope;
     if (!net) return QMANN_EINVAL;
     if (net->attention_mode != QMANN_ATT_HAMMING_V0 && net->attention_mode != QMANN_ATT_HAMMING_V1)
         return QMANN_EUNSUPPORTED;
@@ -411,7 +415,7 @@ int qmann_hops_packed(const qmann_net *net, const uint64_t *key_planes, size_t k
     else { if (nb == 1) QM_HAM(256, 1); else if (nb == 2) QM_HAM(256, 2); else if (nb == 4) QM_HAM(256, 4); else QM_HAM(256, 8); }
 #undef QM_HAM
     QM_LAUNCH_CHECK();
-    return QMANN_OK;
+    return qm_scope.rc();
 }
 
 }  // extern "C"

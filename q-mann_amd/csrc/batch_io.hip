@@ -890,6 +890,7 @@ extern "C" {
 int qmann_answer_f32(const qmann_net *net, const float *w_ans, const float *u, const uint32_t *answer,
                      uint32_t *pred, float *probs, float *cost, uint32_t *match, uint32_t n_query, void *stream)
 {
+    QmBatched qm_scope;
     if (!net || !w_ans || !u || !pred) return QMANN_EINVAL;
     const uint32_t D = net->dim_emb, V = net->dim_input;
     if (D == 0 || V == 0) return QMANN_EINVAL;
@@ -909,18 +910,19 @@ int qmann_answer_f32(const qmann_net *net, const float *w_ans, const float *u, c
         else if (V <= 128) k_answer_small<2><<<blocks, kAnsBlock, lds_small, st>>>(w_ans, u, answer, pred, probs, cost, match, D, V, net->softmax_base, n_query);
         else k_answer_small<4><<<blocks, kAnsBlock, lds_small, st>>>(w_ans, u, answer, pred, probs, cost, match, D, V, net->softmax_base, n_query);
         QM_LAUNCH_CHECK();
-        return QMANN_OK;
+        return qm_scope.rc();
     }
     k_answer<false><<<n_query < 8192u ? n_query : 8192u, kBlock, lds, (hipStream_t)stream>>>(
         w_ans, u, answer, pred, probs, cost, match, D, V, net->softmax_base, n_query);
     QM_LAUNCH_CHECK();
-    return QMANN_OK;
+    return qm_scope.rc();
 }
 
 int qmann_answer_i8(const qmann_net *net, const int8_t *w_ans_i8, qmann_fmt w_fmt, const float *u, float *logits_ws,
                     const uint32_t *answer, uint32_t *pred, float *probs, float *cost, uint32_t *match,
                     uint32_t n_query, void *stream)
 {
+    QmBatched qm_scope;
     if (!net || !w_ans_i8 || !u || !logits_ws || !pred) return QMANN_EINVAL;
     const uint32_t D = net->dim_emb, Dp = net->dim_emb_pad, V = net->dim_input;
     if (D == 0 || V == 0 || Dp % 64 != 0 || D > Dp) return QMANN_EINVAL;
@@ -943,12 +945,13 @@ int qmann_answer_i8(const qmann_net *net, const int8_t *w_ans_i8, qmann_fmt w_fm
     k_answer<true><<<n_query < 8192u ? n_query : 8192u, kBlock, lds, (hipStream_t)stream>>>(
         logits_ws, nullptr, answer, pred, probs, cost, match, D, V, net->softmax_base, n_query);
     QM_LAUNCH_CHECK();
-    return QMANN_OK;
+    return qm_scope.rc();
 }
 
 int qmann_embed_story(const qmann_net *net, const float *story, uint32_t rows_total, const float *const *w_a,
                       const float *const *w_c, int8_t *keys, int8_t *vals, size_t hop_stride, void *stream)
 {
+    QmBatched qm_scope;
     if (!net || !story || !w_a || !w_c || !keys || !vals) return QMANN_EINVAL;
     if (net->n_hop == 0 || net->n_hop > QMANN_MAX_HOP || net->dim_emb > net->dim_emb_pad) return QMANN_EINVAL;
     if (hop_stride < (size_t)rows_total * net->dim_emb_pad) return QMANN_EINVAL;
@@ -966,12 +969,13 @@ int qmann_embed_story(const qmann_net *net, const float *story, uint32_t rows_to
     if (rows_total == 0) return QMANN_OK;
     k_embed_story<<<rows_total < (1u << 22) ? rows_total : (1u << 22), kBlock, 0, (hipStream_t)stream>>>(a);
     QM_LAUNCH_CHECK();
-    return QMANN_OK;
+    return qm_scope.rc();
 }
 
 int qmann_embed_query(const qmann_net *net, const float *question, const float *w_q, float *u0, uint32_t n_query,
                       void *stream)
 {
+    QmBatched qm_scope;
     if (!net || !question || !w_q || !u0) return QMANN_EINVAL;
     if (!fmt8(net->w[0])) return QMANN_ERANGE;
     if (n_query == 0) return QMANN_OK;
@@ -979,12 +983,13 @@ int qmann_embed_query(const qmann_net *net, const float *question, const float *
     k_embed_query<<<n_query, kBlock, 0, (hipStream_t)stream>>>(question, w_q, u0, net->dim_emb, net->dim_input,
                                                              QFmt{net->w[0].iwl, net->w[0].frac});
     QM_LAUNCH_CHECK();
-    return QMANN_OK;
+    return qm_scope.rc();
 }
 
 int qmann_quantize_table_i8(const float *w, int8_t *table, uint32_t dim_emb, uint32_t dim_emb_pad, uint32_t dim_input,
                             qmann_fmt fmt, void *stream)
 {
+    QmBatched qm_scope;
     if (!w || !table || dim_emb > dim_emb_pad) return QMANN_EINVAL;
     if (!fmt8(fmt)) return QMANN_ERANGE;
     const uint32_t n = dim_input * dim_emb_pad;
@@ -992,13 +997,14 @@ int qmann_quantize_table_i8(const float *w, int8_t *table, uint32_t dim_emb, uin
     k_quantize_transpose<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(w, table, dim_emb, dim_input, dim_emb_pad,
                                                                          QFmt{fmt.iwl, fmt.frac});
     QM_LAUNCH_CHECK();
-    return QMANN_OK;
+    return qm_scope.rc();
 }
 
 int qmann_embed_story_idx(const qmann_net *net, const uint16_t *words, uint32_t rows_total, uint32_t max_words,
                           int time_last, const int8_t *const *t_a, const int8_t *const *t_c, int8_t *keys, int8_t *vals,
                           size_t hop_stride, void *stream)
 {
+    QmBatched qm_scope;
     if (!net || !words || !t_a || !t_c || !keys || !vals) return QMANN_EINVAL;
     if (net->n_hop == 0 || net->n_hop > QMANN_MAX_HOP || net->dim_emb > net->dim_emb_pad) return QMANN_EINVAL;
     if (max_words == 0 || max_words > (uint32_t)kMaxWords) return QMANN_ERANGE;
@@ -1042,7 +1048,7 @@ int qmann_embed_story_idx(const qmann_net *net, const uint16_t *words, uint32_t 
         if (K == 64) QM_EM_GO(1, 8); else if (K == 128) QM_EM_GO(2, 16); else QM_EM_GO(4, 16);
 #undef QM_EM_GO
         QM_LAUNCH_CHECK();
-        return QMANN_OK;
+        return qm_scope.rc();
     }
     const uint32_t need = (rows_total + kWaves * 4 - 1) / (kWaves * 4);
     // small dictionaries: all tables in LDS as int16; larger ones are gathered from L2 (for dictionaries whose tables
@@ -1060,12 +1066,13 @@ int qmann_embed_story_idx(const qmann_net *net, const uint16_t *words, uint32_t 
         k_embed_story_idx<false><<<need < 2048u ? need : 2048u, kBlock, wave_lds, (hipStream_t)stream>>>(a);
     }
     QM_LAUNCH_CHECK();
-    return QMANN_OK;
+    return qm_scope.rc();
 }
 
 int qmann_embed_query_idx(const qmann_net *net, const uint16_t *words, uint32_t max_words, const int8_t *t_q, float *u0,
                           uint32_t n_query, void *stream)
 {
+    QmBatched qm_scope;
     if (!net || !words || !t_q || !u0) return QMANN_EINVAL;
     if (max_words == 0 || max_words > (uint32_t)kMaxWords) return QMANN_ERANGE;
     if (!fmt8(net->w[0])) return QMANN_ERANGE;
@@ -1084,7 +1091,7 @@ int qmann_embed_query_idx(const qmann_net *net, const uint16_t *words, uint32_t 
         k_embed_query_idx<false><<<blocks, kBlock, 0, (hipStream_t)stream>>>(
             words, t_q, u0, n_query, max_words, net->dim_emb, net->dim_emb_pad, net->dim_input, fw, pe_dw);
     QM_LAUNCH_CHECK();
-    return QMANN_OK;
+    return qm_scope.rc();
 }
 
 }  // extern "C"

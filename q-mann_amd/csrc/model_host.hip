@@ -97,6 +97,7 @@ extern "C" {
 
 int qmann_model_create(qmann_model **out, const qmann_net *net, const qmann_weights *w, void *stream)
 {
+    QmBatched qm_scope;
     if (!out || !net || !w) return QMANN_EINVAL;
     *out = nullptr;
     if (net->n_hop == 0 || net->n_hop > QMANN_MAX_HOP || net->dim_emb == 0 || net->dim_emb > net->dim_emb_pad) return QMANN_EINVAL;
@@ -140,6 +141,7 @@ int qmann_model_create(qmann_model **out, const qmann_net *net, const qmann_weig
     }
     QM_HIP(hipStreamSynchronize(st));        // the host arrays and the staged floats are free again
     for (float *p : staged) QM_HIP(hipFree(p));
+    if (rc == QMANN_OK) rc = qm_scope.rc();
     if (rc != QMANN_OK) { qmann_model_destroy(m); return rc; }
     *out = m;
     return QMANN_OK;
@@ -160,6 +162,7 @@ int qmann_model_forward_words(qmann_model *m, const uint16_t *story_words, uint3
                               uint32_t max_slots, uint32_t n_query, const uint32_t *answer, uint32_t *pred,
                               float *cost, uint32_t *match, void *stream)
 {
+    QmBatched qm_scope;
     if (!m || !story_words || !question_words || !row_off || !pred) return QMANN_EINVAL;
     if (n_query == 0) return QMANN_OK;
     int rc = ensure(m, rows_total, n_query, use_planes(m, max_slots));
@@ -169,13 +172,15 @@ int qmann_model_forward_words(qmann_model *m, const uint16_t *story_words, uint3
     if (rc) return rc;
     rc = qmann_embed_query_idx(&m->net, question_words, max_q_words, m->t_q, m->u0, n_query, stream);
     if (rc) return rc;
-    return hops_and_answer(m, rows_total, row_off, max_slots, n_query, answer, pred, cost, match, stream);
+    rc = hops_and_answer(m, rows_total, row_off, max_slots, n_query, answer, pred, cost, match, stream);
+    return rc ? rc : qm_scope.rc();
 }
 
 int qmann_model_forward_bow(qmann_model *m, const float *story, uint32_t rows_total, const float *question,
                             const uint32_t *row_off, uint32_t max_slots, uint32_t n_query, const uint32_t *answer,
                             uint32_t *pred, float *cost, uint32_t *match, void *stream)
 {
+    QmBatched qm_scope;
     if (!m || !story || !question || !row_off || !pred) return QMANN_EINVAL;
     if (n_query == 0) return QMANN_OK;
     int rc = ensure(m, rows_total, n_query, use_planes(m, max_slots));
@@ -184,7 +189,8 @@ int qmann_model_forward_bow(qmann_model *m, const float *story, uint32_t rows_to
     if (rc) return rc;
     rc = qmann_embed_query(&m->net, question, m->w_q, m->u0, n_query, stream);
     if (rc) return rc;
-    return hops_and_answer(m, rows_total, row_off, max_slots, n_query, answer, pred, cost, match, stream);
+    rc = hops_and_answer(m, rows_total, row_off, max_slots, n_query, answer, pred, cost, match, stream);
+    return rc ? rc : qm_scope.rc();
 }
 
 const float *qmann_model_last_u(const qmann_model *m) { return m ? m->u : nullptr; }

@@ -6,13 +6,26 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+// The batched entry points (qmann_*: they return QMANN_E* codes) do not end the host process on a HIP failure: inside a
+// QmBatched scope the failure is reported on stderr, remembered, and the entry point returns QMANN_EHIP.  The drop-in
+// cuda_* verbs keep the reference's convention (exit), they have no way to return an error.
+inline thread_local int qm_batched_depth = 0;
+inline thread_local int qm_batched_err = 0;
+struct QmBatched {
+    QmBatched() { if (qm_batched_depth++ == 0) qm_batched_err = 0; }
+    ~QmBatched() { --qm_batched_depth; }
+    QmBatched(const QmBatched &) = delete;
+    int rc(int ok = 0) const { return qm_batched_err ? -5 /* QMANN_EHIP */ : ok; }
+};
+
 #define QM_HIP(call)                                                                  \
     do {                                                                              \
         hipError_t e_ = (call);                                                       \
         if (e_ != hipSuccess) {                                                       \
             fprintf(stderr, "[*E] HIP : %s : %s (%s:%d)\n", __func__,                 \
                     hipGetErrorString(e_), __FILE__, __LINE__);                       \
-            exit((int)e_ ? (int)e_ : 1);                                              \
+            if (qm_batched_depth > 0) qm_batched_err = (int)e_;                       \
+            else exit((int)e_ ? (int)e_ : 1);                                         \
         }                                                                             \
     } while (0)
 

@@ -655,6 +655,19 @@ def test_story_longer_than_max_slots_is_cut_not_a_fault(env, S_true, bound):
 # ---------------------------------------------------------------------------------------------
 # maximum sizes: the largest memory one workgroup's LDS can hold, and the refusal just above it
 # ---------------------------------------------------------------------------------------------
+def test_check_slots_counts_the_stories_a_bound_would_cut(env):
+    """qmann_check_slots: the validation helper for the max_slots bound (a longer story is cut, the call still returns 0)"""
+    torch, abi = env.torch, env.abi
+    n = np.array([3, 70, 64, 65, 0, 1000, 64, 2], np.int64)
+    ro = torch.from_numpy(np.concatenate([[0], np.cumsum(n)]).astype(np.int32)).to(env.dev)
+    over = torch.zeros(1, dtype=torch.int32, device=env.dev)
+    for bound, want in ((64, 3), (69, 2), (1000, 0), (0, 7)):
+        over.zero_()
+        abi.check(abi.lib.qmann_check_slots(C.c_void_p(ro.data_ptr()), len(n), bound, C.c_void_p(over.data_ptr()), None), "qmann_check_slots")
+        torch.cuda.synchronize()
+        assert int(over.item()) == want, (bound, int(over.item()))
+
+
 def test_largest_memory_fixed_point(env, oracle):
     """Score bytes live in LDS: 160 KB - 1 KB - fixed tables leaves room for ~153 000 slots per query."""
     lds_cap = 160 * 1024 - 1024
