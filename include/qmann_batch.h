@@ -155,9 +155,14 @@ int qmann_answer_f32(const qmann_net *net, const float *w_ans, const float *u, c
                      void *stream);
 
 /* The same answer layer when the answer matrix is on an int8 grid: w_ans_i8 [V][Dp] two's-complement
- * codes of Q(w_fmt); the projection runs on the int8 matrix cores (v_mfma_i32_16x16x64_i8) and is
- * bit-identical to the float path on the same grid values (exact integers below 2^24).
- * logits_ws: caller-provided workspace, float [n_query][V]. */
+ * codes of Q(w_fmt); the projection runs on the int8 matrix cores (v_mfma_i32_16x16x64_i8).
+ *   probs == NULL: one pass -- projection, running-maximum softmax statistics and arg-max in the accumulator registers, W
+ *       tiles shared through LDS, no [n_query][V] logits round trip.  Predictions (ties to the highest index) and the match
+ *       count equal the float path exactly (logits are exact integers); the cost -p[answer] agrees within the 1e-5 softmax
+ *       tolerance (normaliser accumulated against the running maximum, hardware exp as the reference's __expf).
+ *   probs != NULL: two kernels -- logits to the workspace, then the float path's softmax on them: probabilities bit-identical
+ *       to qmann_answer_f32 on the same grid values.
+ * logits_ws: caller-provided workspace, float [n_query][V] (the one-pass form keeps its per-slice records there). */
 int qmann_answer_i8(const qmann_net *net, const int8_t *w_ans_i8, qmann_fmt w_fmt, const float *u,
                     float *logits_ws, const uint32_t *answer, uint32_t *pred, float *probs, float *cost,
                     uint32_t *match, uint32_t n_query, void *stream);

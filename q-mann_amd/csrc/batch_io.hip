@@ -3,6 +3,7 @@
 // (projection, softmax, arg-max, test-phase bookkeeping).
 #include "hops_common.h"
 
+#include <limits.h>
 #include <stdlib.h>
 
 namespace {
@@ -275,6 +276,206 @@ k_logits_mfma_i8(const float *__restrict__ u, const int8_t *__restrict__ w, floa
         for (int r = 0; r < 4; r++) {
             const uint32_t qr = m0 + 4 * (lane >> 4) + r;
             if (qr < n_query && col < V) logits[(size_t)qr * V + col] = (float)acc[r] * scale;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The int8 answer layer in one pass, without the [n_query][V] logits round trip: projection on the matrix cores, softmax
+// statistics and arg-max in the accumulator registers.  What makes a one-pass form exact enough:
+//   * logits are integers k times 2^-(frac_u + frac_w), so the arg-max of the rounded probabilities, ties to the highest
+//     index (lib/layer_cuda.cu:1918-1939), is the highest index whose k equals the maximum: two different k cannot round
+//     to the same probability (their ratio is at least e^(2^-14));
+//   * the normaliser sum_v e^(l_v - max) is accumulated against the RUNNING maximum and rescaled when the maximum moves
+//     (relative error ~1e-7, inside the 1e-5 softmax tolerance); it only enters the cost -p[answer], an atomically
+//     accumulated float anyway.  A caller that wants the probabilities themselves takes the two-kernel path.
+// A workgroup of 4 wavefronts owns 64 queries (their code fragments stay in registers) and a slice of the dictionary; the
+// slice's W rows pass through a double-buffered LDS tile shared by the 4 wavefronts (64 rows, pitch Dp + 16).  Slices keep
+// every CU busy at 8 192 queries; a second, tiny kernel merges the per-slice records.
+// ---------------------------------------------------------------------------
+struct AnsPart {            // per (slice, query)
+    int m;                  // maximum logit code of the slice
+    uint32_t idx;           // its highest index
+    double sum;             // sum over the slice of e^((k - m) . scale)
+    int ky;                 // code of the labelled answer's logit, if it lies in the slice
+    uint32_t has_y;
+};
+constexpr uint32_t kAnsTile = 64;                       // dictionary rows per LDS tile
+constexpr int kAnsFloor = -(1 << 28);                   // below every logit code (|sum of 256 products of 7-bit codes| < 2^23); e^(floor . scale) = 0
+
+// e^x for the running normaliser: the hardware exponential (v_exp_f32 of x . log2 e, ~2 ulp) for the e^x base -- the
+// reference's own kernel uses the fast __expf there (lib/layer_cuda.cu:2006) -- and the shared definitions for the others
+__device__ __forceinline__ float ans_exp(float x, const SmCfg &c)
+{
+    return c.base == QMANN_SOFTMAX_EXP ? __expf(x) : sm_exp(x, c);
+}
+
+template <int KSTEPS>
+__global__ void __launch_bounds__(kBlock)
+k_answer_i8_part(const float *__restrict__ u, const int8_t *__restrict__ w, const uint32_t *__restrict__ answer, AnsPart *__restrict__ part,
+                 uint32_t n_query, uint32_t D, uint32_t V, QFmt fu, float scale, uint32_t softmax_base, uint32_t tiles_per_slice)
+{
+    constexpr uint32_t Dp = KSTEPS * 64, PITCH = Dp + 16;
+    __shared__ __attribute__((aligned(16))) uint8_t tile[2][kAnsTile * PITCH];
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const uint32_t m0 = (blockIdx.x * kWaves + wave) * 16;
+    const uint32_t row = lane & 15, kq = lane >> 4;
+    const SmCfg smc{softmax_base, false, false, 1.0f};
+    // A fragments: this lane's query row, converted once
+    i32x4 a[KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ks++) {
+        const uint32_t kb = ks * 64 + 16 * kq;
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            uint32_t pk = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t c = kb + 4 * d + i;
+                const int code = (m0 + row < n_query && c < D) ? qm_code(u[(size_t)(m0 + row) * D + c], fu.iwl, fu.frac) : 0;
+                pk |= ((uint32_t)code & 0xFFu) << (8 * i);
+            }
+            a[ks][d] = (int)pk;
+        }
+    }
+    // accumulator layout: lane l holds answer column l & 15 of the 16-answer block and query rows 4 (l >> 4) + r
+    uint32_t yq[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const uint32_t q = m0 + 4 * kq + r;
+        yq[r] = (answer && q < n_query) ? answer[q] : 0xFFFFFFFFu;
+    }
+    int mx[4] = {kAnsFloor, kAnsFloor, kAnsFloor, kAnsFloor}, ky[4] = {0, 0, 0, 0};     // (no logit is that low: the first one becomes the maximum)
+    uint32_t bi[4] = {0, 0, 0, 0}, hy[4] = {0, 0, 0, 0};
+    double sm[4] = {0.0, 0.0, 0.0, 0.0};
+
+    const uint32_t n_tiles = (V + kAnsTile - 1) / kAnsTile;
+    const uint32_t t_lo = blockIdx.y * tiles_per_slice, t_hi = (t_lo + tiles_per_slice < n_tiles) ? t_lo + tiles_per_slice : n_tiles;
+    constexpr uint32_t PIECES = kAnsTile * Dp / 16 / kBlock;             // 16-byte pieces of a tile per thread: 1, 2 or 4
+    i32x4 stage_r[PIECES];
+    auto fetch = [&](uint32_t t) {
+#pragma unroll
+        for (uint32_t p = 0; p < PIECES; p++) {
+            const uint32_t i = p * kBlock + tid, r = i / (Dp / 16), c = i % (Dp / 16);
+            const uint32_t v = t * kAnsTile + r;
+            stage_r[p] = i32x4{0, 0, 0, 0};
+            if (v < V) stage_r[p] = *(const i32x4 *)(w + (size_t)v * Dp + c * 16);
+        }
+    };
+    auto put = [&](uint32_t b) {
+#pragma unroll
+        for (uint32_t p = 0; p < PIECES; p++) {
+            const uint32_t i = p * kBlock + tid, r = i / (Dp / 16), c = i % (Dp / 16);
+            *(i32x4 *)(tile[b] + r * PITCH + c * 16) = stage_r[p];
+        }
+    };
+    if (t_lo < t_hi) { fetch(t_lo); put(0); }
+    __syncthreads();
+    for (uint32_t t = t_lo; t < t_hi; t++) {
+        const uint32_t b = (t - t_lo) & 1u;
+        if (t + 1 < t_hi) fetch(t + 1);
+#pragma unroll
+        for (uint32_t nb = 0; nb < kAnsTile / 16; nb++) {
+            i32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < KSTEPS; ks++) {
+                const i32x4 bm = *(const i32x4 *)(tile[b] + (nb * 16 + row) * PITCH + ks * 64 + kq * 16);
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks], bm, acc, 0, 0, 0);
+            }
+            const uint32_t v = t * kAnsTile + nb * 16 + row;
+            const bool v_ok = v < V;
+            // Branch-free per element: ONE exp of -|k - max| serves both cases (new maximum: rescale the sum and add 1; else
+            // add the term).  A block whose every logit lies more than 40 below its row's running maximum changes nothing
+            // but the label bookkeeping (terms under 1e-17 of the sum) and is skipped as a whole -- the usual case once the
+            // maxima have settled.
+            bool near = false;
+#pragma unroll
+            for (int r = 0; r < 4; r++) near |= v_ok && (float)(acc[r] - mx[r]) * scale > -40.0f;
+            if (__any(near)) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int k = v_ok ? acc[r] : kAnsFloor;
+                    const bool gt = k > mx[r];
+                    const int dk = gt ? mx[r] - k : k - mx[r];                       // -|k - max| (no overflow: |codes| < 2^23)
+                    const double e = (double)ans_exp((float)dk * scale, smc);
+                    sm[r] = gt ? sm[r] * e + 1.0 : (v_ok ? sm[r] + e : sm[r]);
+                    bi[r] = (v_ok && k >= mx[r]) ? v : bi[r];                      // columns arrive in ascending order: the later index wins a tie
+                    mx[r] = gt ? k : mx[r];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (v == yq[r]) { ky[r] = acc[r]; hy[r] = 1u; }
+        }
+        if (t + 1 < t_hi) put(b ^ 1u);
+        __syncthreads();
+    }
+    // the 16 lanes that hold the same query rows (equal l >> 4) merge their columns
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int m2 = __shfl_xor(mx[r], o);
+            const uint32_t i2 = __shfl_xor(bi[r], o), h2 = __shfl_xor(hy[r], o);
+            const int k2 = __shfl_xor(ky[r], o);
+            const double s2 = __shfl_xor(sm[r], o);
+            const int M = m2 > mx[r] ? m2 : mx[r];
+            const double f1 = mx[r] == M ? 1.0 : (double)ans_exp((float)(mx[r] - M) * scale, smc);
+            const double f2 = m2 == M ? 1.0 : (double)ans_exp((float)(m2 - M) * scale, smc);
+            sm[r] = sm[r] * f1 + s2 * f2;
+            bi[r] = (m2 == mx[r]) ? (i2 > bi[r] ? i2 : bi[r]) : (m2 > mx[r] ? i2 : bi[r]);
+            mx[r] = M;
+            if (h2) { ky[r] = k2; hy[r] = 1u; }
+        }
+    }
+    if (row == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t q = m0 + 4 * kq + r;
+            if (q < n_query) part[(size_t)blockIdx.y * n_query + q] = AnsPart{mx[r], bi[r], sm[r], ky[r], hy[r]};
+        }
+    }
+}
+
+// merges the slices of a query (ascending dictionary ranges: the later slice wins a tie), writes the prediction and
+// accumulates cost / match (cross_entropy_run mode 3)
+__global__ void __launch_bounds__(kBlock)
+k_answer_i8_combine(const AnsPart *__restrict__ part, const uint32_t *__restrict__ answer, uint32_t *__restrict__ pred, float *cost,
+                    uint32_t *match, uint32_t n_query, uint32_t n_slice, uint32_t V, float scale, uint32_t softmax_base)
+{
+    const SmCfg smc{softmax_base, false, false, 1.0f};
+    float cost_acc = 0.0f;
+    uint32_t match_acc = 0;
+    for (size_t q = (size_t)blockIdx.x * kBlock + threadIdx.x; q < n_query; q += (size_t)gridDim.x * kBlock) {
+        int M = kAnsFloor, ky = 0;
+        uint32_t bi = 0, hy = 0;
+        for (uint32_t s = 0; s < n_slice; s++) {
+            const AnsPart p = part[(size_t)s * n_query + q];
+            if (p.m >= M && p.m != kAnsFloor) { M = p.m; bi = p.idx; }
+            if (p.has_y) { ky = p.ky; hy = 1u; }
+        }
+        double total = 0.0;
+        for (uint32_t s = 0; s < n_slice; s++) {
+            const AnsPart p = part[(size_t)s * n_query + q];
+            total += p.sum * (p.m == M ? 1.0 : (double)sm_exp((float)(p.m - M) * scale, smc));
+        }
+        pred[q] = bi;
+        if (answer) {
+            const uint32_t y = answer[q];
+            if (y < V && hy) {
+                const float e = sm_exp((float)(ky - M) * scale, smc);
+                const float py = (softmax_base == QMANN_SOFTMAX_EXP) ? (float)((double)e / total) : e / (float)total;
+                cost_acc += -py;
+                match_acc += (y == bi) ? 1u : 0u;
+            }
+        }
+    }
+    if (answer) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { cost_acc += __shfl_xor(cost_acc, o); match_acc += __shfl_xor(match_acc, o); }
+        if ((threadIdx.x & 63u) == 0) {
+            if (cost) atomicAdd(cost, cost_acc);
+            if (match && match_acc) atomicAdd(match, match_acc);
         }
     }
 }
@@ -933,9 +1134,28 @@ int qmann_answer_i8(const qmann_net *net, const int8_t *w_ans_i8, qmann_fmt w_fm
     if (n_query == 0) return QMANN_OK;
     if (n_query >= (1u << 24)) return QMANN_ERANGE;      // one workgroup per query: a launch holds < 2^32 threads
     const float scale = 1.0f / (float)(1u << (fu.frac + w_fmt.frac));
-    const dim3 grid((n_query + 16 * kWaves - 1) / (16 * kWaves), (V + 16 * kTilesPerBlockY - 1) / (16 * kTilesPerBlockY));
     hipStream_t st = (hipStream_t)stream;
     const QFmt fuq{fu.iwl, fu.frac};
+    if (!probs && !getenv("QMANN_ANSWER_TWO_PASS")) {
+        // one pass: no logits round trip; the workspace holds the per-slice records
+        const uint32_t qblocks = (n_query + 16 * kWaves - 1) / (16 * kWaves), n_tiles = (V + kAnsTile - 1) / kAnsTile;
+        uint32_t n_slice = qblocks >= 512u ? 1u : (512u + qblocks - 1) / qblocks;              // ~2 workgroups per CU
+        if (n_slice > n_tiles) n_slice = n_tiles;
+        while (n_slice > 1 && (size_t)n_slice * sizeof(AnsPart) > (size_t)V * sizeof(float)) n_slice--;   // records must fit logits_ws
+        const uint32_t tps = (n_tiles + n_slice - 1) / n_slice;
+        n_slice = (n_tiles + tps - 1) / tps;
+        AnsPart *part = (AnsPart *)logits_ws;
+        const dim3 grid1(qblocks, n_slice);
+        if (Dp == 64) k_answer_i8_part<1><<<grid1, kBlock, 0, st>>>(u, w_ans_i8, answer, part, n_query, D, V, fuq, scale, net->softmax_base, tps);
+        else if (Dp == 128) k_answer_i8_part<2><<<grid1, kBlock, 0, st>>>(u, w_ans_i8, answer, part, n_query, D, V, fuq, scale, net->softmax_base, tps);
+        else if (Dp == 256) k_answer_i8_part<4><<<grid1, kBlock, 0, st>>>(u, w_ans_i8, answer, part, n_query, D, V, fuq, scale, net->softmax_base, tps);
+        else return QMANN_EUNSUPPORTED;
+        const uint32_t cb = (n_query + kBlock - 1) / kBlock;
+        k_answer_i8_combine<<<cb < 1024u ? cb : 1024u, kBlock, 0, st>>>(part, answer, pred, cost, match, n_query, n_slice, V, scale, net->softmax_base);
+        QM_LAUNCH_CHECK();
+        return qm_scope.rc();
+    }
+    const dim3 grid((n_query + 16 * kWaves - 1) / (16 * kWaves), (V + 16 * kTilesPerBlockY - 1) / (16 * kTilesPerBlockY));
     if (Dp == 64) k_logits_mfma_i8<1><<<grid, kBlock, 0, st>>>(u, w_ans_i8, logits_ws, n_query, D, V, fuq, scale);
     else if (Dp == 128) k_logits_mfma_i8<2><<<grid, kBlock, 0, st>>>(u, w_ans_i8, logits_ws, n_query, D, V, fuq, scale);
     else if (Dp == 256) k_logits_mfma_i8<4><<<grid, kBlock, 0, st>>>(u, w_ans_i8, logits_ws, n_query, D, V, fuq, scale);

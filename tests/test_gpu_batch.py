@@ -373,6 +373,42 @@ def test_answer_mfma_i8_bit_identical_to_float_path(env, oracle, D, V, B):
         np.testing.assert_array_equal(logits[q].cpu().numpy(), lo)
 
 
+@pytest.mark.parametrize("base", [0, 1])
+@pytest.mark.parametrize("D,V,B,sig", [(60, 30, 5, 40), (128, 256, 37, 40), (256, 256, 64, 3), (128, 1000, 33, 40), (256, 4096, 300, 12),
+                                       (60, 4097, 2000, 1), (256, 65, 8192, 40)])
+def test_answer_mfma_i8_one_pass(env, D, V, B, sig, base):
+    """Without a probabilities output the int8 answer layer runs in one pass (no logits round trip, running-maximum
+    normaliser, dictionary slices merged by a second kernel): predictions -- ties to the highest index included -- and the
+    match count equal the float path exactly, the cost within the softmax tolerance.  Small sigma: many exact logit ties."""
+    torch, model, abi = env.torch, env.model, env.abi
+    rng = np.random.default_rng(D + V + B + base)
+    cfg = cfg_synth(D, V, 5, base=base)
+    w_fmt = (1, 6)
+    w_codes = np.clip(np.rint(rng.normal(0, sig, (V, D))), -127, 127).astype(np.int32)
+    w_codes[V // 3] = w_codes[V // 2]                                 # two identical answers: a tie wherever they win
+    w_float = (w_codes / 64.0).astype(np.float32)
+    u = (np.clip(np.rint(rng.normal(0, sig, (B, D))), -127, 127) / 4.0).astype(np.float32)
+    u[::7] = 0.0                                                      # all logits equal: the last index wins
+    wts = weights(1, 3, D, V, 1.0, with_emb=False)
+    wts["w_ans"] = w_float
+    net = model.QNet(cfg, wts)
+    du = torch.from_numpy(u).to(env.dev)
+    w_i8 = net.quantize_i8(torch.from_numpy(w_float).to(env.dev), w_fmt, abi.CODE_TWOS)
+    ans_np = rng.integers(0, V, B)
+    ans_np[::5] = V - 1
+    ans = torch.from_numpy(ans_np.astype(np.int32)).to(env.dev)
+    pred_1, _, cost_1, match_1, _ = net.answer_i8(du, w_i8, w_fmt, answer=ans)                # one pass
+    pred_f, _, cost_f, match_f = net.answer(du, answer=ans)
+    pred_n = net.answer_i8(du, w_i8, w_fmt)[0]                                               # no labels
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(pred_1.cpu().numpy(), pred_f.cpu().numpy())
+    np.testing.assert_array_equal(pred_n.cpu().numpy(), pred_f.cpu().numpy())
+    assert int(match_1.cpu()) == int(match_f.cpu())
+    # (both costs are float sums over the batch in different orders: ~1 ulp of the running total per atomic add)
+    assert float(cost_1.cpu()) == pytest.approx(float(cost_f.cpu()), rel=1e-4, abs=1e-6)
+    assert (pred_f.cpu().numpy()[::7] == V - 1).all()
+
+
 # ---------------------------------------------------------------------------------------------
 # ATTENTION_MODE 1: float attention over quantized embeddings
 # ---------------------------------------------------------------------------------------------
