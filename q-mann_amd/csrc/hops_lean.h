@@ -17,6 +17,7 @@
 #pragma once
 #include "hops_small.h"
 
+#include <limits.h>
 #include <stdlib.h>
 
 namespace {
@@ -36,11 +37,55 @@ constexpr uint32_t kLwSc = 256;         // i16 [64]  scores, slot r
 constexpr uint32_t kLwOc = 384;         // i16 [64]  read-out codes o[c]
 constexpr uint32_t kLwBytes = 512;
 
+constexpr uint32_t kLmHopBytes = 64u * 192u;       // a hop's linear map in LDS: 64 rows x {even magnitudes, odd magnitudes, signs}
+
 struct LeanArgs {
     uint32_t rows_pad;        // value-tile rows per wavefront (max_slots rounded up to 16)
     uint32_t exp_table;       // 1: fixed-point scores, e^x base, no scale layer: exp(-d . unit) comes from a table
     uint32_t lm_in_lds;       // 1: the linear maps are staged in LDS
 };
+
+// Wavefront reductions on the DPP network (row shifts, then the two row broadcasts; the total lands in lane 63 and is
+// handed to every lane through an SGPR).  A shuffle-based butterfly costs no vector instructions either, but each of its
+// 6 steps is a dependent LDS-crossbar round trip (~120 cycles): 18 of them per hop were a fifth of a wavefront's time.
+template <typename Op>
+__device__ __forceinline__ int dpp_reduce_i32(int v, int identity, Op op)
+{
+    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x111, 0xF, 0xF, false));      // row_shr:1
+    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x112, 0xF, 0xF, false));      // row_shr:2
+    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x114, 0xF, 0xF, false));      // row_shr:4
+    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x118, 0xF, 0xF, false));      // row_shr:8
+    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x142, 0xA, 0xF, false));      // row_bcast:15 -> rows 1, 3
+    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x143, 0xC, 0xF, false));      // row_bcast:31 -> rows 2, 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+    return dpp_reduce_i32(v, INT_MIN, [](int a, int b) { return a > b ? a : b; });
+}
+__device__ __forceinline__ float wave_max_f32(float v)
+{
+    float r = v;                                        // identity for lanes the shift does not reach: -inf
+#define QM_DPP_MAXF(CTRL, RM) r = fmaxf(r, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp((int)0xFF800000, __builtin_bit_cast(int, r), CTRL, RM, 0xF, false)))
+    QM_DPP_MAXF(0x111, 0xF); QM_DPP_MAXF(0x112, 0xF); QM_DPP_MAXF(0x114, 0xF); QM_DPP_MAXF(0x118, 0xF); QM_DPP_MAXF(0x142, 0xA); QM_DPP_MAXF(0x143, 0xC);
+#undef QM_DPP_MAXF
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r), 63));
+}
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+#define QM_DPP_ADDD(CTRL, RM)                                                                                          \
+    do {                                                                                                               \
+        const uint64_t b_ = __builtin_bit_cast(uint64_t, v);                                                           \
+        const uint32_t lo_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b_, CTRL, RM, 0xF, false);        \
+        const uint32_t hi_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b_ >> 32), CTRL, RM, 0xF, false); \
+        v += __builtin_bit_cast(double, (uint64_t)lo_ | ((uint64_t)hi_ << 32));                                        \
+    } while (0)
+    QM_DPP_ADDD(0x111, 0xF); QM_DPP_ADDD(0x112, 0xF); QM_DPP_ADDD(0x114, 0xF); QM_DPP_ADDD(0x118, 0xF); QM_DPP_ADDD(0x142, 0xA); QM_DPP_ADDD(0x143, 0xC);
+#undef QM_DPP_ADDD
+    const uint64_t b = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, 63), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), 63);
+    return __builtin_bit_cast(double, (uint64_t)lo | ((uint64_t)hi << 32));
+}
 
 __device__ __forceinline__ void wave_sync()
 {
@@ -107,6 +152,26 @@ __device__ __forceinline__ int lane_sum_w(const i32x4 x, const ScanConst &c, uin
 {
     return W7 ? lane_row_sum7(x, c) : lane_row_sum(x, c, sh);
 }
+// the same on a row that is already split into even / odd magnitudes and sign bits (the linear maps in LDS)
+template <bool W7>
+__device__ __forceinline__ int lane_sum_split(const i32x4 ev, const i32x4 od, const i32x4 sn, const ScanConst &c, uint32_t sh)
+{
+    int acc = 0;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        uint32_t tb;
+        if (W7) {
+            tb = __builtin_amdgcn_perm(pk_mul_sat_i16((uint32_t)od[d], c.uo[d]), pk_mul_sat_i16((uint32_t)ev[d], c.ue[d]), 0x07030501u);
+        } else {
+            const u16x2 te = __builtin_bit_cast(u16x2, pk_mul_sat_u16((uint32_t)ev[d], c.ue[d])) >> (unsigned short)sh;
+            const u16x2 to = __builtin_bit_cast(u16x2, pk_mul_sat_u16((uint32_t)od[d], c.uo[d])) >> (unsigned short)sh;
+            tb = __builtin_bit_cast(uint32_t, te) | (__builtin_bit_cast(uint32_t, to) << 8);
+        }
+        const uint32_t sg = __builtin_amdgcn_perm(0x01010101u, 0x01010101u, (uint32_t)sn[d] ^ c.s7[d]);
+        acc = __builtin_amdgcn_sdot4((int)tb, (int)sg, acc, false);
+    }
+    return acc;
+}
 
 // exp tables [n_hop][256] and linear maps [n_hop][64][64] of a (persistent) workgroup; ends WITHOUT a barrier
 __device__ __forceinline__ void lean_stage_tables(const HopArgs &a, const LeanArgs &la, float *etab, uint8_t *lmap, uint32_t tid,
@@ -121,12 +186,18 @@ __device__ __forceinline__ void lean_stage_tables(const HopArgs &a, const LeanAr
         }
     }
     if (la.lm_in_lds) {
+        // The linear maps are constant, so the part of the packed multiply that touches only the matrix bytes is done here,
+        // once per workgroup: a row is kept as three 64-byte images -- |H| of the even columns and of the odd columns as
+        // 16-bit lanes (the multiplier's operands) and the sign bits -- 6 instead of 9 operations per 4 columns in the hop.
         for (uint32_t h = 0; h < H; h++) {
-            const i32x4 *src = (const i32x4 *)a.lin_map[h];
-            for (uint32_t i = tid; i < 256u; i += nthreads) {
-                i32x4 x = {0, 0, 0, 0};
-                if (i * 16u < a.D * 64u) x = src[i];
-                *(i32x4 *)(lmap + h * 4096u + i * 16u) = x;
+            const uint32_t *src = (const uint32_t *)a.lin_map[h];
+            for (uint32_t i = tid; i < 64u * 16u; i += nthreads) {           // dword i & 15 of row i >> 4
+                const uint32_t r = i >> 4, d = i & 15u;
+                const uint32_t w = r < a.D ? src[i] : 0u;
+                uint32_t *dst = (uint32_t *)(lmap + h * kLmHopBytes + r * 192u);
+                dst[d] = w & 0x007F007Fu;
+                dst[16 + d] = (w >> 8) & 0x007F007Fu;
+                dst[32 + d] = w & 0x80808080u;
             }
         }
     }
@@ -198,20 +269,14 @@ __device__ __forceinline__ void lean_hop(const HopArgs &a, const LeanArgs &la, u
     float e;
     double total;
     if (MODE == kModeFixed && la.exp_table) {
-        int mxc = live ? code : -32768;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(mxc, o); mxc = t > mxc ? t : mxc; }
+        const int mxc = wave_max_i32(live ? code : -32768);
         e = live ? etab[h * 256u + (uint32_t)(mxc - code)] : 0.0f;
     } else {
         const float xs = live ? sm_scaled((float)code * unit, smc) : -INFINITY;
-        float mx = xs;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        const float mx = wave_max_f32(xs);
         e = live ? sm_exp(xs - mx, smc) : 0.0f;
     }
-    total = (double)e;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+    total = wave_sum_f64((double)e);
     const float p = live ? sm_quot(e, total, smc) : 0.0f;
     // Q(p) for 0 <= p <= 1: trunc(p . 2^frac), saturated (qm_code without the cases a probability cannot reach)
     int kp = (int)__builtin_ldexpf(p, (int)fa.frac);
@@ -220,13 +285,22 @@ __device__ __forceinline__ void lean_hop(const HopArgs &a, const LeanArgs &la, u
     // ---- read-out over the rows whose weight code is non-zero (lane c owns column c) -----------------
     before_readout();
     int acc = 0;
-    for (uint64_t m = __ballot(kp != 0); m; m &= m - 1) {
-        const int r = __builtin_ctzll(m);
-        const int kpr = __builtin_amdgcn_readlane(kp, r);
-        const uint32_t b = vt[(uint32_t)r * Dp + lane];
-        uint32_t t = ((uint32_t)kpr * (b & 0x7Fu)) >> fa.frac;   // |Q(p) . v| / 2^frac toward zero
-        t = t > (uint32_t)maxa ? (uint32_t)maxa : t;
-        acc += (b & 0x80u) ? -(int)t : (int)t;
+    for (uint64_t m = __ballot(kp != 0); m;) {                    // up to four surviving rows per round, their bytes requested together
+        int rr[4], kk[4];
+        uint32_t bb[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            rr[i] = m ? __builtin_ctzll(m) : -1;                  // (wavefront-uniform)
+            m &= m - 1;                                           // (0 stays 0)
+            kk[i] = rr[i] >= 0 ? __builtin_amdgcn_readlane(kp, rr[i] >= 0 ? rr[i] : 0) : 0;
+            bb[i] = rr[i] >= 0 ? vt[(uint32_t)rr[i] * Dp + lane] : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint32_t t = ((uint32_t)kk[i] * (bb[i] & 0x7Fu)) >> fa.frac;   // |Q(p) . v| / 2^frac toward zero
+            t = t > (uint32_t)maxa ? (uint32_t)maxa : t;
+            acc += (bb[i] & 0x80u) ? -(int)t : (int)t;
+        }
     }
     acc = acc > maxa ? maxa : (acc < -maxa ? -maxa : acc);
     *(int16_t *)(lw + kLwOc + lane * 2) = (int16_t)acc;
@@ -246,8 +320,8 @@ __device__ __forceinline__ void lean_hop(const HopArgs &a, const LeanArgs &la, u
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             if ((uint32_t)t < n_it) {                             // wavefront-uniform
-                const i32x4 x = *(const i32x4 *)(lmap + h * 4096u + (t * 16 + sub) * 64u + chunk * 16u);
-                const int s = row_lanes_sum<LPR>(lane_sum_w<W7>(x, csc, csh));
+                const uint8_t *hr = lmap + h * kLmHopBytes + (t * 16 + sub) * 192u + chunk * 16u;
+                const int s = row_lanes_sum<LPR>(lane_sum_split<W7>(*(const i32x4 *)hr, *(const i32x4 *)(hr + 64), *(const i32x4 *)(hr + 128), csc, csh));
                 if (chunk == (uint32_t)t) keep = s;
             }
         }
@@ -281,8 +355,8 @@ k_hops_lean(const HopArgs a, const LeanArgs la)
     const uint32_t sub = lane >> 2, chunk = lane & 3u;
     const uint32_t D = a.D, H = a.n_hop;
     float *etab = (float *)smem;                                        // [H][256]
-    uint8_t *lmap = smem + (la.exp_table ? H * 1024u : 0u);             // [H][64][64]
-    uint8_t *wbase = lmap + (la.lm_in_lds ? H * 4096u : 0u);
+    uint8_t *lmap = smem + (la.exp_table ? H * 1024u : 0u);             // [H][64][3][64] (lean_stage_tables)
+    uint8_t *wbase = lmap + (la.lm_in_lds ? H * kLmHopBytes : 0u);
     const uint32_t wslice = la.rows_pad * 64u + kLwBytes;
     uint8_t *vt = wbase + wave * wslice;                                // value tile
     uint8_t *lw = vt + la.rows_pad * 64u;                               // small arrays
@@ -365,7 +439,7 @@ inline void launch_lean_w(HopArgs a, uint32_t max_slots, uint32_t n_query, hipSt
     la.exp_table = (MODE == kModeFixed && a.softmax_base == QMANN_SOFTMAX_EXP && !a.softmax_shift && !a.en_att_scale) ? 1u : 0u;
     la.lm_in_lds = a.en_lin_map ? 1u : 0u;
     a.rows_total = n_query;                                               // (the kernel has no taps: the field carries the query count)
-    const size_t lds = (la.exp_table ? a.n_hop * 1024u : 0u) + (la.lm_in_lds ? a.n_hop * 4096u : 0u) +
+    const size_t lds = (la.exp_table ? a.n_hop * 1024u : 0u) + (la.lm_in_lds ? a.n_hop * kLmHopBytes : 0u) +
                        (size_t)kLeanWaves * (la.rows_pad * 64u + kLwBytes);
     if (lds > kLdsDefaultLimit)
         QM_HIP(hipFuncSetAttribute((const void *)k_hops_lean<MODE, NB, W7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
