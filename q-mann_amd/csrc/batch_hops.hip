@@ -31,7 +31,9 @@
 
 namespace {
 
-template <int LPR, int kUnroll, bool NT, int MINW>
+// W7: every attention format of the launch has word length 7 -- the clamp comes from the signed saturation of the
+// multiply and the quotient is a byte gather (hops_common.h::lane_row_sum7): 9 instead of 11 operations per 4 key bytes
+template <int LPR, int kUnroll, bool NT, int MINW, bool W7>
 __global__ void __launch_bounds__(kBlock, MINW)
 k_hops_fixed(const HopArgs a)
 {
@@ -76,11 +78,12 @@ k_hops_fixed(const HopArgs a)
         if (S > 0) {
             // lane constants: |u| pre-shifted so that saturation == the per-product clamp
             ScanConst c;
-            const uint32_t sh = make_scan_const(c, ku, (lane % LPR) * 16, fm.iwl + fm.frac, fv, hop_relu(a, h),
-                                                fb.iwl + fb.frac == 0);
+            uint32_t sh = 0;
+            if (W7) make_scan_const7(c, ku, (lane % LPR) * 16, fv, hop_relu(a, h), fb.iwl + fb.frac == 0);
+            else sh = make_scan_const(c, ku, (lane % LPR) * 16, fm.iwl + fm.frac, fv, hop_relu(a, h), fb.iwl + fb.frac == 0);
             const uint8_t *kb = (const uint8_t *)a.keys + (size_t)h * a.hop_stride + (size_t)r0 * Dp;
             uint32_t *hw = hist + wave * 256;
-            auto row_sum = [&](const i32x4 x) { return lane_row_sum(x, c, sh); };
+            auto row_sum = [&](const i32x4 x) { return W7 ? lane_row_sum7(x, c) : lane_row_sum(x, c, sh); };
             auto retire = [&](uint32_t r, int v) {          // Qm of the row sum (lib/layer_cuda.cu:135)
                 const int code = v > maxm ? maxm : (v < -maxm ? -maxm : v);
                 sc[r] = (int8_t)code;
@@ -291,18 +294,23 @@ int qmann_hops_i8(const qmann_net *net, const int8_t *keys, const int8_t *vals, 
     // memories of 65..256 slots run one wavefront per query with the histogram softmax: four times
     // as many queries resident per CU and no cross-wavefront barriers
     const dim3 grid(n_query), block(max_slots <= 256 ? kWave : kBlock);
-#define QM_LAUNCH_HOPS(LPR, UN, NT, MINW)                                                               \
+#define QM_LAUNCH_HOPS_W(LPR, UN, NT, MINW, W7)                                                         \
     do {                                                                                                \
         if (lds > kLdsDefaultLimit)         /* beyond the default 64 KB: raise the limit (no cached state:  */ \
-            QM_HIP(hipFuncSetAttribute((const void *)k_hops_fixed<LPR, UN, NT, MINW>,   /* thread- and    */ \
+            QM_HIP(hipFuncSetAttribute((const void *)k_hops_fixed<LPR, UN, NT, MINW, W7>, /* thread- and  */ \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); /* device-safe */ \
-        k_hops_fixed<LPR, UN, NT, MINW><<<grid, block, lds, st>>>(a);                                   \
+        k_hops_fixed<LPR, UN, NT, MINW, W7><<<grid, block, lds, st>>>(a);                               \
     } while (0)
+#define QM_LAUNCH_HOPS(LPR, UN, NT, MINW)                                                               \
+    do { if (w7) QM_LAUNCH_HOPS_W(LPR, UN, NT, MINW, true); else QM_LAUNCH_HOPS_W(LPR, UN, NT, MINW, false); } while (0)
+    bool w7 = getenv("QMANN_NO_W7") == nullptr;
+    for (uint32_t h = 0; h < net->n_hop; h++) w7 = w7 && net->att[h].iwl + net->att[h].frac == 7;
     // (bounding the kernel to 96 VGPRs for a fifth wavefront per SIMD measured 1-3 % slower: MINW stays 1)
     if (net->dim_emb_pad == 64) QM_LAUNCH_HOPS(4, kUnrollDefault, true, 1);
     else if (net->dim_emb_pad == 256) QM_LAUNCH_HOPS(16, kUnrollDefault, true, 1);
     else QM_LAUNCH_HOPS(8, kUnrollDefault, true, 1);
 #undef QM_LAUNCH_HOPS
+#undef QM_LAUNCH_HOPS_W
     QM_LAUNCH_CHECK();
     return qm_scope.rc();
 }

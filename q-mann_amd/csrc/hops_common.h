@@ -150,6 +150,50 @@ __device__ __forceinline__ uint32_t make_scan_const(ScanConst &c, const short *k
     return sh;
 }
 
+// Word length 7 (every 8-bit configuration): the per-product clamp at 127 is the SIGNED 16-bit saturation of
+// |k| . (|u| << (8 - frac_v)) (32767 >> 8 = 127), and the quotient is then the product's high byte: no shift, and
+// one v_perm_b32 gathers the four high bytes.  9 VALU operations per 4 key bytes instead of 11.
+__device__ __forceinline__ uint32_t pk_mul_sat_i16(uint32_t a, uint32_t b)
+{
+    uint32_t d;
+    asm("v_pk_mad_i16 %0, %1, %2, 0 clamp" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ int lane_row_sum7(const i32x4 x, const ScanConst &c)
+{
+    int acc = 0;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const uint32_t w = (uint32_t)x[d];
+        const uint32_t pe = pk_mul_sat_i16(w & 0x007F007Fu, c.ue[d]);           // bytes 0 and 2
+        const uint32_t po = pk_mul_sat_i16((w >> 8) & 0x007F007Fu, c.uo[d]);    // bytes 1 and 3
+        const uint32_t tb = __builtin_amdgcn_perm(po, pe, 0x07030501u);         // the four high bytes, in column order
+        const uint32_t sb = (w ^ c.s7[d]) & 0x80808080u;
+        const uint32_t sg = __builtin_amdgcn_perm(0x01010101u, 0x01010101u, sb);
+        acc = __builtin_amdgcn_sdot4((int)tb, (int)sg, acc, false);
+    }
+    return acc;
+}
+// make_scan_const for that form: |u| << (8 - fv), saturated at 0x7FFF
+__device__ __forceinline__ void make_scan_const7(ScanConst &c, const short *ku, uint32_t c0, int fv, bool relu = false, bool sign_fmt = false)
+{
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        uint32_t m[4], sg = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int k = ku[c0 + 4 * d + i];
+            if (relu && k < 0) k = sign_fmt ? 1 : 0;
+            const uint32_t a = (uint32_t)(k < 0 ? -k : k) << (8 - fv);
+            m[i] = a > 0x7FFFu ? 0x7FFFu : a;
+            sg |= (k < 0 ? 0x80u : 0u) << (8 * i);
+        }
+        c.ue[d] = m[0] | (m[2] << 16);
+        c.uo[d] = m[1] | (m[3] << 16);
+        c.s7[d] = sg;
+    }
+}
+
 template <bool NT>
 __device__ __forceinline__ i32x4 load16(const uint8_t *p)
 {

@@ -114,30 +114,6 @@ __device__ __forceinline__ uint32_t fetch_scan_const(ScanConst &c, const uint8_t
     return 16u - wl;
 }
 
-// Word length 7 (every 8-bit configuration): the per-product clamp at 127 is the SIGNED 16-bit saturation of
-// |k| . (|u| << (8 - frac_v)) (32767 >> 8 = 127), and the quotient is then the product's high byte: no shift, and
-// one v_perm_b32 gathers the four high bytes.  9 VALU operations per 4 key bytes instead of 11.
-__device__ __forceinline__ uint32_t pk_mul_sat_i16(uint32_t a, uint32_t b)
-{
-    uint32_t d;
-    asm("v_pk_mad_i16 %0, %1, %2, 0 clamp" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-__device__ __forceinline__ int lane_row_sum7(const i32x4 x, const ScanConst &c)
-{
-    int acc = 0;
-#pragma unroll
-    for (int d = 0; d < 4; d++) {
-        const uint32_t w = (uint32_t)x[d];
-        const uint32_t pe = pk_mul_sat_i16(w & 0x007F007Fu, c.ue[d]);           // bytes 0 and 2
-        const uint32_t po = pk_mul_sat_i16((w >> 8) & 0x007F007Fu, c.uo[d]);    // bytes 1 and 3
-        const uint32_t tb = __builtin_amdgcn_perm(po, pe, 0x07030501u);         // the four high bytes, in column order
-        const uint32_t sb = (w ^ c.s7[d]) & 0x80808080u;
-        const uint32_t sg = __builtin_amdgcn_perm(0x01010101u, 0x01010101u, sb);
-        acc = __builtin_amdgcn_sdot4((int)tb, (int)sg, acc, false);
-    }
-    return acc;
-}
 // W7: every matrix format of the launch (attention and linear-map weights) has word length 7
 template <bool W7>
 __device__ __forceinline__ void publish_const(uint8_t *lw, uint32_t lane, int k, uint32_t wl, int fv)
