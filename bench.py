@@ -714,7 +714,7 @@ def run_workload(args, name, dev, rank, world):
                    "queries_per_gpu": B, "format": "Q5.2", "attention_mode": mode,
                    "key_row_bytes": key_row_bytes, "answer_layer": wl["ans"], "dim_answer": V,
                    "parallelism": f"replicas x{world}, query-sharded"},
-        "roofline": {"bound": "hbm", "kernel": "k_hops_small" if (mode != 1 and S <= 64) else KERNEL_OF_MODE[mode], "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": "k_hops_lean" if (mode != 1 and S <= 64 and Dp == 64 and planes is None) else KERNEL_OF_MODE[mode], "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes_per_launch": bytes_per_query * B, "bytes_per_query": bytes_per_query,
                      "bytes_counted": "keys + values (float read-out streams both)" if mode == 1 else
@@ -726,6 +726,16 @@ def run_workload(args, name, dev, rank, world):
                          "tops": 2.0 * B * V * D / (ans_ms * 1e-3) / 1e12,
                          "mfma_int8_peak_tops": 5000.0 if wl["ans"] == "i8" else None},
     }
+    if wl["ans"] == "i8":
+        al = out["answer_layer"]
+        al["kernel"] = "k_answer_i8_part + k_answer_i8_combine (one pass: MFMA projection, softmax statistics and arg-max in registers)"
+        al["frac_of_int8_peak"] = al["tops"] / 5000.0
+        mj = ROOT / "profiles" / "mfma.json"
+        if mj.exists():
+            rec = json.loads(mj.read_text()).get(name)
+            if rec:      # matrix-pipe occupancy from the PMC counters of a separate rocprofv3 pass of this command (not measured in this run)
+                al["mfma_busy_frac_counters"] = rec["mfma_busy_frac"]
+                al["mfma_counters_source"] = rec["source"]
     st = rank_stats(world, dev, roofline_frac=achieved / HBM_PEAK_GBS, kernel_ms=hop_ms,
                     queries_per_s=B * args.steps / elapsed_local)
     if st:

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (via gpurun): rocprofv3 passes for one bench workload, CSV output under gpurun_out/prof/.
-#   tools/collect_profiles.sh <tag> <workload> [fetch] [sq]
+#   tools/collect_profiles.sh <tag> <workload> [fetch] [sq] [mfma]
 # kernel trace + stats always; "fetch" adds a FETCH_SIZE counter pass, "sq" an SQ instruction-mix pass
 # (counters are collected in their own runs, never together with tracing).
 set -e
@@ -18,6 +18,7 @@ prune $P/${tag}_stats
 for pass in "$@"; do
   case $pass in
     fetch) rocprofv3 --pmc FETCH_SIZE --output-format csv -d $P/${tag}_pmc_fetch -- python3 $R/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $P/${tag}_pmc_fetch.log 2>&1; prune $P/${tag}_pmc_fetch ;;
+    mfma) rocprofv3 --pmc SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU --output-format csv -d $P/${tag}_pmc_mfma -- python3 $R/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $P/${tag}_pmc_mfma.log 2>&1; prune $P/${tag}_pmc_mfma ;;
     sq) rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $P/${tag}_pmc_sq -- python3 $R/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $P/${tag}_pmc_sq.log 2>&1; prune $P/${tag}_pmc_sq ;;
   esac
 done

@@ -66,3 +66,32 @@ if sq:
             for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
                 if k in agg: f.write(f"{k} / SQ_WAVE_CYCLES = {sum(agg[k]) / len(agg[k]) / wc:.3f}\n")
     print(open(out / f"{tag}_pmc_sq_{workload}.txt").read())
+
+mf = glob.glob(str(src / f"{tag}_pmc_mfma" / "*" / "*counter_collection.csv"))
+if mf:
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(mf[0])):
+        if "k_answer_i8_part" in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    st_rows = [r for r in rows if "k_answer_i8_part" in r["Name"]] if st else []
+    if agg and st_rows:
+        avg_ns = float(st_rows[0]["AverageNs"])
+        busy = sum(agg["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(agg["SQ_VALU_MFMA_BUSY_CYCLES"])
+        insts = sum(agg["SQ_INSTS_VALU_MFMA_I8"]) / len(agg["SQ_INSTS_VALU_MFMA_I8"])
+        # SQ_VALU_MFMA_BUSY_CYCLES: cycles, summed over the chip's 1 024 SIMDs; the kernel's cycles at the clock SQ_BUSY_CYCLES implies
+        sq_busy = sum(agg["SQ_BUSY_CYCLES"]) / len(agg["SQ_BUSY_CYCLES"])
+        frac = busy / 1024.0 / (avg_ns * 1e-9 * 2.1e9)
+        with open(out / f"{tag}_pmc_mfma_{workload}.txt", "w") as f:
+            f.write(f"rocprofv3 --pmc SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU --output-format csv -- python3 bench.py --workload {workload} --steps 3 --warmup 1 --no-cpu-baseline --no-secondary (MI355X)\n")
+            f.write("k_answer_i8_part (int8 MFMA projection + softmax statistics + arg-max), mean per dispatch\n")
+            for k, v in sorted(agg.items()):
+                f.write(f"{k:28s} {sum(v) / len(v):16.0f}\n")
+            f.write(f"v_mfma_i32_16x16x64_i8 issued = {insts:.0f} = {insts * 2 * 16 * 16 * 64 / 1e9:.2f} GOP\n")
+            f.write(f"kernel average (kernel trace of the same command) = {avg_ns / 1e3:.1f} us\n")
+            f.write(f"matrix-pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (kernel time x 2.1 GHz) = {frac:.4f}\n")
+            f.write(f"SQ_BUSY_CYCLES (per XCD-SE aggregate, for the clock estimate) = {sq_busy:.0f}\n")
+        print(open(out / f"{tag}_pmc_mfma_{workload}.txt").read())
+        mj = out / "mfma.json"
+        d = json.loads(mj.read_text()) if mj.exists() else {}
+        d[workload] = {"mfma_busy_frac": frac, "mfma_insts": insts, "kernel_us": avg_ns / 1e3, "source": f"profiles/{tag}_pmc_mfma_{workload}.txt"}
+        mj.write_text(json.dumps(d, indent=1) + "\n")
