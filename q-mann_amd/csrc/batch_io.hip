@@ -297,56 +297,65 @@ struct AnsPart {            // per (slice, query)
     int m;                  // maximum logit code of the slice
     uint32_t idx;           // its highest index
     double sum;             // sum over the slice of e^((k - m) . scale)
-    int ky;                 // code of the labelled answer's logit, if it lies in the slice
-    uint32_t has_y;
 };
-constexpr uint32_t kAnsTile = 64;                       // dictionary rows per LDS tile
+constexpr uint32_t kAnsTile = 64;                       // dictionary rows per LDS tile = 4 accumulator blocks of 16
 constexpr int kAnsFloor = -(1 << 28);                   // below every logit code (|sum of 256 products of 7-bit codes| < 2^23); e^(floor . scale) = 0
 
-// e^x for the running normaliser: the hardware exponential (v_exp_f32 of x . log2 e, ~2 ulp) for the e^x base -- the
-// reference's own kernel uses the fast __expf there (lib/layer_cuda.cu:2006) -- and the shared definitions for the others
-__device__ __forceinline__ float ans_exp(float x, const SmCfg &c)
+// e^((k - m) . scale) for a code difference dk <= 0.  Base e^x: the hardware exponential with scale . log2 e folded into one
+// factor (v_cvt, v_mul, v_exp; ~2 ulp -- the reference's own kernel uses the fast __expf there, lib/layer_cuda.cu:2006);
+// the other bases through the shared definitions.
+template <bool EXPB>
+__device__ __forceinline__ float ans_term(int dk, float scale, float scale_log2e, const SmCfg &c)
 {
-    return c.base == QMANN_SOFTMAX_EXP ? __expf(x) : sm_exp(x, c);
+    if (EXPB) return __builtin_amdgcn_exp2f((float)dk * scale_log2e);
+    return sm_exp((float)dk * scale, c);
 }
 
-template <int KSTEPS>
+template <int KSTEPS, bool EXPB>
 __global__ void __launch_bounds__(kBlock)
-k_answer_i8_part(const float *__restrict__ u, const int8_t *__restrict__ w, const uint32_t *__restrict__ answer, AnsPart *__restrict__ part,
+k_answer_i8_part(const float *__restrict__ u, const int8_t *__restrict__ w, AnsPart *__restrict__ part,
                  uint32_t n_query, uint32_t D, uint32_t V, QFmt fu, float scale, uint32_t softmax_base, uint32_t tiles_per_slice)
 {
-    constexpr uint32_t Dp = KSTEPS * 64, PITCH = Dp + 16;
+    constexpr uint32_t Dp = KSTEPS * 64, PITCH = Dp + 16, NB = kAnsTile / 16;
     __shared__ __attribute__((aligned(16))) uint8_t tile[2][kAnsTile * PITCH];
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
     const uint32_t m0 = (blockIdx.x * kWaves + wave) * 16;
     const uint32_t row = lane & 15, kq = lane >> 4;
     const SmCfg smc{softmax_base, false, false, 1.0f};
-    // A fragments: this lane's query row, converted once
+    const float scale_log2e = scale * 1.44269504088896341f;
+    // A fragments: the wavefront's 16 query rows are read coalesced, turned into codes and passed through a private
+    // corner of the second tile buffer (nobody writes it before the barrier below), so that each lane can pick up its
+    // row's 16-byte pieces; they stay in registers for the whole slice
     i32x4 a[KSTEPS];
+    {
+        uint8_t *stage = tile[1] + wave * 16 * PITCH;
+        const bool vec = (D & 3u) == 0;
+#pragma unroll 4
+        for (uint32_t i = lane; i < 16 * (Dp / 4); i += kWave) {
+            const uint32_t r = i / (Dp / 4), c = (i % (Dp / 4)) * 4;
+            const bool ok = m0 + r < n_query;
+            const float *src = u + (size_t)(m0 + r) * D + c;
+            float x[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (vec) {
+                if (ok && c < D) { const float4 v = *(const float4 *)src; x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w; }
+            } else {
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ks++) {
-        const uint32_t kb = ks * 64 + 16 * kq;
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
+                for (int j = 0; j < 4; j++) if (ok && c + j < D) x[j] = src[j];
+            }
             uint32_t pk = 0;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const uint32_t c = kb + 4 * d + i;
-                const int code = (m0 + row < n_query && c < D) ? qm_code(u[(size_t)(m0 + row) * D + c], fu.iwl, fu.frac) : 0;
-                pk |= ((uint32_t)code & 0xFFu) << (8 * i);
-            }
-            a[ks][d] = (int)pk;
+            for (int j = 0; j < 4; j++) pk |= ((uint32_t)qm_code(x[j], fu.iwl, fu.frac) & 0xFFu) << (8 * j);
+            *(uint32_t *)(stage + r * PITCH + c) = pk;
         }
-    }
-    // accumulator layout: lane l holds answer column l & 15 of the 16-answer block and query rows 4 (l >> 4) + r
-    uint32_t yq[4];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const uint32_t q = m0 + 4 * kq + r;
-        yq[r] = (answer && q < n_query) ? answer[q] : 0xFFFFFFFFu;
+        for (int ks = 0; ks < KSTEPS; ks++) a[ks] = *(const i32x4 *)(stage + row * PITCH + ks * 64 + 16 * kq);
     }
-    int mx[4] = {kAnsFloor, kAnsFloor, kAnsFloor, kAnsFloor}, ky[4] = {0, 0, 0, 0};     // (no logit is that low: the first one becomes the maximum)
-    uint32_t bi[4] = {0, 0, 0, 0}, hy[4] = {0, 0, 0, 0};
+    // accumulator layout: lane l holds answer column l & 15 of a 16-answer block and query rows 4 (l >> 4) + r
+    int mx[4] = {kAnsFloor, kAnsFloor, kAnsFloor, kAnsFloor};       // (no logit is that low: the first one becomes the maximum)
+    uint32_t bi[4] = {0, 0, 0, 0};
     double sm[4] = {0.0, 0.0, 0.0, 0.0};
 
     const uint32_t n_tiles = (V + kAnsTile - 1) / kAnsTile;
@@ -374,38 +383,40 @@ k_answer_i8_part(const float *__restrict__ u, const int8_t *__restrict__ w, cons
     for (uint32_t t = t_lo; t < t_hi; t++) {
         const uint32_t b = (t - t_lo) & 1u;
         if (t + 1 < t_hi) fetch(t + 1);
+        // four independent accumulator chains: the matrix pipe runs them back to back
+        i32x4 acc[NB];
 #pragma unroll
-        for (uint32_t nb = 0; nb < kAnsTile / 16; nb++) {
-            i32x4 acc = {0, 0, 0, 0};
+        for (uint32_t nb = 0; nb < NB; nb++) acc[nb] = i32x4{0, 0, 0, 0};
 #pragma unroll
-            for (int ks = 0; ks < KSTEPS; ks++) {
+        for (int ks = 0; ks < KSTEPS; ks++)
+#pragma unroll
+            for (uint32_t nb = 0; nb < NB; nb++) {
                 const i32x4 bm = *(const i32x4 *)(tile[b] + (nb * 16 + row) * PITCH + ks * 64 + kq * 16);
-                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks], bm, acc, 0, 0, 0);
+                acc[nb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks], bm, acc[nb], 0, 0, 0);
             }
-            const uint32_t v = t * kAnsTile + nb * 16 + row;
-            const bool v_ok = v < V;
-            // Branch-free per element: ONE exp of -|k - max| serves both cases (new maximum: rescale the sum and add 1; else
-            // add the term).  A block whose every logit lies more than 40 below its row's running maximum changes nothing
-            // but the label bookkeeping (terms under 1e-17 of the sum) and is skipped as a whole -- the usual case once the
-            // maxima have settled.
-            bool near = false;
+        const uint32_t v0 = t * kAnsTile + row;                          // this lane's column in block nb: v0 + 16 nb
+        if (t * kAnsTile + kAnsTile > V) {                               // the ragged last tile: columns past V drop out
 #pragma unroll
-            for (int r = 0; r < 4; r++) near |= v_ok && (float)(acc[r] - mx[r]) * scale > -40.0f;
-            if (__any(near)) {
+            for (uint32_t nb = 0; nb < NB; nb++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int k = v_ok ? acc[r] : kAnsFloor;
-                    const bool gt = k > mx[r];
-                    const int dk = gt ? mx[r] - k : k - mx[r];                       // -|k - max| (no overflow: |codes| < 2^23)
-                    const double e = (double)ans_exp((float)dk * scale, smc);
-                    sm[r] = gt ? sm[r] * e + 1.0 : (v_ok ? sm[r] + e : sm[r]);
-                    bi[r] = (v_ok && k >= mx[r]) ? v : bi[r];                      // columns arrive in ascending order: the later index wins a tie
-                    mx[r] = gt ? k : mx[r];
-                }
+                for (int r = 0; r < 4; r++) acc[nb][r] = (v0 + 16 * nb < V) ? acc[nb][r] : kAnsFloor;
+        }
+        // Per query row: the new maximum over the four columns first, ONE rescale of the running sum, then the four terms
+        // (summed in float: four values <= 1) -- 2 conversions and 1 multiply-add in double per row and tile.
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int mn = mx[r];
+#pragma unroll
+            for (uint32_t nb = 0; nb < NB; nb++) mn = acc[nb][r] > mn ? acc[nb][r] : mn;
+            const float fs = ans_term<EXPB>(mx[r] - mn, scale, scale_log2e, smc);      // 1 when the maximum stays (no overflow: |codes| < 2^23)
+            float e = 0.0f;
+#pragma unroll
+            for (uint32_t nb = 0; nb < NB; nb++) {
+                e += ans_term<EXPB>(acc[nb][r] - mn, scale, scale_log2e, smc);
+                bi[r] = (acc[nb][r] == mn) ? v0 + 16 * nb : bi[r];        // columns arrive in ascending order: the later index wins a tie
             }
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-                if (v == yq[r]) { ky[r] = acc[r]; hy[r] = 1u; }
+            sm[r] = sm[r] * (double)fs + (double)e;
+            mx[r] = mn;
         }
         if (t + 1 < t_hi) put(b ^ 1u);
         __syncthreads();
@@ -416,43 +427,60 @@ k_answer_i8_part(const float *__restrict__ u, const int8_t *__restrict__ w, cons
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int m2 = __shfl_xor(mx[r], o);
-            const uint32_t i2 = __shfl_xor(bi[r], o), h2 = __shfl_xor(hy[r], o);
-            const int k2 = __shfl_xor(ky[r], o);
+            const uint32_t i2 = __shfl_xor(bi[r], o);
             const double s2 = __shfl_xor(sm[r], o);
             const int M = m2 > mx[r] ? m2 : mx[r];
-            const double f1 = mx[r] == M ? 1.0 : (double)ans_exp((float)(mx[r] - M) * scale, smc);
-            const double f2 = m2 == M ? 1.0 : (double)ans_exp((float)(m2 - M) * scale, smc);
+            const double f1 = (double)ans_term<EXPB>(mx[r] - M, scale, scale_log2e, smc);
+            const double f2 = (double)ans_term<EXPB>(m2 - M, scale, scale_log2e, smc);
             sm[r] = sm[r] * f1 + s2 * f2;
             bi[r] = (m2 == mx[r]) ? (i2 > bi[r] ? i2 : bi[r]) : (m2 > mx[r] ? i2 : bi[r]);
             mx[r] = M;
-            if (h2) { ky[r] = k2; hy[r] = 1u; }
         }
     }
     if (row == 0) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const uint32_t q = m0 + 4 * kq + r;
-            if (q < n_query) part[(size_t)blockIdx.y * n_query + q] = AnsPart{mx[r], bi[r], sm[r], ky[r], hy[r]};
+            if (q < n_query) part[(size_t)blockIdx.y * n_query + q] = AnsPart{mx[r], bi[r], sm[r]};
         }
     }
 }
 
 // merges the slices of a query (ascending dictionary ranges: the later slice wins a tie), writes the prediction and
-// accumulates cost / match (cross_entropy_run mode 3)
+// accumulates cost / match (cross_entropy_run mode 3).  16 lanes per query: they also form the labelled answer's logit
+// code (one row of W against the query's codes -- the same integer the matrix cores produced for that column), so the
+// projection kernel carries no label bookkeeping.
 __global__ void __launch_bounds__(kBlock)
-k_answer_i8_combine(const AnsPart *__restrict__ part, const uint32_t *__restrict__ answer, uint32_t *__restrict__ pred, float *cost,
-                    uint32_t *match, uint32_t n_query, uint32_t n_slice, uint32_t V, float scale, uint32_t softmax_base)
+k_answer_i8_combine(const AnsPart *__restrict__ part, const float *__restrict__ u, const int8_t *__restrict__ w,
+                    const uint32_t *__restrict__ answer, uint32_t *__restrict__ pred, float *cost, uint32_t *match,
+                    uint32_t n_query, uint32_t n_slice, uint32_t D, uint32_t Dp, uint32_t V, QFmt fu, float scale, uint32_t softmax_base)
 {
     const SmCfg smc{softmax_base, false, false, 1.0f};
+    const uint32_t lane = threadIdx.x & (kWave - 1), sub = lane & 15;
+    const uint32_t wave_g = (blockIdx.x * kBlock + threadIdx.x) / kWave, n_wave = gridDim.x * (kBlock / kWave);
     float cost_acc = 0.0f;
     uint32_t match_acc = 0;
-    for (size_t q = (size_t)blockIdx.x * kBlock + threadIdx.x; q < n_query; q += (size_t)gridDim.x * kBlock) {
-        int M = kAnsFloor, ky = 0;
-        uint32_t bi = 0, hy = 0;
+    for (uint32_t qb = wave_g * 4; qb < n_query; qb += n_wave * 4) {              // wavefront-uniform trip count
+        const uint32_t q = qb + (lane >> 4);
+        const bool q_ok = q < n_query;
+        const uint32_t y = (answer && q_ok) ? answer[q] : 0xFFFFFFFFu;
+        int ky = 0;
+        if (y < V) {
+            const uint32_t per = Dp / 16;
+            for (uint32_t i = 0; i < per; i++) {
+                const uint32_t c = sub * per + i;
+                const int code = c < D ? qm_code(u[(size_t)q * D + c], fu.iwl, fu.frac) : 0;
+                ky += code * (int)w[(size_t)y * Dp + c];
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) ky += __shfl_xor(ky, o);
+        if (sub != 0 || !q_ok) continue;
+        int M = kAnsFloor;
+        uint32_t bi = 0;
         for (uint32_t s = 0; s < n_slice; s++) {
             const AnsPart p = part[(size_t)s * n_query + q];
             if (p.m >= M && p.m != kAnsFloor) { M = p.m; bi = p.idx; }
-            if (p.has_y) { ky = p.ky; hy = 1u; }
         }
         double total = 0.0;
         for (uint32_t s = 0; s < n_slice; s++) {
@@ -460,20 +488,17 @@ k_answer_i8_combine(const AnsPart *__restrict__ part, const uint32_t *__restrict
             total += p.sum * (p.m == M ? 1.0 : (double)sm_exp((float)(p.m - M) * scale, smc));
         }
         pred[q] = bi;
-        if (answer) {
-            const uint32_t y = answer[q];
-            if (y < V && hy) {
-                const float e = sm_exp((float)(ky - M) * scale, smc);
-                const float py = (softmax_base == QMANN_SOFTMAX_EXP) ? (float)((double)e / total) : e / (float)total;
-                cost_acc += -py;
-                match_acc += (y == bi) ? 1u : 0u;
-            }
+        if (y < V) {
+            const float e = sm_exp((float)(ky - M) * scale, smc);
+            const float py = (softmax_base == QMANN_SOFTMAX_EXP) ? (float)((double)e / total) : e / (float)total;
+            cost_acc += -py;
+            match_acc += (y == bi) ? 1u : 0u;
         }
     }
     if (answer) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { cost_acc += __shfl_xor(cost_acc, o); match_acc += __shfl_xor(match_acc, o); }
-        if ((threadIdx.x & 63u) == 0) {
+        if (lane == 0) {
             if (cost) atomicAdd(cost, cost_acc);
             if (match && match_acc) atomicAdd(match, match_acc);
         }
@@ -1136,22 +1161,32 @@ int qmann_answer_i8(const qmann_net *net, const int8_t *w_ans_i8, qmann_fmt w_fm
     const float scale = 1.0f / (float)(1u << (fu.frac + w_fmt.frac));
     hipStream_t st = (hipStream_t)stream;
     const QFmt fuq{fu.iwl, fu.frac};
-    if (!probs && !getenv("QMANN_ANSWER_TWO_PASS")) {
+    // (the running-maximum normaliser needs a true exponential: the piece-wise linear exp_plan takes the two-pass form)
+    if (!probs && net->softmax_base != QMANN_SOFTMAX_EXP_PLAN && !getenv("QMANN_ANSWER_TWO_PASS")) {
         // one pass: no logits round trip; the workspace holds the per-slice records
         const uint32_t qblocks = (n_query + 16 * kWaves - 1) / (16 * kWaves), n_tiles = (V + kAnsTile - 1) / kAnsTile;
-        uint32_t n_slice = qblocks >= 512u ? 1u : (512u + qblocks - 1) / qblocks;              // ~2 workgroups per CU
+        // ~2 workgroups per CU (measured at 8 192 x 4 096 x 256: 128 workgroups 86 us, 256: 55, 512: 45, 1 024: 46)
+        uint32_t n_slice = qblocks >= 512u ? 1u : (512u + qblocks - 1) / qblocks;
         if (n_slice > n_tiles) n_slice = n_tiles;
         while (n_slice > 1 && (size_t)n_slice * sizeof(AnsPart) > (size_t)V * sizeof(float)) n_slice--;   // records must fit logits_ws
         const uint32_t tps = (n_tiles + n_slice - 1) / n_slice;
         n_slice = (n_tiles + tps - 1) / tps;
         AnsPart *part = (AnsPart *)logits_ws;
         const dim3 grid1(qblocks, n_slice);
-        if (Dp == 64) k_answer_i8_part<1><<<grid1, kBlock, 0, st>>>(u, w_ans_i8, answer, part, n_query, D, V, fuq, scale, net->softmax_base, tps);
-        else if (Dp == 128) k_answer_i8_part<2><<<grid1, kBlock, 0, st>>>(u, w_ans_i8, answer, part, n_query, D, V, fuq, scale, net->softmax_base, tps);
-        else if (Dp == 256) k_answer_i8_part<4><<<grid1, kBlock, 0, st>>>(u, w_ans_i8, answer, part, n_query, D, V, fuq, scale, net->softmax_base, tps);
+        const bool eb = net->softmax_base == QMANN_SOFTMAX_EXP;
+#define QM_ANS_PART(KS)                                                                                                              \
+    do {                                                                                                                             \
+        if (eb) k_answer_i8_part<KS, true><<<grid1, kBlock, 0, st>>>(u, w_ans_i8, part, n_query, D, V, fuq, scale, net->softmax_base, tps);  \
+        else k_answer_i8_part<KS, false><<<grid1, kBlock, 0, st>>>(u, w_ans_i8, part, n_query, D, V, fuq, scale, net->softmax_base, tps);   \
+    } while (0)
+        if (Dp == 64) QM_ANS_PART(1);
+        else if (Dp == 128) QM_ANS_PART(2);
+        else if (Dp == 256) QM_ANS_PART(4);
         else return QMANN_EUNSUPPORTED;
-        const uint32_t cb = (n_query + kBlock - 1) / kBlock;
-        k_answer_i8_combine<<<cb < 1024u ? cb : 1024u, kBlock, 0, st>>>(part, answer, pred, cost, match, n_query, n_slice, V, scale, net->softmax_base);
+#undef QM_ANS_PART
+        const uint32_t cb = (n_query * 16 + kBlock - 1) / kBlock;
+        k_answer_i8_combine<<<cb < 2048u ? cb : 2048u, kBlock, 0, st>>>(part, u, w_ans_i8, answer, pred, cost, match, n_query, n_slice, D, Dp, V,
+                                                                        fuq, scale, net->softmax_base);
         QM_LAUNCH_CHECK();
         return qm_scope.rc();
     }

@@ -373,13 +373,14 @@ def test_answer_mfma_i8_bit_identical_to_float_path(env, oracle, D, V, B):
         np.testing.assert_array_equal(logits[q].cpu().numpy(), lo)
 
 
-@pytest.mark.parametrize("base", [0, 1])
+@pytest.mark.parametrize("base", [0, 1, 2])
 @pytest.mark.parametrize("D,V,B,sig", [(60, 30, 5, 40), (128, 256, 37, 40), (256, 256, 64, 3), (128, 1000, 33, 40), (256, 4096, 300, 12),
                                        (60, 4097, 2000, 1), (256, 65, 8192, 40)])
 def test_answer_mfma_i8_one_pass(env, D, V, B, sig, base):
     """Without a probabilities output the int8 answer layer runs in one pass (no logits round trip, running-maximum
     normaliser, dictionary slices merged by a second kernel): predictions -- ties to the highest index included -- and the
-    match count equal the float path exactly, the cost within the softmax tolerance.  Small sigma: many exact logit ties."""
+    match count equal the float path exactly, the cost within the softmax tolerance.  Small sigma: many exact logit ties.
+    (Base 2, exp_plan, is not an exponential: the library must route it to the two-pass form.)"""
     torch, model, abi = env.torch, env.model, env.abi
     rng = np.random.default_rng(D + V + B + base)
     cfg = cfg_synth(D, V, 5, base=base)
