@@ -127,20 +127,25 @@ k_hops_float(const HopArgs a)
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[i] = 0.0f;
             const uint8_t *vb = (const uint8_t *)a.vals + (size_t)h * a.hop_stride + (size_t)r0 * Dp + chunk * 16;
-            // acc[i] += (p . 2^-frac) . (+-|code|): the magnitude byte converts with one v_cvt_f32_ubyte, the
-            // sign bit is moved onto the float's sign, one FMA accumulates (inside the mode's 1e-5 tolerance)
+            // acc[i] += (p . 2^-frac) . code.  Four sign-magnitude bytes become two's complement in 6 word-wide steps
+            // (offset binary first: 128 + m or 128 - m never carries into the neighbour byte, "minus zero" included; then the
+            // top bits flip), each byte converts with one sign-extending v_cvt_f32_i32 (SDWA byte select), one FMA accumulates
             auto accumulate = [&](const i32x4 x, float ps) {
 #pragma unroll
                 for (int d = 0; d < 4; d++) {
                     const uint32_t w = (uint32_t)x[d];
-                    const uint32_t mag = w & 0x7F7F7F7Fu;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const float m = (float)((mag >> (8 * i)) & 0xFFu);
-                        const uint32_t sgn = (w << (24 - 8 * i)) & 0x80000000u;
-                        const float v = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, m) | sgn);
-                        acc[4 * d + i] = __builtin_fmaf(ps, v, acc[4 * d + i]);
-                    }
+                    const uint32_t t = w & 0x80808080u, one = t >> 7;                    // 0x80 / 0x01 in the negative bytes
+                    const uint32_t ob = (w ^ 0x80808080u ^ (t - one)) + one;             // 128 + m | (127 - m) + 1
+                    const uint32_t tc = ob ^ 0x80808080u;
+                    float v0, v1, v2, v3;
+                    asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0" : "=v"(v0) : "v"(tc));
+                    asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1" : "=v"(v1) : "v"(tc));
+                    asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2" : "=v"(v2) : "v"(tc));
+                    asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3" : "=v"(v3) : "v"(tc));
+                    acc[4 * d + 0] = __builtin_fmaf(ps, v0, acc[4 * d + 0]);
+                    acc[4 * d + 1] = __builtin_fmaf(ps, v1, acc[4 * d + 1]);
+                    acc[4 * d + 2] = __builtin_fmaf(ps, v2, acc[4 * d + 2]);
+                    acc[4 * d + 3] = __builtin_fmaf(ps, v3, acc[4 * d + 3]);
                 }
             };
             if (S >= TILE) {
