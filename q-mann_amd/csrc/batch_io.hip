@@ -115,33 +115,59 @@ k_answer(const float *__restrict__ w_ans, const float *__restrict__ u, const uin
     }
 }
 
-// Answer layer for small dictionaries (V <= 256: bAbI single-task and joint sizes): one WAVEFRONT per
-// query, lane l owns the VPT adjacent logits VPT.l .. VPT.l + VPT - 1 -- the same arithmetic as k_answer
-// without block barriers; W is staged transposed in LDS once per (persistent) workgroup, so a lane reads
-// its VPT weights of an embedding column with one 4.VPT-byte LDS load and the products / sums go through
-// the packed fp32 pipeline.
+// Answer layer for small dictionaries (V <= 256: bAbI single-task and joint sizes): SIXTEEN LANES per query, four
+// queries per wavefront; lane s of a group owns the VPT adjacent logits VPT.s .. VPT.s + VPT - 1 (16 . VPT >= V).  The
+// arithmetic is k_answer's (serial float sum over the embedding axis per logit, softmax with a double normaliser,
+// arg-max with ties to the highest index) without block barriers.  W is staged transposed in LDS once per (persistent)
+// workgroup; per embedding column a lane reads its VPT weights and its query's component from LDS and the products /
+// sums go through the packed fp32 pipeline.  The kernel is bound by vector-instruction issue: with one query per
+// wavefront (round 1) the reductions and the per-logit divisions cost ~450 instructions per query whatever V was; a
+// 16-lane group is one DPP row, so every reduction is four DPP steps serving four queries.
 // 16 wavefronts per workgroup share one copy of W^T (up to 61 KB): 2 workgroups fill a CU's 32 wavefront slots
 constexpr int kAnsBlock = 1024, kAnsWaves = kAnsBlock / kWave;
-template <int VPT>
-__global__ void __launch_bounds__(kAnsBlock)
+
+// butterfly over the 16 lanes of a DPP row: after the four steps every lane holds the row's result
+// (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror)
+#define QM_ROW_STEPS(X) X(0xB1) X(0x4E) X(0x141) X(0x140)
+template <int CTRL> __device__ __forceinline__ float row_peer_f32(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL> __device__ __forceinline__ uint32_t row_peer_u32(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL> __device__ __forceinline__ double row_peer_f64(double v)
+{
+    const uint64_t b = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = row_peer_u32<CTRL>((uint32_t)b), hi = row_peer_u32<CTRL>((uint32_t)(b >> 32));
+    return __builtin_bit_cast(double, (uint64_t)lo | ((uint64_t)hi << 32));
+}
+
+template <int LPQ, int VPT, int QB>
+__global__ void __launch_bounds__(kAnsBlock, 8)             // 64 registers: two workgroups per CU
 k_answer_small(const float *__restrict__ w_ans, const float *__restrict__ u, const uint32_t *__restrict__ answer,
                uint32_t *__restrict__ pred, float *__restrict__ probs, float *cost, uint32_t *match, uint32_t D,
                uint32_t V, uint32_t softmax_base, uint32_t n_query)
 {
-    typedef float fvec __attribute__((ext_vector_type(VPT)));
+    static_assert(VPT % 2 == 0, "logits are handled in pairs");
+    typedef float f2 __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr uint32_t VP = 64 * VPT;                   // logits padded to whole wavefronts (zero columns)
+    static_assert(LPQ == 16 || LPQ == 32 || LPQ == 64, "a query's lanes are whole DPP rows");
+    constexpr uint32_t VP = LPQ * VPT;                  // logits padded to a whole group (zero columns)
+    constexpr uint32_t QPW = (kWave / LPQ) * QB;        // queries per wavefront: QB per lane group, sharing each weight read
+    typedef float fq __attribute__((ext_vector_type(QB)));
     float *wt = (float *)smem;                          // [D][VP]: W transposed
-    float *us = wt + (size_t)D * VP + (threadIdx.x / kWave) * D;     // [kAnsWaves][D]: this wavefront's query
-    const uint32_t lane = threadIdx.x & (kWave - 1);
-    const size_t stride = (size_t)gridDim.x * kAnsWaves;
+    float *us = wt + (size_t)D * VP + (threadIdx.x / kWave) * QPW * D;   // [kAnsWaves][D][QPW]: this wavefront's queries, interleaved
+    const uint32_t lane = threadIdx.x & (kWave - 1), grp = lane / LPQ, sub = lane % LPQ;
+    const size_t stride = (size_t)gridDim.x * kAnsWaves * QPW;
     for (uint32_t i = threadIdx.x; i < D * VP; i += kAnsBlock) {
         const uint32_t c = i / VP, v = i % VP;
         wt[i] = v < V ? w_ans[(size_t)v * D + c] : 0.0f;
     }
     __syncthreads();
     const SmCfg smc{softmax_base, false, false, 1.0f};  // sf_out is never shift-based (MemN2N.c:910)
-    const uint32_t v0 = lane * VPT;                     // first logit of this lane
+    const uint32_t v0 = sub * VPT;                      // first logit of this lane
     bool live[VPT];
 #pragma unroll
     for (int k = 0; k < VPT; k++) live[k] = v0 + k < V;
@@ -149,72 +175,106 @@ k_answer_small(const float *__restrict__ w_ans, const float *__restrict__ u, con
     // single word would serialise the whole batch (~12 ns each)
     float cost_acc = 0.0f;
     uint32_t match_acc = 0;
-    for (size_t q = (size_t)blockIdx.x * kAnsWaves + threadIdx.x / kWave; q < n_query; q += stride) {
-        for (uint32_t c = lane; c < D; c += kWave) us[c] = u[q * D + c];
+    for (size_t qb = ((size_t)blockIdx.x * kAnsWaves + threadIdx.x / kWave) * QPW; qb < n_query; qb += stride) {
+        const uint32_t nq = n_query - qb < QPW ? (uint32_t)(n_query - qb) : QPW;
+        for (uint32_t i = lane; i < nq * D; i += kWave) us[(i % D) * QPW + i / D] = u[qb * D + i];   // consecutive queries: one contiguous block
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        fvec acc = 0.0f;
-#pragma unroll 4
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        f2 acc[QB][VPT / 2];
+#pragma unroll
+        for (int j = 0; j < QB; j++)
+#pragma unroll
+            for (int k = 0; k < VPT / 2; k++) acc[j][k] = f2{0.0f, 0.0f};
+        const float *uq = us + grp * QB;
+        const float *wl = wt + v0;
+#pragma unroll 2
         for (uint32_t c = 0; c < D; c++) {               // serial over the embedding axis, as the reference sums
-            const fvec w = *(const fvec *)(wt + c * VP + v0);
-            const fvec t = w * us[c];
-            acc += t;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // reads of us[] done before the next query overwrites it
-        float sum[VPT];
+            const fq uc = *(const fq *)(uq + c * QPW);
 #pragma unroll
-        for (int k = 0; k < VPT; k++) sum[k] = acc[k];
-        float mx = -INFINITY;
+            for (int k = 0; k < VPT / 2; k++) {
+                const f2 w = *(const f2 *)(wl + c * VP + 2 * k);
 #pragma unroll
-        for (int k = 0; k < VPT; k++) mx = (live[k] && sum[k] > mx) ? sum[k] : mx;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float t = __shfl_xor(mx, o);
-            mx = t > mx ? t : mx;
-        }
-        float e[VPT];
-        double total = 0.0;
-#pragma unroll
-        for (int k = 0; k < VPT; k++) {
-            e[k] = live[k] ? sm_exp(sum[k] - mx, smc) : 0.0f;
-            total += (double)e[k];
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
-        float bv = -INFINITY;
-        uint32_t bi = 0;
-        float p[VPT];
-#pragma unroll
-        for (int k = 0; k < VPT; k++) {
-            p[k] = (softmax_base == QMANN_SOFTMAX_EXP) ? (float)((double)e[k] / total) : e[k] / (float)total;
-            if (live[k]) {
-                if (probs) probs[q * V + v0 + k] = p[k];
-                if (!(bv > p[k])) { bv = p[k]; bi = v0 + k; }               // later index wins a tie
+                for (int j = 0; j < QB; j++) {
+                    const f2 t = w * uc[j];
+                    acc[j][k] += t;
+                }
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // reads of us[] done before the next queries overwrite it
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float tv = __shfl_xor(bv, o);
-            const uint32_t ti = __shfl_xor(bi, o);
-            if (tv > bv || (tv == bv && ti > bi)) { bv = tv; bi = ti; }   // ties go to the highest index
-        }
-        if (lane == 0) pred[q] = bi;
-        if (answer) {
-            const uint32_t y = answer[q];
-            if (y < V) {
-                float py = 0.0f;
+        for (int j = 0; j < QB; j++) {
+            const bool q_ok = grp * QB + j < nq;         // (a missing query's lanes compute on stale LDS and store nothing)
+            const size_t q = qb + grp * QB + j;
+            float sum[VPT];
 #pragma unroll
-                for (int k = 0; k < VPT; k++) py = (y % VPT == (uint32_t)k) ? __shfl(p[k], (int)(y / VPT)) : py;
-                cost_acc += -py;
-                match_acc += (y == bi) ? 1u : 0u;
+            for (int k = 0; k < VPT; k++) sum[k] = acc[j][k / 2][k % 2];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < VPT; k++) mx = (live[k] && sum[k] > mx) ? sum[k] : mx;
+#define QM_STEP(C) { const float t = row_peer_f32<C>(mx); mx = t > mx ? t : mx; }
+            QM_ROW_STEPS(QM_STEP)
+#undef QM_STEP
+#pragma unroll
+            for (int o = 16; o < LPQ; o <<= 1) { const float t = __shfl_xor(mx, o); mx = t > mx ? t : mx; }
+            float e[VPT];
+            double total = 0.0;
+#pragma unroll
+            for (int k = 0; k < VPT; k++) {
+                e[k] = live[k] ? sm_exp(sum[k] - mx, smc) : 0.0f;
+                total += (double)e[k];
+            }
+#define QM_STEP(C) total += row_peer_f64<C>(total);
+            QM_ROW_STEPS(QM_STEP)
+#undef QM_STEP
+#pragma unroll
+            for (int o = 16; o < LPQ; o <<= 1) total += __shfl_xor(total, o);
+            float bv = -INFINITY;
+            uint32_t bi = 0;
+            float p[VPT];
+#pragma unroll
+            for (int k = 0; k < VPT; k++) {
+                p[k] = (softmax_base == QMANN_SOFTMAX_EXP) ? (float)((double)e[k] / total) : e[k] / (float)total;
+                if (live[k]) {
+                    if (probs && q_ok) probs[q * V + v0 + k] = p[k];
+                    if (!(bv > p[k])) { bv = p[k]; bi = v0 + k; }               // later index wins a tie
+                }
+            }
+#define QM_STEP(C) { const float tv = row_peer_f32<C>(bv); const uint32_t ti = row_peer_u32<C>(bi); \
+                     if (tv > bv || (tv == bv && ti > bi)) { bv = tv; bi = ti; } }   /* ties go to the highest index */
+            QM_ROW_STEPS(QM_STEP)
+#undef QM_STEP
+#pragma unroll
+            for (int o = 16; o < LPQ; o <<= 1) {
+                const float tv = __shfl_xor(bv, o);
+                const uint32_t ti = __shfl_xor(bi, o);
+                if (tv > bv || (tv == bv && ti > bi)) { bv = tv; bi = ti; }
+            }
+            if (sub == 0 && q_ok) pred[q] = bi;
+            if (answer) {
+                const uint32_t y = q_ok ? answer[q] : 0xFFFFFFFFu;
+                const uint32_t ys = y < V ? y : 0u;
+                float psel = p[0];
+#pragma unroll
+                for (int k = 1; k < VPT; k++) psel = (ys % VPT == (uint32_t)k) ? p[k] : psel;
+                const float py = __shfl(psel, (int)(grp * LPQ + ys / VPT));
+                if (sub == 0 && y < V) {
+                    cost_acc += -py;
+                    match_acc += (y == bi) ? 1u : 0u;
+                }
             }
         }
     }
-    if (answer && lane == 0) {
-        if (cost) atomicAdd(cost, cost_acc);
-        if (match && match_acc) atomicAdd(match, match_acc);
+    if (answer) {
+#pragma unroll
+        for (int o = LPQ; o < kWave; o <<= 1) { cost_acc += __shfl_xor(cost_acc, o); match_acc += __shfl_xor(match_acc, o); }
+        if (lane == 0) {
+            if (cost) atomicAdd(cost, cost_acc);
+            if (match && match_acc) atomicAdd(match, match_acc);
+        }
     }
 }
+#undef QM_ROW_STEPS
 
 // ---------------------------------------------------------------------------
 // Answer projection on the matrix cores, for an answer matrix that lives on an int8 grid:
@@ -1126,15 +1186,35 @@ int qmann_answer_f32(const qmann_net *net, const float *w_ans, const float *u, c
     if (n_query >= (1u << 24)) return QMANN_ERANGE;      // one workgroup per query: a launch holds < 2^32 threads
     if (lds > 48 * 1024)
         QM_HIP(hipFuncSetAttribute((const void *)k_answer<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const uint32_t v_pad = V <= 64 ? 64u : (V <= 128 ? 128u : 256u);
-    const size_t lds_small = ((size_t)D * v_pad + (size_t)kAnsWaves * D) * sizeof(float);
-    if (V <= 4u * kWave && lds_small <= 64 * 1024) {        // W^T fits LDS: one wavefront per query
-        const uint32_t need = (n_query + kAnsWaves - 1) / kAnsWaves;
+    // lanes per query / logits per lane / queries per lane group.  Short dictionaries: 16 lanes (one DPP row), four
+    // queries side by side in a wavefront (the reductions are most of the work there); the joint-task sizes: the whole
+    // wavefront on four queries at once, every weight read from LDS used four times (that kernel is bound by LDS reads)
+    const uint32_t lpq = V <= 128 ? 16u : 64u, qb = V <= 128 ? 1u : 4u;
+    uint32_t vpt = (V + lpq - 1) / lpq;
+    vpt = vpt <= 2 ? 2u : vpt <= 4 ? 4u : vpt <= 6 ? 6u : 8u;
+    const uint32_t qpw = kWave / lpq * qb;
+    const size_t lds_small = ((size_t)D * lpq * vpt + (size_t)kAnsWaves * qpw * D) * sizeof(float);
+    if (V <= 256u && lds_small <= 78 * 1024) {              // W^T fits LDS twice per CU
+        const uint32_t need = (n_query + kAnsWaves * qpw - 1) / (kAnsWaves * qpw);
         const uint32_t blocks = need < 512u ? need : 512u;  // persistent: two 16-wavefront workgroups per CU
         hipStream_t st = (hipStream_t)stream;
-        if (V <= 64) k_answer_small<1><<<blocks, kAnsBlock, lds_small, st>>>(w_ans, u, answer, pred, probs, cost, match, D, V, net->softmax_base, n_query);
-        else if (V <= 128) k_answer_small<2><<<blocks, kAnsBlock, lds_small, st>>>(w_ans, u, answer, pred, probs, cost, match, D, V, net->softmax_base, n_query);
-        else k_answer_small<4><<<blocks, kAnsBlock, lds_small, st>>>(w_ans, u, answer, pred, probs, cost, match, D, V, net->softmax_base, n_query);
+#define QM_ANS_SMALL(L, N, Q)                                                                                                    \
+    do {                                                                                                                         \
+        if (lds_small > 48 * 1024)                                                                                               \
+            QM_HIP(hipFuncSetAttribute((const void *)k_answer_small<L, N, Q>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_small)); \
+        k_answer_small<L, N, Q><<<blocks, kAnsBlock, lds_small, st>>>(w_ans, u, answer, pred, probs, cost, match, D, V, net->softmax_base, n_query); \
+    } while (0)
+        if (lpq == 64) {
+            if (vpt <= 2) QM_ANS_SMALL(64, 2, 4); else QM_ANS_SMALL(64, 4, 4);
+        } else {
+            switch (vpt) {
+            case 2: QM_ANS_SMALL(16, 2, 1); break;
+            case 4: QM_ANS_SMALL(16, 4, 1); break;
+            case 6: QM_ANS_SMALL(16, 6, 1); break;
+            default: QM_ANS_SMALL(16, 8, 1); break;
+            }
+        }
+#undef QM_ANS_SMALL
         QM_LAUNCH_CHECK();
         return qm_scope.rc();
     }
