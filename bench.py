@@ -612,6 +612,8 @@ def run_workload(args, name, dev, rank, world):
     H = 3
     cfg = model.babi_cfg(V, attention_mode=mode, softmax_base=0, iwl=5, n_hop=H, D=D, en_mq=bool(wl.get("bow")))
     cfg["num_bit"] = nb
+    if os.environ.get("QMANN_BENCH_NO_LINMAP"):            # experiment: what the in-kernel linear map costs
+        cfg["en_lin_map"] = False
 
     # parameters: created on rank 0, broadcast once over RCCL (xGMI) -- the only collective
     wts = make_params(cfg, D, V, seed=0x51A44) if rank == 0 else None

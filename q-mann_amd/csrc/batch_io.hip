@@ -1205,7 +1205,7 @@ int qmann_answer_f32(const qmann_net *net, const float *w_ans, const float *u, c
         k_answer_small<L, N, Q><<<blocks, kAnsBlock, lds_small, st>>>(w_ans, u, answer, pred, probs, cost, match, D, V, net->softmax_base, n_query); \
     } while (0)
         if (lpq == 64) {
-            if (vpt <= 2) QM_ANS_SMALL(64, 2, 4); else QM_ANS_SMALL(64, 4, 4);
+            QM_ANS_SMALL(64, 4, 4);                         // V in 129 .. 256
         } else {
             switch (vpt) {
             case 2: QM_ANS_SMALL(16, 2, 1); break;

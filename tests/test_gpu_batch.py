@@ -631,12 +631,13 @@ def test_forward_from_weight_files_equals_forward_from_memory(env, oracle, gold,
 # answer layer on its own: every dictionary size class, ties, bookkeeping
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("base", [0, 1, 2])
-@pytest.mark.parametrize("V,D", [(30, 60), (64, 60), (65, 60), (100, 20), (128, 60), (200, 60), (256, 60), (256, 128),
-                                 (300, 60), (1000, 33)])
+@pytest.mark.parametrize("V,D", [(5, 60), (30, 60), (64, 60), (65, 60), (96, 60), (100, 20), (128, 60), (129, 60), (200, 60),
+                                 (256, 60), (256, 128), (300, 60), (1000, 33)])
 def test_answer_layer_vs_oracle(env, oracle, V, D, base):
     """logits in the reference's serial order (bit-identical), softmax within 1e-5, arg-max with ties to the
-    highest index, cost = -sum p[answer], match count -- for the one-wavefront kernel (V <= 256, W^T in LDS)
-    and the workgroup-per-query kernel."""
+    highest index, cost = -sum p[answer], match count -- for every shape of the small-dictionary kernel (V <= 256, W^T in
+    LDS: 16 lanes per query with 2 / 4 / 6 / 8 logits per lane, a whole wavefront on four queries above 128) and the
+    workgroup-per-query kernel."""
     torch, model = env.torch, env.model
     rng = np.random.default_rng(V * 7 + D + base)
     B = 37
