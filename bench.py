@@ -75,6 +75,9 @@ WORKLOADS = {
 # the whole forward from word indices through the library's own host object (include/qmann_model.h)
 for _n, _m, _nb in (("babi_joint20_v1", 11, 8), ("babi_joint20_v0", 10, 8), ("babi_joint20_appx", 3, 8), ("babi_joint20_fixed", 2, 8)):
     WORKLOADS[_n] = dict(S=64, D=60, V=238, B=262000, mode=_m, nb=_nb, ans="f32", joint=True)
+# the same with the embedding matrices tied across the hops as the reference trains them (TYPE_WEIGHT_TYING 2,
+# MemN2N/define.h:287; MemN2N.c:1770-1773): the host model then embeds the stories once for all hops
+WORKLOADS["babi_joint20_v1_tied"] = dict(S=64, D=60, V=238, B=262000, mode=11, nb=8, ans="f32", joint=True, tied=True)
 KERNEL_OF_MODE = {1: "k_hops_float", 2: "k_hops_fixed", 3: "k_hops_ham", 10: "k_hops_ham", 11: "k_hops_ham"}
 
 
@@ -425,6 +428,7 @@ def run_joint(args, name, wl, cfg, wts, dev, rank, world, model):
                    "dim_input": cfg["dim_input"], "hops": cfg["n_hop"], "queries_per_gpu": B, "format": "Q5.2",
                    "attention_mode": cfg["attention_mode"], "num_bit": cfg.get("num_bit", 8),
                    "stages": "one qmann_model_forward_words call: story embedding (int8 MFMA) + question embedding + hops + answer layer",
+                   "weight_tying": "layer-wise (hop 0's embedding matrices on every hop): one shared memory plane" if wl.get("tied") else "none (independent matrices per hop)",
                    "parallelism": f"replicas x{world}, query-sharded"},
         "roofline": {"bound": "hbm", "kernel": "whole forward (issue / latency bound at these sizes)",
                      "achieved": bytes_in * args.steps / elapsed / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -626,6 +630,9 @@ def run_workload(args, name, dev, rank, world):
     ans_fmt = (1, 6)
     if wl["ans"] == "i8":                       # answer matrix on an int8 grid -> the MFMA projection is exact
         wts["w_ans"] = (np.clip(np.rint(wts["w_ans"] * 64.0 * 4), -127, 127) / 64.0).astype(np.float32)
+    if wl.get("tied"):
+        wts["w_a"] = [wts["w_a"][0]] * H
+        wts["w_c"] = [wts["w_c"][0]] * H
     if wl.get("joint"):
         return run_joint(args, name, wl, cfg, wts, dev, rank, world, model)
     net = model.QNet(cfg, wts, device=str(dev))

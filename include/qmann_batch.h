@@ -124,7 +124,10 @@ int qmann_quantize_i8(const float *src, int8_t *dst, size_t rows, uint32_t cols,
  * then carry Q(w[h]) codes -- the embedding outputs, not re-quantised), or QMANN_ATT_HAMMING_V0 / _V1
  * computed straight from the int8 keys (the top num_bit bits of a sign-magnitude byte are its bit planes):
  * same scores as qmann_hops_packed without a packing pass -- the choice for short memories and for
- * num_bit = 8, where planes are no smaller than bytes. */
+ * num_bit = 8, where planes are no smaller than bytes.
+ * hop_stride may be 0: every hop then reads the same key / value plane -- layer-wise weight tying with equal
+ * formats on every hop (TYPE_WEIGHT_TYING 2, MemN2N/define.h:287; MemN2N.c:1770-1773 copies hop 0's embedding
+ * matrices over the others), where the per-hop memories are the same bytes.  `taps` need distinct planes. */
 int qmann_hops_i8(const qmann_net *net, const int8_t *keys, const int8_t *vals, size_t hop_stride,
                   const uint32_t *row_off, uint32_t max_slots, const float *u0, float *u_out,
                   const qmann_taps *taps, uint32_t n_query, void *stream);

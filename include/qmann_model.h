@@ -27,7 +27,10 @@ typedef struct qmann_model qmann_model;
 /* net: dimensions, attention mode, softmax variant and every Q-format (lin_map pointers are ignored:
  * the object builds its own); w: HOST float matrices as the layer structs hold them (e.g. straight
  * from qmann_weights_load, or the reference's emb_q.w_mat[0] ... after training).  The weights are
- * uploaded and converted on `stream`; the host arrays may be freed when the call returns. */
+ * uploaded and converted on `stream`; the host arrays may be freed when the call returns.
+ * Layer-wise weight tying (what the reference trains: TYPE_WEIGHT_TYING 2, MemN2N/define.h:287, MemN2N.c:1770-1773) is
+ * detected here: when every hop's embedding matrices equal hop 0's and the hops share their formats (EN_MQ off), the
+ * memories are embedded once and all hops read the one plane -- same results, a third of the embedding work. */
 int qmann_model_create(qmann_model **out, const qmann_net *net, const qmann_weights *w, void *stream);
 void qmann_model_destroy(qmann_model *m);
 

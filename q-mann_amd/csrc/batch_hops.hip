@@ -238,6 +238,7 @@ int qmann_hops_i8(const qmann_net *net, const int8_t *keys, const int8_t *vals, 
     if (net->n_hop == 0 || net->n_hop > QMANN_MAX_HOP) return QMANN_EINVAL;
     if (net->dim_emb == 0 || net->dim_emb > net->dim_emb_pad) return QMANN_EINVAL;
     if (net->dim_emb_pad != 64 && net->dim_emb_pad != 128 && net->dim_emb_pad != 256) return QMANN_EUNSUPPORTED;
+    if (taps && hop_stride == 0) return QMANN_EINVAL;       // taps are indexed [hop][row]: they need distinct hop planes
     if (net->attention_mode == QMANN_ATT_APPX)
         return qmann_hops_appx_impl(net, keys, vals, hop_stride, row_off, max_slots, u0, u_out, taps, n_query, stream);
     if (net->attention_mode == QMANN_ATT_HAMMING_V0 || net->attention_mode == QMANN_ATT_HAMMING_V1)

@@ -391,6 +391,7 @@ int qmann_hops_packed(const qmann_net *net, const uint64_t *key_planes, size_t k
     const uint32_t nb = net->num_bit, Dp = net->dim_emb_pad;
     if (nb != 1 && nb != 2 && nb != 4 && nb != 8) return QMANN_EUNSUPPORTED;
     if (key_hop_stride != val_hop_stride / Dp * (Dp / 64) * nb * 8) return QMANN_EINVAL;
+    if (taps && val_hop_stride == 0) return QMANN_EINVAL;   // taps are indexed [hop][row]: they need distinct hop planes
     HopArgs a;
     const int rc = fill_args(a, net, key_planes, vals, key_hop_stride, val_hop_stride, row_off, u0, u_out, taps);
     if (rc) return rc;

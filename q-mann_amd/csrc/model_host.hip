@@ -5,12 +5,18 @@
 #include "../../include/qmann_model.h"
 
 #include <new>
+#include <stdlib.h>
+#include <string.h>
 #include <vector>
 
 struct qmann_model {
     qmann_net net{};
     qmann_net emb_net{};     // formats the embedding kernels quantise the memories to (see qmann_model_create)
     uint32_t H = 0, D = 0, Dp = 0, V = 0;
+    // Layer-wise weight tying (TYPE_WEIGHT_TYING 2, MemN2N/define.h:287: after every update the reference copies hop 0's
+    // embedding matrices over the other hops', MemN2N.c:1770-1773): with equal formats on every hop the hops' memories
+    // are the same bytes, so they are embedded ONCE and every hop reads the one plane (hop stride 0)
+    bool tied = false;
     // parameters on the device
     float *w_q = nullptr, *w_ans = nullptr;
     float *w_a[QMANN_MAX_HOP] = {}, *w_c[QMANN_MAX_HOP] = {};
@@ -53,14 +59,15 @@ bool use_planes(const qmann_model *m, uint32_t max_slots)
 
 int ensure(qmann_model *m, size_t rows, uint32_t n_query, bool planes)
 {
+    const size_t n_plane = m->tied ? 1 : m->H;          // hop planes held
     if (rows > m->cap_rows) {
         const size_t cap = rows + rows / 4;
-        regrow(&m->keys, (size_t)m->H * cap * m->Dp);
-        regrow(&m->vals, (size_t)m->H * cap * m->Dp);
+        regrow(&m->keys, n_plane * cap * m->Dp);
+        regrow(&m->vals, n_plane * cap * m->Dp);
         m->cap_rows = cap;
     }
     if (planes) {
-        const size_t words = (size_t)m->H * m->cap_rows * (m->Dp / 64) * m->net.num_bit;
+        const size_t words = n_plane * m->cap_rows * (m->Dp / 64) * m->net.num_bit;
         if (words > m->cap_plane_words) { regrow(&m->planes, words); m->cap_plane_words = words; }
     }
     if (n_query > m->cap_query) {
@@ -72,15 +79,15 @@ int ensure(qmann_model *m, size_t rows, uint32_t n_query, bool planes)
     return QMANN_OK;
 }
 
-// hops + answer on the memories sitting in the workspace (hop planes rows_total . Dp apart)
+// hops + answer on the memories sitting in the workspace (hop planes rows_total . Dp apart; one shared plane when tied)
 int hops_and_answer(qmann_model *m, uint32_t rows_total, const uint32_t *row_off, uint32_t max_slots, uint32_t n_query,
                     const uint32_t *answer, uint32_t *pred, float *cost, uint32_t *match, void *stream)
 {
-    const size_t hop_stride = (size_t)rows_total * m->Dp;
+    const size_t hop_stride = m->tied ? 0 : (size_t)rows_total * m->Dp;
     int rc;
     if (use_planes(m, max_slots)) {
-        const size_t key_hop_stride = (size_t)rows_total * (m->Dp / 64) * m->net.num_bit * 8;
-        rc = qmann_pack_bitplanes(m->keys, m->planes, (size_t)m->H * rows_total, m->Dp, m->net.num_bit, stream);
+        const size_t key_hop_stride = m->tied ? 0 : (size_t)rows_total * (m->Dp / 64) * m->net.num_bit * 8;
+        rc = qmann_pack_bitplanes(m->keys, m->planes, (size_t)(m->tied ? 1 : m->H) * rows_total, m->Dp, m->net.num_bit, stream);
         if (rc) return rc;
         rc = qmann_hops_packed(&m->net, m->planes, key_hop_stride, m->vals, hop_stride, row_off, max_slots, m->u0, m->u,
                                nullptr, n_query, stream);
@@ -118,6 +125,14 @@ int qmann_model_create(qmann_model **out, const qmann_net *net, const qmann_weig
     m->H = net->n_hop; m->D = net->dim_emb; m->Dp = net->dim_emb_pad; m->V = net->dim_input;
     hipStream_t st = (hipStream_t)stream;
     const size_t DV = (size_t)m->D * m->V, DD = (size_t)m->D * m->D;
+    m->tied = net->n_hop > 1 && !getenv("QMANN_NO_TIED");
+    for (uint32_t h = 1; h < net->n_hop && m->tied; h++) {
+        const qmann_net &e = m->emb_net;
+        m->tied = e.w[h].iwl == e.w[0].iwl && e.w[h].frac == e.w[0].frac && e.att[h].iwl == e.att[0].iwl && e.att[h].frac == e.att[0].frac &&
+                  e.act[h].iwl == e.act[0].iwl && e.act[h].frac == e.act[0].frac &&
+                  memcmp(w->w_a[h], w->w_a[0], DV * sizeof(float)) == 0 && memcmp(w->w_c[h], w->w_c[0], DV * sizeof(float)) == 0;
+    }
+    if (m->tied) m->emb_net.n_hop = 1;       // the embedding kernels fill one plane
     std::vector<float *> staged;             // float copies needed only for the conversion below
     m->w_q = upload(w->w_q, DV, st);
     m->w_ans = upload(w->w_ans, DV, st);

@@ -273,3 +273,42 @@ def test_position_encoding_random_questions(env, V, fmt_w0):
     cfg["fmt_w"] = [fmt_w0] + cfg["fmt_w"][1:]
     cfg.update(en_pe=True, pe_dim_word=9)
     run_both(env, cfg, weights(V, 3, 60, V, 1.5), sw, qw, n_sen, rng.integers(0, V, 300))
+
+
+def tied(wts, H=3):
+    """layer-wise weight tying as the reference trains (TYPE_WEIGHT_TYING 2: hop 0's embedding matrices copied over the
+    other hops', MemN2N.c:1770-1773); lin_map stays per hop"""
+    w = dict(wts)
+    w["w_a"] = [wts["w_a"][0].copy() for _ in range(H)]
+    w["w_c"] = [wts["w_c"][0].copy() for _ in range(H)]
+    return w
+
+
+@pytest.mark.parametrize("mode,nb,slots", [(2, 8, [1, 2, 6, 10, 33, 64]), (3, 8, [1, 5, 50]), (10, 8, [2, 9, 64]), (11, 4, [3, 40]),
+                                           (10, 2, [3, 70, 200]), (11, 4, [65, 130]), (2, 8, [70, 300])])
+def test_tied_hops_share_one_memory_plane(env, mode, nb, slots):
+    """With tied embedding matrices and equal formats on every hop the host model embeds the stories once and every hop
+    reads the one plane (hop stride 0; packed planes built once too): results equal the chain that embeds every hop on its
+    own, bit for bit -- short memories (lean / small kernels) and long ones (streaming kernels, packed planes)."""
+    rng = np.random.default_rng(mode * 10 + nb + len(slots))
+    V, D = 60, 60
+    sw, qw, n_sen = random_stories(rng, 120, V, V - 12, 8, slots)
+    cfg = env.model.babi_cfg(V, attention_mode=mode, D=D, en_mq=False)
+    cfg["num_bit"] = nb
+    run_both(env, cfg, tied(weights(mode + nb, 3, D, V, 1.5)), sw, qw, n_sen, rng.integers(0, V, 120))
+
+
+def test_tied_detection_needs_equal_formats_and_matrices(env, monkeypatch):
+    """EN_MQ formats differ per hop: the memories differ although the matrices are tied, so nothing may be shared (the
+    result must still equal the per-hop chain); and QMANN_NO_TIED switches the sharing off for an A/B."""
+    rng = np.random.default_rng(4)
+    V, D = 40, 60
+    sw, qw, n_sen = random_stories(rng, 100, V, V - 10, 8, [1, 4, 10, 30])
+    wts = tied(weights(8, 3, D, V, 1.5))
+    run_both(env, env.model.babi_cfg(V, attention_mode=2, D=D, en_mq=True), wts, sw, qw, n_sen, rng.integers(0, V, 100))
+    wts2 = tied(weights(8, 3, D, V, 1.5))
+    wts2["w_c"][2][5, 7] += 0.25                                   # one entry apart: not tied
+    cfg = env.model.babi_cfg(V, attention_mode=2, D=D, en_mq=False)
+    run_both(env, cfg, wts2, sw, qw, n_sen, rng.integers(0, V, 100))
+    monkeypatch.setenv("QMANN_NO_TIED", "1")
+    run_both(env, cfg, wts, sw, qw, n_sen, rng.integers(0, V, 100))
