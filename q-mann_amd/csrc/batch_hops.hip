@@ -132,12 +132,19 @@ k_hops_fixed(const HopArgs a)
                     if (a.tap_probs) a.tap_probs[tb + r] = ptab[code + 127];
                 }
             }
-            // rows whose quantised weight is non-zero
-            for (uint32_t r = tid; r < S; r += nthreads) {
-                const uint8_t kp = kplut[(int)sc[r] + 127];
-                if (kp) {
-                    const uint32_t i = atomicAdd(&misc[0], 1u);
-                    if (i < (uint32_t)kLiveCap) { live_row[i] = r; live_kp[i] = kp; }
+            // rows whose quantised weight is non-zero: 16 score bytes per LDS read and their 16 table look-ups in flight
+            // together (one score -> look-up -> branch chain per row left every row two LDS latencies long)
+            for (uint32_t rb = tid * 16; rb < S; rb += nthreads * 16) {
+                const i32x4 v = *(const i32x4 *)(sc + rb);           // (the score array is padded to 16 rows)
+                uint8_t kp[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) kp[i] = kplut[(int)(int8_t)((uint32_t)v[i / 4] >> (8 * (i % 4))) + 127];
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    if (rb + i < S && kp[i]) {
+                        const uint32_t n = atomicAdd(&misc[0], 1u);
+                        if (n < (uint32_t)kLiveCap) { live_row[n] = rb + i; live_kp[n] = kp[i]; }
+                    }
                 }
             }
             __syncthreads();

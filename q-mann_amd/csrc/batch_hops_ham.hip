@@ -144,16 +144,27 @@ k_hops_ham(const HopArgs a, const uint32_t key_row_bytes, const uint32_t lds_slo
                 v0_kp[d] = (uint8_t)qm_code(p, fa.iwl, fa.frac);
             }
             __syncthreads();
-            const size_t tb = (size_t)h * a.rows_total + r0;
-            for (uint32_t r = tid; r < S; r += kBlock) {
-                const int v = sc[r];
-                if (a.tap_codes) a.tap_codes[tb + r] = v;
-                if (a.tap_scores) a.tap_scores[tb + r] = (float)v;
-                if (a.tap_probs) a.tap_probs[tb + r] = v0_p[v];
-                const uint8_t kp = v0_kp[v];
-                if (kp) {
-                    const uint32_t i = atomicAdd(&misc[0], 1u);
-                    if (i < (uint32_t)kLiveCap) { live_row[i] = r; live_kp[i] = kp; }
+            if (a.tap_codes || a.tap_scores || a.tap_probs) {
+                const size_t tb = (size_t)h * a.rows_total + r0;
+                for (uint32_t r = tid; r < S; r += kBlock) {
+                    const int v = sc[r];
+                    if (a.tap_codes) a.tap_codes[tb + r] = v;
+                    if (a.tap_scores) a.tap_scores[tb + r] = (float)v;
+                    if (a.tap_probs) a.tap_probs[tb + r] = v0_p[v];
+                }
+            }
+            // rows whose quantised weight is non-zero: 8 scores per LDS read, their 8 table look-ups in flight together
+            for (uint32_t rb = tid * 8; rb < S; rb += kBlock * 8) {
+                const i32x4 v = *(const i32x4 *)(sc + rb);               // (the score array is padded to 8 rows)
+                uint8_t kp[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) kp[i] = v0_kp[rb + i < S ? ((uint32_t)v[i / 2] >> (16 * (i % 2))) & 0xFFFFu : 0u];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    if (rb + i < S && kp[i]) {
+                        const uint32_t n = atomicAdd(&misc[0], 1u);
+                        if (n < (uint32_t)kLiveCap) { live_row[n] = rb + i; live_kp[n] = kp[i]; }
+                    }
                 }
             }
             __syncthreads();
