@@ -714,6 +714,20 @@ def run_workload(args, name, dev, rank, world):
     survey_bytes = H * S * (key_row_bytes + Dp)
     survey_gbs = survey_bytes * B / (hop_ms * 1e-3) / 1e9
 
+    lean = mode != 1 and S <= 64 and Dp == 64 and planes is None
+    if mode == 1:
+        counted = "keys + values (float read-out streams both)"
+    elif lean:
+        counted = ("key planes only (the algorithmic figure of the long memories); with <= 64 slots most value rows survive "
+                   "Q(p), so this kernel streams the value plane as well: `traffic` is about keys + values")
+    else:
+        counted = "key planes only: Q(p) = 0 for all but <= 2^frac rows, the value plane is not streamed"
+    if wl["ans"] == "i8":
+        answer = {"ms": ans_ms, "int_ops": 2.0 * B * V * D, "tops": 2.0 * B * V * D / (ans_ms * 1e-3) / 1e12,
+                  "mfma_int8_peak_tops": 5000.0}
+    else:
+        answer = {"ms": ans_ms, "kernel": "k_answer_small (float, serial-order sums)" if V <= 256 else "k_answer (float, serial-order sums)",
+                  "flop": 2.0 * B * V * D, "tflops": 2.0 * B * V * D / (ans_ms * 1e-3) / 1e12}
     out = {
         "metric": "queries/sec", "value": world * B * args.steps / elapsed, "unit": "queries/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -723,17 +737,14 @@ def run_workload(args, name, dev, rank, world):
                    "queries_per_gpu": B, "format": "Q5.2", "attention_mode": mode,
                    "key_row_bytes": key_row_bytes, "answer_layer": wl["ans"], "dim_answer": V,
                    "parallelism": f"replicas x{world}, query-sharded"},
-        "roofline": {"bound": "hbm", "kernel": "k_hops_lean" if (mode != 1 and S <= 64 and Dp == 64 and planes is None) else KERNEL_OF_MODE[mode], "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": "k_hops_lean" if lean else KERNEL_OF_MODE[mode], "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes_per_launch": bytes_per_query * B, "bytes_per_query": bytes_per_query,
-                     "bytes_counted": "keys + values (float read-out streams both)" if mode == 1 else
-                                      "key planes only: Q(p) = 0 for all but <= 2^frac rows, the value plane is not streamed",
+                     "bytes_counted": counted,
                      "bytes_per_query_survey_formula": survey_bytes,
                      "frac_by_survey_formula": survey_gbs / HBM_PEAK_GBS,
                      "kernel_ms": hop_ms},
-        "answer_layer": {"ms": ans_ms, "int_ops": 2.0 * B * V * D,
-                         "tops": 2.0 * B * V * D / (ans_ms * 1e-3) / 1e12,
-                         "mfma_int8_peak_tops": 5000.0 if wl["ans"] == "i8" else None},
+        "answer_layer": answer,
     }
     if wl["ans"] == "i8":
         al = out["answer_layer"]
