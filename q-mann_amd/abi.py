@@ -148,6 +148,10 @@ _proto("qmann_weights_save", C.c_int, [C.c_char_p, C.POINTER(Weights), C.POINTER
 _proto("qmann_weights_load", C.c_int, [C.c_char_p, C.POINTER(Weights), C.c_int, C.POINTER(Fmt)])
 
 
+# include/qmann_batch.h return codes
+QMANN_OK, QMANN_EINVAL, QMANN_ERANGE, QMANN_EUNSUPPORTED, QMANN_EIO, QMANN_EHIP = 0, -1, -2, -3, -4, -5
+
+
 def check(rc: int, what: str):
     if rc != 0:
         raise RuntimeError(f"{what} failed with code {rc}")

@@ -1287,7 +1287,7 @@ int qmann_embed_story(const qmann_net *net, const float *story, uint32_t rows_to
                       const float *const *w_c, int8_t *keys, int8_t *vals, size_t hop_stride, void *stream)
 {
     QmBatched qm_scope;
-    if (!net || !story || !w_a || !w_c || !keys || !vals) return QMANN_EINVAL;
+    if (!net || (!story && rows_total) || !w_a || !w_c || !keys || !vals) return QMANN_EINVAL;   // (no rows: no story array needed)
     if (net->n_hop == 0 || net->n_hop > QMANN_MAX_HOP || net->dim_emb > net->dim_emb_pad) return QMANN_EINVAL;
     if (hop_stride < (size_t)rows_total * net->dim_emb_pad) return QMANN_EINVAL;
     EmbedArgs a{};
@@ -1340,7 +1340,7 @@ int qmann_embed_story_idx(const qmann_net *net, const uint16_t *words, uint32_t 
                           size_t hop_stride, void *stream)
 {
     QmBatched qm_scope;
-    if (!net || !words || !t_a || !t_c || !keys || !vals) return QMANN_EINVAL;
+    if (!net || (!words && rows_total) || !t_a || !t_c || !keys || !vals) return QMANN_EINVAL;   // (no rows: no word array needed)
     if (net->n_hop == 0 || net->n_hop > QMANN_MAX_HOP || net->dim_emb > net->dim_emb_pad) return QMANN_EINVAL;
     if (max_words == 0 || max_words > (uint32_t)kMaxWords) return QMANN_ERANGE;
     if (hop_stride < (size_t)rows_total * net->dim_emb_pad) return QMANN_EINVAL;

@@ -60,17 +60,17 @@ bool use_planes(const qmann_model *m, uint32_t max_slots)
 int ensure(qmann_model *m, size_t rows, uint32_t n_query, bool planes)
 {
     const size_t n_plane = m->tied ? 1 : m->H;          // hop planes held
-    if (rows > m->cap_rows) {
-        const size_t cap = rows + rows / 4;
+    if (rows > m->cap_rows || !m->keys) {               // (a first batch may hold no rows at all: the planes still exist)
+        const size_t cap = rows + rows / 4 + 1;
         regrow(&m->keys, n_plane * cap * m->Dp);
         regrow(&m->vals, n_plane * cap * m->Dp);
         m->cap_rows = cap;
     }
     if (planes) {
         const size_t words = n_plane * m->cap_rows * (m->Dp / 64) * m->net.num_bit;
-        if (words > m->cap_plane_words) { regrow(&m->planes, words); m->cap_plane_words = words; }
+        if (words > m->cap_plane_words || !m->planes) { regrow(&m->planes, words); m->cap_plane_words = words; }
     }
-    if (n_query > m->cap_query) {
+    if (n_query > m->cap_query || !m->u0) {
         const size_t cap = (size_t)n_query + n_query / 4;
         regrow(&m->u0, cap * m->D);
         regrow(&m->u, cap * m->D);
@@ -178,8 +178,9 @@ int qmann_model_forward_words(qmann_model *m, const uint16_t *story_words, uint3
                               float *cost, uint32_t *match, void *stream)
 {
     QmBatched qm_scope;
-    if (!m || !story_words || !question_words || !row_off || !pred) return QMANN_EINVAL;
-    if (n_query == 0) return QMANN_OK;
+    if (!m) return QMANN_EINVAL;
+    if (n_query == 0) return QMANN_OK;                  // (an empty batch needs no arrays)
+    if ((!story_words && rows_total) || !question_words || !row_off || !pred) return QMANN_EINVAL;   // (every story may be empty)
     int rc = ensure(m, rows_total, n_query, use_planes(m, max_slots));
     if (rc) return rc;
     rc = qmann_embed_story_idx(&m->emb_net, story_words, rows_total, max_words, 1, m->t_a, m->t_c, m->keys, m->vals,
@@ -196,8 +197,9 @@ int qmann_model_forward_bow(qmann_model *m, const float *story, uint32_t rows_to
                             uint32_t *pred, float *cost, uint32_t *match, void *stream)
 {
     QmBatched qm_scope;
-    if (!m || !story || !question || !row_off || !pred) return QMANN_EINVAL;
+    if (!m) return QMANN_EINVAL;
     if (n_query == 0) return QMANN_OK;
+    if ((!story && rows_total) || !question || !row_off || !pred) return QMANN_EINVAL;
     int rc = ensure(m, rows_total, n_query, use_planes(m, max_slots));
     if (rc) return rc;
     rc = qmann_embed_story(&m->emb_net, story, rows_total, m->w_a, m->w_c, m->keys, m->vals, (size_t)rows_total * m->Dp, stream);

@@ -1,0 +1,126 @@
+"""Edge cases and caller errors of the batched C-ABI: empty batches, stories without sentences, a single query, bounds that
+the kernels cannot serve, null pointers -- a caller error must come back as a QMANN_E* code with nothing launched, never as
+a fault or an exit.  (The reference has no such tests: its host sizes everything from define.h; these are the cases a
+library call has to survive.)"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import load_pkg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    assert torch.cuda.is_available()
+    load_pkg()
+    import qmann_amd.abi as abi
+    import qmann_amd.model as model
+
+    class Env:
+        pass
+    e = Env()
+    e.torch, e.model, e.abi, e.dev = torch, model, abi, torch.device("cuda:0")
+    return e
+
+
+def weights(seed, H, D, V):
+    rng = np.random.default_rng(seed)
+    return {"w_q": rng.normal(0, 1.0, (D, V)).astype(np.float32),
+            "w_a": [rng.normal(0, 1.0, (D, V)).astype(np.float32) for _ in range(H)],
+            "w_c": [rng.normal(0, 1.0, (D, V)).astype(np.float32) for _ in range(H)],
+            "w_h": [rng.normal(0, 1.0, (D, D)).astype(np.float32) for _ in range(H)],
+            "w_ans": rng.normal(0, 0.1, (V, D)).astype(np.float32)}
+
+
+MODES = [(1, 8), (2, 8), (3, 8), (10, 4), (11, 4)]
+
+
+@pytest.mark.parametrize("mode,nb", MODES)
+def test_stories_without_sentences(env, mode, nb):
+    """every story empty: o = 0 in every hop, the state is driven by the linear map alone -- equal to the general chain of
+    kernels, in every attention mode (short-memory and streaming kernels alike see S = 0)"""
+    torch, model = env.torch, env.model
+    V, D, B = 30, 60, 7
+    cfg = model.babi_cfg(V, attention_mode=mode, D=D, en_mq=False)
+    cfg["num_bit"] = nb
+    wts = weights(mode, 3, D, V)
+    qw = np.full((B, 8), 0xFFFF, np.uint16)
+    qw[:, 0] = np.arange(B) % V
+    sw = np.full((1, 8), 0xFFFF, np.uint16)                          # (one dummy row: rows_total = 0 below)
+    row_off = torch.zeros(B + 1, dtype=torch.int32, device=env.dev)
+    hm = model.HostModel(cfg, wts)
+    d_qw = torch.from_numpy(qw.view(np.int16)).to(env.dev)
+    d_sw = torch.from_numpy(sw.view(np.int16)).to(env.dev)[:0]
+    for max_slots in (1, 50, 300):                                   # lean / small / streaming kernels
+        pred, _, _ = hm.forward_words(d_sw, d_qw, row_off, max_slots)
+        torch.cuda.synchronize()
+        u = hm.last_u(B).cpu().numpy()
+        assert np.isfinite(u).all()
+        if max_slots == 1:
+            u_first, p_first = u, pred.cpu().numpy()
+        else:
+            np.testing.assert_array_equal(u, u_first)
+            np.testing.assert_array_equal(pred.cpu().numpy(), p_first)
+    hm.close()
+    # the same through the op-by-op chain
+    net = model.QNet(cfg, wts)
+    ques = np.zeros((B, V), np.float32)
+    ques[np.arange(B), qw[:, 0]] = 1.0
+    keys, vals, u0 = net.embed(torch.zeros((1, V), device=env.dev), torch.from_numpy(ques).to(env.dev))
+    uc = net.hops(keys, vals, row_off, 1, u0, taps=True)[0]
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(u_first, uc.cpu().numpy())
+
+
+def test_empty_batch_and_single_query(env):
+    torch, model = env.torch, env.model
+    V, D = 30, 60
+    cfg = model.babi_cfg(V, attention_mode=2, D=D)
+    hm = model.HostModel(cfg, weights(1, 3, D, V))
+    sw = torch.from_numpy(np.array([[3, 4, 20, 0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF]], np.uint16).view(np.int16)).to(env.dev)
+    qw = torch.from_numpy(np.array([[3, 0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF]], np.uint16).view(np.int16)).to(env.dev)
+    ro = torch.tensor([0, 1], dtype=torch.int32, device=env.dev)
+    pred, _, _ = hm.forward_words(sw, qw, ro, 1)
+    torch.cuda.synchronize()
+    assert 0 <= int(pred[0]) < V
+    pred0, _, _ = hm.forward_words(sw[:0], qw[:0], ro[:1], 1)       # n_query = 0: returns at once
+    assert pred0.numel() == 0
+    hm.close()
+
+
+def test_caller_errors_come_back_as_codes(env):
+    torch, model, abi = env.torch, env.model, env.abi
+    V, D, B, S = 30, 60, 4, 5
+    cfg = model.babi_cfg(V, attention_mode=2, D=D)
+    net = model.QNet(cfg, weights(2, 3, D, V))
+    rows = B * S
+    keys = torch.zeros((3, rows, 64), dtype=torch.int8, device=env.dev)
+    u0 = torch.zeros((B, D), device=env.dev)
+    u1 = torch.zeros_like(u0)
+    ro = (torch.arange(B + 1, dtype=torch.int32, device=env.dev) * S)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    call = lambda net_, k, v, stride, r, ms, a, b, n: abi.lib.qmann_hops_i8(C.byref(net_), k, v, stride, r, ms, a, b, None, n, None)
+    ok = call(net.net, p(keys), p(keys), rows * 64, p(ro), S, p(u0), p(u1), B)
+    assert ok == 0
+    assert call(net.net, None, p(keys), rows * 64, p(ro), S, p(u0), p(u1), B) == abi.QMANN_EINVAL          # null keys
+    assert call(net.net, p(keys), p(keys), rows * 64, p(ro), S, p(u0), p(u1), 1 << 24) == abi.QMANN_ERANGE  # a launch holds < 2^32 threads
+    assert call(net.net, p(keys), p(keys), rows * 64, p(ro), S, p(u0), p(u1), 0) == 0                        # empty batch
+    assert call(net.net, p(keys), p(keys), rows * 64, p(ro), 200000, p(u0), p(u1), B) == abi.QMANN_ERANGE   # scores beyond the LDS
+    bad = abi.Net.from_buffer_copy(bytes(net.net))
+    bad.dim_emb_pad = 96
+    assert call(bad, p(keys), p(keys), rows * 64, p(ro), S, p(u0), p(u1), B) == abi.QMANN_EUNSUPPORTED
+    bad = abi.Net.from_buffer_copy(bytes(net.net))
+    bad.n_hop = 0
+    assert call(bad, p(keys), p(keys), rows * 64, p(ro), S, p(u0), p(u1), B) == abi.QMANN_EINVAL
+    bad = abi.Net.from_buffer_copy(bytes(net.net))
+    bad.dim_emb = 65
+    assert call(bad, p(keys), p(keys), rows * 64, p(ro), S, p(u0), p(u1), B) == abi.QMANN_EINVAL
+    # taps need distinct hop planes
+    taps = abi.Taps(0, 0, 0, u0.data_ptr(), 0)
+    rc = abi.lib.qmann_hops_i8(C.byref(net.net), p(keys), p(keys), 0, p(ro), S, p(u0), p(u1), C.byref(taps), B, None)
+    assert rc == abi.QMANN_EINVAL
+    torch.cuda.synchronize()
