@@ -124,3 +124,43 @@ def test_caller_errors_come_back_as_codes(env):
     rc = abi.lib.qmann_hops_i8(C.byref(net.net), p(keys), p(keys), 0, p(ro), S, p(u0), p(u1), C.byref(taps), B, None)
     assert rc == abi.QMANN_EINVAL
     torch.cuda.synchronize()
+
+
+def test_workspace_regrows_between_batches(env):
+    """the model object keeps a workspace that grows on demand: a small batch, a larger one, a small one again, on a
+    side stream -- every query's result equals the one-shot run's"""
+    torch, model = env.torch, env.model
+    rng = np.random.default_rng(12)
+    V, D, B = 40, 60, 600
+    cfg = model.babi_cfg(V, attention_mode=2, D=D)
+    wts = weights(3, 3, D, V)
+    n_sen = rng.integers(0, 12, B)
+    rows = int(n_sen.sum())
+    sw = np.full((rows, 8), 0xFFFF, np.uint16)
+    for r in range(rows):
+        n = int(rng.integers(1, 7))
+        sw[r, :n] = rng.integers(0, V - 10, n)
+        sw[r, n] = V - 10 + int(rng.integers(0, 10))                 # time entry
+    qw = np.full((B, 8), 0xFFFF, np.uint16)
+    qw[:, :2] = rng.integers(0, V - 10, (B, 2))
+    off = np.concatenate([[0], np.cumsum(n_sen)]).astype(np.int64)
+    dev = env.dev
+
+    def run(hm, q0, q1):
+        ro = torch.from_numpy((off[q0:q1 + 1] - off[q0]).astype(np.int32)).to(dev)
+        s = torch.from_numpy(np.ascontiguousarray(sw[off[q0]:off[q1]]).view(np.int16)).to(dev)
+        q = torch.from_numpy(np.ascontiguousarray(qw[q0:q1]).view(np.int16)).to(dev)
+        pred, _, _ = hm.forward_words(s, q, ro, 16)
+        torch.cuda.synchronize()
+        return pred.cpu().numpy(), hm.last_u(q1 - q0).cpu().numpy()
+
+    hm = model.HostModel(cfg, wts)
+    p_all, u_all = run(hm, 0, B)
+    hm.close()
+    side = torch.cuda.Stream()
+    hm = model.HostModel(cfg, wts, stream=side.cuda_stream)
+    for q0, q1 in ((0, 5), (5, 400), (400, 403), (403, B)):
+        p, u = run(hm, q0, q1)
+        np.testing.assert_array_equal(p, p_all[q0:q1])
+        np.testing.assert_array_equal(u, u_all[q0:q1])
+    hm.close()
