@@ -261,13 +261,14 @@ def run_bow(args, name, wl, net, cfg, wts, dev, rank, world, model):
         sw = torch.from_numpy(np.tile(to_words(g["story"], dd, 8, True), (rep, 1)).view(np.int16)).to(dev)
         qw = torch.from_numpy(np.tile(to_words(g["question"], cfg["dim_input"], 8, False), (rep, 1)).view(np.int16)).to(dev)
         net.make_tables()
-        hm = model.HostModel(cfg, wts, device=str(dev))          # the library's own host object: one call per batch
+    hm = model.HostModel(cfg, wts, device=str(dev))              # the library's own host object: one call per batch
     torch.cuda.synchronize()
 
     def step():
-        if not use_idx:
-            return net.forward_bow(story, ques, row_off, max_slots, answer=ans)
-        pred, cost, match = hm.forward_words(sw, qw, row_off, max_slots, ans)
+        if not use_idx:                                          # float rows in, as the reference's cuda_data_in pools hold them
+            pred, cost, match = hm.forward_bow(story, ques, row_off, max_slots, ans)
+        else:
+            pred, cost, match = hm.forward_words(sw, qw, row_off, max_slots, ans)
         return dict(pred=pred, cost=cost, match=match)
 
     for _ in range(args.warmup):
@@ -301,7 +302,7 @@ def run_bow(args, name, wl, net, cfg, wts, dev, rank, world, model):
         "config": {"workload": name, "slots": "2..10 (mean 5.9)", "dim_emb": 60, "dim_input": cfg["dim_input"],
                    "hops": 3, "queries_per_gpu": B, "format": "Q5.2 + EN_MQ weight formats", "attention_mode": 2,
                    "stages": ("one qmann_model_forward_words call: story embedding (int8 MFMA) + question embedding + hops + answer layer" if use_idx
-                              else "embed_story + embed_query + hops + answer"),
+                              else "one qmann_model_forward_bow call: rows -> word lists on the device (irregular rows redone by the float kernels) + the same stages"),
                    "input": "uint16 word indices" if use_idx else "float bag-of-words",
                    "parallelism": f"replicas x{world}, query-sharded"},
         "roofline": {"bound": "hbm", "kernel": "whole forward (latency bound at these sizes)",

@@ -179,6 +179,22 @@ int qmann_embed_story(const qmann_net *net, const float *story, uint32_t rows_to
 int qmann_embed_query(const qmann_net *net, const float *question, const float *w_q, float *u0,
                       uint32_t n_query, void *stream);
 
+/* Bag-of-words rows -> word lists, for callers that hold the reference's float pools (dev_m_test / dev_q_test,
+ * MemN2N.c:2337-2349) and want the word-index kernels' speed: a row whose non-zero entries are integers 1..16 (counts;
+ * the time entry is a 1) becomes words[row][0..15] (ascending indices, an index repeated by its count, 0xFFFF = unused) --
+ * feed them to qmann_embed_story_idx with max_words = 16 and time_last = 0 (every entry counts), or to
+ * qmann_embed_query_idx.  Any other row (fractional or negative entries such as EN_PE position weights, more than 16 words)
+ * gets an empty list and its index is appended to irregular_rows[(*n_irregular)++] (device memory, capacity `rows`;
+ * *n_irregular is NOT reset here): redo exactly those rows with the float kernels through qmann_embed_story_rows /
+ * qmann_embed_query_rows, which take the list and read its length on the device -- no host round trip. */
+int qmann_bow_to_words(const float *bow, uint32_t rows, uint32_t dim_input, uint16_t *words, uint32_t *irregular_rows,
+                       uint32_t *n_irregular, void *stream);
+int qmann_embed_story_rows(const qmann_net *net, const float *story, uint32_t rows_total, const uint32_t *row_list,
+                           const uint32_t *n_list, const float *const *w_a, const float *const *w_c, int8_t *keys,
+                           int8_t *vals, size_t hop_stride, void *stream);
+int qmann_embed_query_rows(const qmann_net *net, const float *question, const uint32_t *row_list, const uint32_t *n_list,
+                           const float *w_q, float *u0, uint32_t n_query, void *stream);
+
 /* Compact wire format for stories: word indices instead of float bag-of-words
  * rows.  words: uint16 [rows][max_words] (max_words <= 16, unused entries 0xFFFF); with time_last the
  * last valid entry of a row is its time-encoding index (bag-of-words entry SET to 1; word entries

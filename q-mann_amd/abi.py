@@ -138,6 +138,9 @@ _proto("qmann_embed_story_idx", C.c_int, [C.POINTER(Net), _vp, C.c_uint32, C.c_u
                                           C.POINTER(_vp), _vp, _vp, C.c_size_t, _vp])
 _proto("qmann_embed_query_idx", C.c_int, [C.POINTER(Net), _vp, C.c_uint32, _vp, _vp, C.c_uint32, _vp])
 _proto("qmann_embed_query", C.c_int, [C.POINTER(Net), _vp, _vp, _vp, C.c_uint32, _vp])
+_proto("qmann_bow_to_words", C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp])
+_proto("qmann_embed_story_rows", C.c_int, [C.POINTER(Net), _vp, C.c_uint32, _vp, _vp, _vp, _vp, _vp, _vp, C.c_size_t, _vp])
+_proto("qmann_embed_query_rows", C.c_int, [C.POINTER(Net), _vp, _vp, _vp, _vp, _vp, C.c_uint32, _vp])
 _proto("qmann_model_create", C.c_int, [C.POINTER(_vp), C.POINTER(Net), C.POINTER(Weights), _vp])
 _proto("qmann_model_destroy", None, [_vp])
 _proto("qmann_model_forward_words", C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint32, _vp, C.c_uint32,

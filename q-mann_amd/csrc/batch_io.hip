@@ -592,6 +592,8 @@ struct EmbedArgs {
     size_t hop_stride;
     uint32_t n_hop, D, Dp, V, rows;
     QFmt act[QMANN_MAX_HOP], w[QMANN_MAX_HOP], att[QMANN_MAX_HOP];
+    const uint32_t *row_list;     // optional: only these rows (device array; its length is read from *n_list)
+    const uint32_t *n_list;
 };
 
 __global__ void __launch_bounds__(kBlock)
@@ -601,7 +603,9 @@ k_embed_story(const EmbedArgs a)
     __shared__ float nz_val[kMaxNnz];
     __shared__ uint32_t nnz;
     const uint32_t tid = threadIdx.x;
-    for (size_t s = blockIdx.x; s < a.rows; s += gridDim.x) {      // grid-stride over story rows
+    const size_t n_it = a.row_list ? (size_t)*a.n_list : (size_t)a.rows;
+    for (size_t it = blockIdx.x; it < n_it; it += gridDim.x) {     // grid-stride over story rows
+    const size_t s = a.row_list ? (size_t)a.row_list[it] : it;
     const float *x = a.story + s * a.V;
     __syncthreads();
     if (tid == 0) nnz = 0;
@@ -651,14 +655,18 @@ k_embed_story(const EmbedArgs a)
 // Question embedding u0[j] = Qw0( sum_k Qw0( Qw0(W[j][k]) . Qw0(q[k]) ) ) (lib/layer_cuda.cu:49-83 via :3184)
 __global__ void __launch_bounds__(kBlock)
 k_embed_query(const float *__restrict__ question, const float *__restrict__ w_q, float *__restrict__ u0,
-              uint32_t D, uint32_t V, QFmt fw)
+              uint32_t D, uint32_t V, QFmt fw, uint32_t n_query, const uint32_t *__restrict__ row_list,
+              const uint32_t *__restrict__ n_list)
 {
     __shared__ uint32_t nz_idx[kMaxNnz];
     __shared__ float nz_val[kMaxNnz];
     __shared__ uint32_t nnz;
     const uint32_t tid = threadIdx.x;
-    const size_t q = blockIdx.x;
+    const size_t n_it = row_list ? (size_t)*n_list : (size_t)n_query;
+    for (size_t it = blockIdx.x; it < n_it; it += gridDim.x) {     // grid-stride over questions
+    const size_t q = row_list ? (size_t)row_list[it] : it;
     const float *x = question + q * V;
+    __syncthreads();
     if (tid == 0) nnz = 0;
     __syncthreads();
     for (uint32_t k = tid; k < V; k += kBlock) {
@@ -679,6 +687,57 @@ k_embed_query(const float *__restrict__ question, const float *__restrict__ w_q,
             for (uint32_t k = 0; k < V; k++) s += qm_fixed_mul(wr[k], x[k], fw, fw);
         }
         u0[q * D + j] = qm_quant(s, fw.iwl, fw.frac);
+    }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Bag-of-words rows -> word lists.  The reference hands its stories over as float rows of dim_input entries
+// (cuda_data_in pools, MemN2N.c:2337-2349) although sample.c knows every sentence as a handful of word indices; a row
+// whose non-zero entries are small positive integers (counts; the time entry is a 1) IS such a list, and the word-index
+// kernels embed it on the integer / matrix-core path, bit-identical to the float path.  One wavefront per row: the
+// non-zeros are compacted in ascending index order, an index repeated by its count; a row that is not a plain bag of
+// words (fractional or negative entries -- position encoding --, more than 16 words) gets an empty list and is
+// recorded in `irr_rows` for the float kernel to redo.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+k_bow_to_words(const float *__restrict__ bow, uint32_t rows, uint32_t V, uint16_t *__restrict__ words,
+               uint32_t *__restrict__ irr_rows, uint32_t *__restrict__ n_irr)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t buf[kWaves][16];
+    const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    for (size_t r = (size_t)blockIdx.x * kWaves + wave; r < rows; r += (size_t)gridDim.x * kWaves) {
+        if (lane < 16) buf[wave][lane] = 0xFFFFu;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t base = 0;
+        bool bad = false;
+        for (uint32_t c0 = 0; c0 < V; c0 += kWave) {                     // wavefront-uniform
+            const uint32_t k = c0 + lane;
+            const float x = k < V ? bow[r * V + k] : 0.0f;
+            const bool nz = x != 0.0f;                                   // (a NaN is "non-zero" and fails the next test)
+            const int c = (x >= 1.0f && x <= 16.0f) ? (int)x : 0;
+            const bool ok = nz && c > 0 && (float)c == x;
+            bad |= nz && !ok;
+            const uint32_t cnt = ok ? (uint32_t)c : 0u;
+            uint32_t incl = cnt;
+#pragma unroll
+            for (int o = 1; o < kWave; o <<= 1) {
+                const uint32_t t = __shfl_up(incl, o);
+                if (lane >= (uint32_t)o) incl += t;
+            }
+            const uint32_t pos = base + incl - cnt;
+            for (uint32_t t = 0; t < cnt; t++)
+                if (pos + t < 16u) buf[wave][pos + t] = (uint16_t)k;
+            base += __shfl(incl, kWave - 1);
+        }
+        const bool irregular = __any(bad) || base > 16u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < 8) ((uint32_t *)(words + r * 16))[lane] = irregular ? 0xFFFFFFFFu : ((const uint32_t *)buf[wave])[lane];
+        if (irregular && lane == 0) irr_rows[atomicAdd(n_irr, 1u)] = (uint32_t)r;
+        __builtin_amdgcn_wave_barrier();                                 // the next row rewrites the buffer
     }
 }
 
@@ -1283,16 +1342,19 @@ int qmann_answer_i8(const qmann_net *net, const int8_t *w_ans_i8, qmann_fmt w_fm
     return qm_scope.rc();
 }
 
-int qmann_embed_story(const qmann_net *net, const float *story, uint32_t rows_total, const float *const *w_a,
-                      const float *const *w_c, int8_t *keys, int8_t *vals, size_t hop_stride, void *stream)
+static int embed_story_impl(const qmann_net *net, const float *story, uint32_t rows_total, const uint32_t *row_list,
+                            const uint32_t *n_list, const float *const *w_a, const float *const *w_c, int8_t *keys, int8_t *vals,
+                            size_t hop_stride, void *stream)
 {
     QmBatched qm_scope;
     if (!net || (!story && rows_total) || !w_a || !w_c || !keys || !vals) return QMANN_EINVAL;   // (no rows: no story array needed)
+    if ((row_list == nullptr) != (n_list == nullptr)) return QMANN_EINVAL;
     if (net->n_hop == 0 || net->n_hop > QMANN_MAX_HOP || net->dim_emb > net->dim_emb_pad) return QMANN_EINVAL;
     if (hop_stride < (size_t)rows_total * net->dim_emb_pad) return QMANN_EINVAL;
     EmbedArgs a{};
     a.story = story; a.keys = keys; a.vals = vals; a.hop_stride = hop_stride;
     a.n_hop = net->n_hop; a.D = net->dim_emb; a.Dp = net->dim_emb_pad; a.V = net->dim_input; a.rows = rows_total;
+    a.row_list = row_list; a.n_list = n_list;
     for (uint32_t h = 0; h < net->n_hop; h++) {
         if (!w_a[h] || !w_c[h]) return QMANN_EINVAL;
         if (!fmt8(net->act[h]) || !fmt8(net->w[h]) || !fmt8(net->att[h])) return QMANN_ERANGE;
@@ -1302,7 +1364,39 @@ int qmann_embed_story(const qmann_net *net, const float *story, uint32_t rows_to
         a.att[h] = QFmt{net->att[h].iwl, net->att[h].frac};
     }
     if (rows_total == 0) return QMANN_OK;
-    k_embed_story<<<rows_total < (1u << 22) ? rows_total : (1u << 22), kBlock, 0, (hipStream_t)stream>>>(a);
+    // a listed launch does not know the list's length on the host: a fixed grid walks it (and leaves at once if it is empty)
+    const uint32_t grid = row_list ? (rows_total < 4096u ? rows_total : 4096u) : (rows_total < (1u << 22) ? rows_total : (1u << 22));
+    k_embed_story<<<grid, kBlock, 0, (hipStream_t)stream>>>(a);
+    QM_LAUNCH_CHECK();
+    return qm_scope.rc();
+}
+
+int qmann_embed_story(const qmann_net *net, const float *story, uint32_t rows_total, const float *const *w_a,
+                      const float *const *w_c, int8_t *keys, int8_t *vals, size_t hop_stride, void *stream)
+{
+    return embed_story_impl(net, story, rows_total, nullptr, nullptr, w_a, w_c, keys, vals, hop_stride, stream);
+}
+
+int qmann_embed_story_rows(const qmann_net *net, const float *story, uint32_t rows_total, const uint32_t *row_list,
+                           const uint32_t *n_list, const float *const *w_a, const float *const *w_c, int8_t *keys,
+                           int8_t *vals, size_t hop_stride, void *stream)
+{
+    if (!row_list || !n_list) return QMANN_EINVAL;
+    return embed_story_impl(net, story, rows_total, row_list, n_list, w_a, w_c, keys, vals, hop_stride, stream);
+}
+
+static int embed_query_impl(const qmann_net *net, const float *question, const uint32_t *row_list, const uint32_t *n_list,
+                            const float *w_q, float *u0, uint32_t n_query, void *stream)
+{
+    QmBatched qm_scope;
+    if (!net || !question || !w_q || !u0) return QMANN_EINVAL;
+    if ((row_list == nullptr) != (n_list == nullptr)) return QMANN_EINVAL;
+    if (!fmt8(net->w[0])) return QMANN_ERANGE;
+    if (n_query == 0) return QMANN_OK;
+    if (n_query >= (1u << 24)) return QMANN_ERANGE;      // one workgroup per query: a launch holds < 2^32 threads
+    const uint32_t grid = row_list ? (n_query < 4096u ? n_query : 4096u) : n_query;
+    k_embed_query<<<grid, kBlock, 0, (hipStream_t)stream>>>(question, w_q, u0, net->dim_emb, net->dim_input,
+                                                           QFmt{net->w[0].iwl, net->w[0].frac}, n_query, row_list, n_list);
     QM_LAUNCH_CHECK();
     return qm_scope.rc();
 }
@@ -1310,13 +1404,25 @@ int qmann_embed_story(const qmann_net *net, const float *story, uint32_t rows_to
 int qmann_embed_query(const qmann_net *net, const float *question, const float *w_q, float *u0, uint32_t n_query,
                       void *stream)
 {
+    return embed_query_impl(net, question, nullptr, nullptr, w_q, u0, n_query, stream);
+}
+
+int qmann_embed_query_rows(const qmann_net *net, const float *question, const uint32_t *row_list, const uint32_t *n_list,
+                           const float *w_q, float *u0, uint32_t n_query, void *stream)
+{
+    if (!row_list || !n_list) return QMANN_EINVAL;
+    return embed_query_impl(net, question, row_list, n_list, w_q, u0, n_query, stream);
+}
+
+int qmann_bow_to_words(const float *bow, uint32_t rows, uint32_t dim_input, uint16_t *words, uint32_t *irregular_rows,
+                       uint32_t *n_irregular, void *stream)
+{
     QmBatched qm_scope;
-    if (!net || !question || !w_q || !u0) return QMANN_EINVAL;
-    if (!fmt8(net->w[0])) return QMANN_ERANGE;
-    if (n_query == 0) return QMANN_OK;
-    if (n_query >= (1u << 24)) return QMANN_ERANGE;      // one workgroup per query: a launch holds < 2^32 threads
-    k_embed_query<<<n_query, kBlock, 0, (hipStream_t)stream>>>(question, w_q, u0, net->dim_emb, net->dim_input,
-                                                             QFmt{net->w[0].iwl, net->w[0].frac});
+    if ((!bow && rows) || !words || !irregular_rows || !n_irregular) return QMANN_EINVAL;
+    if (dim_input == 0 || dim_input >= 0xFFFFu) return QMANN_ERANGE;          // 0xFFFF marks an unused slot
+    if (rows == 0) return QMANN_OK;
+    const uint32_t need = (rows + kWaves - 1) / kWaves;
+    k_bow_to_words<<<need < 16384u ? need : 16384u, kBlock, 0, (hipStream_t)stream>>>(bow, rows, dim_input, words, irregular_rows, n_irregular);
     QM_LAUNCH_CHECK();
     return qm_scope.rc();
 }

@@ -26,7 +26,10 @@ struct qmann_model {
     int8_t *keys = nullptr, *vals = nullptr;
     uint64_t *planes = nullptr;
     float *u0 = nullptr, *u = nullptr;
-    size_t cap_rows = 0, cap_plane_words = 0, cap_query = 0;
+    // bag-of-words input: word lists made from the rows, the rows that are no plain bags of words, two counters
+    uint16_t *bow_words = nullptr;
+    uint32_t *bow_irr = nullptr;
+    size_t cap_rows = 0, cap_plane_words = 0, cap_query = 0, cap_bow = 0;
 };
 
 namespace {
@@ -168,7 +171,7 @@ void qmann_model_destroy(qmann_model *m)
     auto drop = [](void *p) { if (p) QM_HIP(hipFree(p)); };
     drop(m->w_q); drop(m->w_ans); drop(m->t_q);
     for (uint32_t h = 0; h < QMANN_MAX_HOP; h++) { drop(m->w_a[h]); drop(m->w_c[h]); drop(m->lin_map[h]); drop(m->t_a[h]); drop(m->t_c[h]); }
-    drop(m->keys); drop(m->vals); drop(m->planes); drop(m->u0); drop(m->u);
+    drop(m->keys); drop(m->vals); drop(m->planes); drop(m->u0); drop(m->u); drop(m->bow_words); drop(m->bow_irr);
     delete m;
 }
 
@@ -202,9 +205,34 @@ int qmann_model_forward_bow(qmann_model *m, const float *story, uint32_t rows_to
     if ((!story && rows_total) || !question || !row_off || !pred) return QMANN_EINVAL;
     int rc = ensure(m, rows_total, n_query, use_planes(m, max_slots));
     if (rc) return rc;
-    rc = qmann_embed_story(&m->emb_net, story, rows_total, m->w_a, m->w_c, m->keys, m->vals, (size_t)rows_total * m->Dp, stream);
+    // Rows that are plain bags of words (integer counts) go through the word-index kernels -- the int8 gather / matrix-core
+    // path, bit-identical to the float path and several times faster; the others (fractional entries: position encoding,
+    // long rows) are listed on the device and redone by the float kernels.  No host round trip.
+    const size_t n_all = (size_t)rows_total + n_query;
+    if (n_all > m->cap_bow || !m->bow_words) {
+        const size_t cap = n_all + n_all / 4 + 1;
+        regrow(&m->bow_words, cap * 16);
+        regrow(&m->bow_irr, cap + 2);
+        m->cap_bow = cap;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t *n_irr = m->bow_irr, *irr_s = m->bow_irr + 2, *irr_q = irr_s + rows_total;
+    uint16_t *sw = m->bow_words, *qw = m->bow_words + (size_t)rows_total * 16;
+    QM_HIP(hipMemsetAsync(n_irr, 0, 2 * sizeof(uint32_t), st));
+    rc = qmann_bow_to_words(story, rows_total, m->V, sw, irr_s, n_irr, stream);
     if (rc) return rc;
-    rc = qmann_embed_query(&m->net, question, m->w_q, m->u0, n_query, stream);
+    rc = qmann_bow_to_words(question, n_query, m->V, qw, irr_q, n_irr + 1, stream);
+    if (rc) return rc;
+    const size_t hop_stride = (size_t)rows_total * m->Dp;
+    rc = qmann_embed_story_idx(&m->emb_net, sw, rows_total, 16, /*time_last=*/0, m->t_a, m->t_c, m->keys, m->vals, hop_stride, stream);
+    if (rc) return rc;
+    rc = qmann_embed_story_rows(&m->emb_net, story, rows_total, irr_s, n_irr, m->w_a, m->w_c, m->keys, m->vals, hop_stride, stream);
+    if (rc) return rc;
+    qmann_net qnet = m->net;
+    qnet.en_pe = 0;                                     // (position weights, if any, are IN the rows: such rows take the float kernel)
+    rc = qmann_embed_query_idx(&qnet, qw, 16, m->t_q, m->u0, n_query, stream);
+    if (rc) return rc;
+    rc = qmann_embed_query_rows(&m->net, question, irr_q, n_irr + 1, m->w_q, m->u0, n_query, stream);
     if (rc) return rc;
     rc = hops_and_answer(m, rows_total, row_off, max_slots, n_query, answer, pred, cost, match, stream);
     return rc ? rc : qm_scope.rc();

@@ -312,3 +312,90 @@ def test_tied_detection_needs_equal_formats_and_matrices(env, monkeypatch):
     run_both(env, cfg, wts2, sw, qw, n_sen, rng.integers(0, V, 100))
     monkeypatch.setenv("QMANN_NO_TIED", "1")
     run_both(env, cfg, wts, sw, qw, n_sen, rng.integers(0, V, 100))
+
+
+def bow_chain(env, cfg, wts, story, ques, n_sen, ans, ms):
+    """the op-by-op chain on float bag-of-words rows: k_embed_story / k_embed_query, the general hop kernel, the answer layer"""
+    torch, model = env.torch, env.model
+    net = model.QNet(cfg, wts, device="cuda:0")
+    row_off = np.concatenate([[0], np.cumsum(n_sen)]).astype(np.int32)
+    keys, vals, u0 = net.embed(torch.from_numpy(story).to(env.dev), torch.from_numpy(ques).to(env.dev))
+    u, _ = net.hops(keys, vals, torch.from_numpy(row_off).to(env.dev), ms, u0, taps=True)
+    p, _, c, m = net.answer(u, torch.from_numpy(ans.astype(np.int32)).to(env.dev))
+    torch.cuda.synchronize()
+    return p.cpu().numpy(), u.cpu().numpy(), float(c.item()), int(m.item())
+
+
+@pytest.mark.parametrize("mode,nb,V", [(2, 8, 40), (10, 4, 40), (2, 8, 300), (1, 8, 40), (3, 8, 238)])
+def test_forward_from_bag_of_words_rows(env, mode, nb, V):
+    """qmann_model_forward_bow turns the rows that are plain bags of words into word lists on the device and embeds them
+    on the integer path; rows that are not -- fractional / negative entries, a count above 16, more than 16 words -- are
+    listed and redone by the float kernels.  A batch that mixes all of them must equal the float chain bit for bit."""
+    torch, model = env.torch, env.model
+    rng = np.random.default_rng(V + mode)
+    D, B = 60, 160
+    dd = V - 12
+    sw, qw, n_sen = random_stories(rng, B, V, dd, 8, [0, 1, 3, 9, 20, 50])
+    story = words_to_bow(sw, V, True)
+    ques = words_to_bow(qw, V, False)
+    rows = story.shape[0]
+    # irregular rows: position-encoding-like fractions, a negative entry, a count of 17, 20 different words
+    for r in range(0, rows, 7):
+        story[r, rng.integers(0, dd)] = np.float32(1.0 + 0.25 * rng.integers(1, 4))
+    for r in range(3, rows, 31):
+        story[r, rng.integers(0, dd)] = -1.0
+    for r in range(5, rows, 37):
+        story[r, rng.integers(0, dd)] = 17.0
+    for r in range(11, rows, 41):
+        story[r, rng.choice(dd, 20, replace=False)] = 1.0
+    for r in range(2, rows, 13):
+        story[r, 1] = 3.0                                              # a regular row with a repeated word
+    for q in range(0, B, 5):
+        ques[q, rng.integers(0, dd)] = np.float32(0.5)
+    for q in range(1, B, 9):
+        ques[q, 2] = 2.0
+    cfg = model.babi_cfg(V, attention_mode=mode, D=D, en_mq=(mode == 2))
+    cfg["num_bit"] = nb
+    wts = weights(V + 3, 3, D, V, 1.5)
+    ans = rng.integers(0, V, B)
+    ms = int(n_sen.max())
+    hm = model.HostModel(cfg, wts, device="cuda:0")
+    row_off = np.concatenate([[0], np.cumsum(n_sen)]).astype(np.int32)
+    pred, cost, match = hm.forward_bow(torch.from_numpy(story).to(env.dev), torch.from_numpy(ques).to(env.dev),
+                                       torch.from_numpy(row_off).to(env.dev), ms, torch.from_numpy(ans.astype(np.int32)).to(env.dev))
+    torch.cuda.synchronize()
+    u = hm.last_u(B).cpu().numpy()
+    hm.close()
+    p2, u2, c2, m2 = bow_chain(env, cfg, wts, story, ques, n_sen, ans, ms)
+    bad = np.flatnonzero((u != u2).any(1))
+    assert bad.size == 0, f"final hop state differs for {bad.size} of {B} queries, first {bad[:5]}"
+    np.testing.assert_array_equal(pred.cpu().numpy(), p2)
+    assert int(match.item()) == m2
+    assert float(cost.item()) == pytest.approx(c2, rel=1e-4, abs=1e-3)
+
+
+def test_bow_to_words_lists(env):
+    """the conversion on its own: ascending indices, an index repeated by its count, 0xFFFF padding; irregular rows listed"""
+    import ctypes as C
+    torch = env.torch
+    import qmann_amd.abi as abi
+    V = 70
+    bow = np.zeros((6, V), np.float32)
+    bow[0, [3, 9, 64]] = [1, 2, 1]                                     # regular: 3, 9, 9, 64
+    bow[1, 5] = 0.5                                                    # fraction
+    bow[2, :17] = 1.0                                                  # 17 words
+    bow[3, 69] = 16.0                                                  # 16 times the last index: fills the list
+    bow[4, 8] = -2.0                                                   # negative
+    d = torch.from_numpy(bow).to(env.dev)
+    words = torch.zeros((6, 16), dtype=torch.int16, device=env.dev)
+    irr = torch.zeros(6, dtype=torch.int32, device=env.dev)
+    n = torch.zeros(1, dtype=torch.int32, device=env.dev)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    assert abi.lib.qmann_bow_to_words(p(d), 6, V, p(words), p(irr), p(n), None) == 0
+    torch.cuda.synchronize()
+    w = words.cpu().numpy().view(np.uint16)
+    assert list(w[0][:4]) == [3, 9, 9, 64] and (w[0][4:] == 0xFFFF).all()
+    assert (w[3] == 69).all()
+    assert (w[5] == 0xFFFF).all()                                      # an empty row is a regular, empty list
+    assert sorted(irr.cpu().numpy()[:int(n.item())].tolist()) == [1, 2, 4]
+    assert (w[[1, 2, 4]] == 0xFFFF).all()
