@@ -10,3 +10,4 @@ timeout -k 10 300 bash tools/collect_profiles.sh r02_idx babi_task1_idx
 timeout -k 10 300 bash tools/collect_profiles.sh r02_j20v1 babi_joint20_v1
 timeout -k 10 300 bash tools/collect_profiles.sh r02_j20fx babi_joint20_fixed
 timeout -k 10 300 bash tools/collect_profiles.sh r02_j20tied babi_joint20_v1_tied
+timeout -k 10 300 bash tools/collect_profiles.sh r02_bow babi_task1_bow
