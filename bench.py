@@ -59,6 +59,9 @@ WORKLOADS = {
     "synth10k_d256_ham_v4096": dict(S=10000, D=256, V=4096, B=8192, mode=10, nb=1, ans="i8", sk=30.0, sv=30.0, su=30.0),
     "synth10k_d128_appx": dict(S=10000, D=128, V=256, B=8192, mode=3, nb=8, ans="f32", sk=30.0, sv=30.0, su=30.0),
     "synth10k_d128_float": dict(S=10000, D=128, V=256, B=4096, mode=1, nb=8, ans="f32", sk=3.5, sv=30.0, su=3.5),
+    # between the bAbI cap and the long memories: the one-wavefront-workgroup form of the streaming kernel (65..256 slots)
+    "synth200_d64": dict(S=200, D=60, V=80, B=131072, mode=2, nb=8, ans="f32", sk=8.0, sv=30.0, su=8.0),
+    "synth1000_d64": dict(S=1000, D=60, V=80, B=32768, mode=2, nb=8, ans="f32", sk=8.0, sv=30.0, su=8.0),
     "babi_mem50": dict(S=50, D=60, V=80, B=262144, mode=2, nb=8, ans="f32", sk=8.0, sv=30.0, su=8.0),
     "babi_joint_appx": dict(S=50, D=60, V=256, B=262144, mode=3, nb=8, ans="f32", sk=30.0, sv=30.0, su=30.0),
     # BASELINE.json configs[2] shape with the CPU-spec weighted Hamming score on packed bit planes + popcount
