@@ -151,6 +151,36 @@ _proto("qmann_weights_save", C.c_int, [C.c_char_p, C.POINTER(Weights), C.POINTER
 _proto("qmann_weights_load", C.c_int, [C.c_char_p, C.POINTER(Weights), C.c_int, C.POINTER(Fmt)])
 
 
+class Dataset(C.Structure):
+    """include/qmann_dataset.h"""
+    _fields_ = [("n_query", C.c_uint32), ("rows_total", C.c_uint32), ("max_words", C.c_uint32), ("max_q_words", C.c_uint32),
+                ("dim_dict", C.c_uint32), ("dim_input", C.c_uint32), ("max_line", C.c_uint32), ("dim_word", C.c_uint32),
+                ("row_off", C.POINTER(C.c_uint32)), ("story_words", C.POINTER(C.c_uint16)),
+                ("question_words", C.POINTER(C.c_uint16)), ("answer", C.POINTER(C.c_uint32))]
+
+
+_proto("qmann_dataset_load", C.c_int, [C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(Dataset)])
+_proto("qmann_dataset_free", None, [C.POINTER(Dataset)])
+
+
+def load_dataset(train_path, test_path, max_sen_len=50, n_train_cap=0, n_test_cap=0):
+    """qmann_dataset_load -> dict of numpy arrays (copies; the C arrays are released)."""
+    import numpy as np
+    ds = Dataset()
+    check(lib.qmann_dataset_load(str(train_path).encode(), str(test_path).encode(), max_sen_len, n_train_cap, n_test_cap,
+                                 C.byref(ds)), "qmann_dataset_load")
+    try:
+        nq, rows = ds.n_query, ds.rows_total
+        out = dict(n_query=nq, rows_total=rows, dim_dict=ds.dim_dict, dim_input=ds.dim_input, max_line=ds.max_line, dim_word=ds.dim_word,
+                   row_off=np.ctypeslib.as_array(ds.row_off, (nq + 1,)).copy(),
+                   story_words=np.ctypeslib.as_array(ds.story_words, (max(rows, 1), ds.max_words))[:rows].copy(),
+                   question_words=np.ctypeslib.as_array(ds.question_words, (max(nq, 1), ds.max_q_words))[:nq].copy(),
+                   answer=np.ctypeslib.as_array(ds.answer, (max(nq, 1),))[:nq].copy())
+    finally:
+        lib.qmann_dataset_free(C.byref(ds))
+    return out
+
+
 # include/qmann_batch.h return codes
 QMANN_OK, QMANN_EINVAL, QMANN_ERANGE, QMANN_EUNSUPPORTED, QMANN_EIO, QMANN_EHIP = 0, -1, -2, -3, -4, -5
 

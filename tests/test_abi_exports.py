@@ -21,7 +21,8 @@ def test_library_loads_and_reports_66(abi):
 
 def test_every_declared_symbol_is_exported(abi):
     declared = (abi.header_symbols("qmann_abi.h") + abi.header_symbols("qmann_batch.h")
-                + abi.header_symbols("qmann_weights.h") + abi.header_symbols("qmann_model.h"))
+                + abi.header_symbols("qmann_weights.h") + abi.header_symbols("qmann_model.h")
+                + abi.header_symbols("qmann_dataset.h"))
     assert "qmann_weights_save" in declared and "qmann_weights_load" in declared
     assert "qmann_model_create" in declared and "qmann_model_forward_words" in declared
     cuda = [s for s in declared if s.startswith("cuda_")]
@@ -35,7 +36,8 @@ def test_symbols_are_unmangled_c(abi):
                          check=True).stdout
     names = {l.split()[-1] for l in out.splitlines() if " T " in l}
     for s in (abi.header_symbols("qmann_abi.h") + abi.header_symbols("qmann_batch.h")
-              + abi.header_symbols("qmann_weights.h") + abi.header_symbols("qmann_model.h")):
+              + abi.header_symbols("qmann_weights.h") + abi.header_symbols("qmann_model.h")
+                + abi.header_symbols("qmann_dataset.h")):
         assert s in names, s
 
 

@@ -15,7 +15,7 @@ LINK = ["-L", str(ROOT / "q-mann_amd" / "lib"), "-lqmann_hip", "-L/opt/rocm/lib"
 
 def test_headers_are_strict_c99(tmp_path):
     src = tmp_path / "hdr.c"
-    src.write_text('#include "qmann_abi.h"\n#include "qmann_batch.h"\n#include "qmann_weights.h"\n#include "qmann_model.h"\n'
+    src.write_text('#include "qmann_abi.h"\n#include "qmann_batch.h"\n#include "qmann_weights.h"\n#include "qmann_model.h"\n#include "qmann_dataset.h"\n'
                    "int main(void) { qmann_net n = {0}; qmann_weights w = {0}; (void)n; (void)w; return (int)sizeof(qmann_taps) * 0; }\n")
     r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", *INC, "-fsyntax-only", str(src)],
                        capture_output=True, text=True)
