@@ -399,3 +399,31 @@ def test_bow_to_words_lists(env):
     assert (w[5] == 0xFFFF).all()                                      # an empty row is a regular, empty list
     assert sorted(irr.cpu().numpy()[:int(n.item())].tolist()) == [1, 2, 4]
     assert (w[[1, 2, 4]] == 0xFFFF).all()
+
+
+def test_record_file_to_predictions(env, tmp_path):
+    """include/qmann_dataset.h end to end: a record file in the reference's format -> word lists -> the forward; equal to the
+    float bag-of-words chain on the rows the lists stand for"""
+    import qmann_amd.abi as abi
+    rng = np.random.default_rng(31)
+    vocab = [f"w{i}" for i in range(25)]
+
+    def records(n):
+        out = []
+        for _ in range(n):
+            sens = [" ".join(rng.choice(vocab, rng.integers(1, 7))) for _ in range(rng.integers(1, 12))]
+            out.append((sens, " ".join(rng.choice(vocab, 3)), str(rng.choice(vocab))))
+        return out
+
+    def write_set(path, recs):
+        lines = ["", "+NS+", str(len(recs)), ""]
+        for i, (sens, q, a) in enumerate(recs):
+            lines += ["+I+", str(i), "+S+", str(len(sens))] + [s + " " for s in sens] + ["+Q+", q + " ", "+A+", a, ""]
+        path.write_text("\n".join(lines) + "\n")
+    write_set(tmp_path / "train", records(300)); write_set(tmp_path / "test", records(150))
+    ds = abi.load_dataset(tmp_path / "train", tmp_path / "test", 50)
+    V = ds["dim_input"]
+    n_sen = np.diff(ds["row_off"].astype(np.int64))
+    cfg = env.model.babi_cfg(V, attention_mode=2, D=60)
+    ans = np.where(ds["answer"] == 0xFFFFFFFF, 0xFFFF, ds["answer"]).astype(np.int64)
+    run_both(env, cfg, weights(5, 3, 60, V, 1.5), ds["story_words"], ds["question_words"], n_sen, ans)
