@@ -326,8 +326,9 @@ def bow_chain(env, cfg, wts, story, ques, n_sen, ans, ms):
     return p.cpu().numpy(), u.cpu().numpy(), float(c.item()), int(m.item())
 
 
-@pytest.mark.parametrize("mode,nb,V", [(2, 8, 40), (10, 4, 40), (2, 8, 300), (1, 8, 40), (3, 8, 238)])
-def test_forward_from_bag_of_words_rows(env, mode, nb, V):
+@pytest.mark.parametrize("mode,nb,V,tie", [(2, 8, 40, False), (10, 4, 40, False), (2, 8, 300, False), (1, 8, 40, False), (3, 8, 238, False),
+                                            (11, 8, 40, True), (10, 2, 70, True)])
+def test_forward_from_bag_of_words_rows(env, mode, nb, V, tie):
     """qmann_model_forward_bow turns the rows that are plain bags of words into word lists on the device and embeds them
     on the integer path; rows that are not -- fractional / negative entries, a count above 16, more than 16 words -- are
     listed and redone by the float kernels.  A batch that mixes all of them must equal the float chain bit for bit."""
@@ -357,6 +358,8 @@ def test_forward_from_bag_of_words_rows(env, mode, nb, V):
     cfg = model.babi_cfg(V, attention_mode=mode, D=D, en_mq=(mode == 2))
     cfg["num_bit"] = nb
     wts = weights(V + 3, 3, D, V, 1.5)
+    if tie:                                                            # tied hops: one memory plane, also from float rows
+        wts = tied(wts)
     ans = rng.integers(0, V, B)
     ms = int(n_sen.max())
     hm = model.HostModel(cfg, wts, device="cuda:0")
