@@ -57,6 +57,9 @@ WORKLOADS = {
     "synth10k_d256_ham": dict(S=10000, D=256, V=256, B=8192, mode=10, nb=1, ans="i8", sk=30.0, sv=30.0, su=30.0),
     # config 5 with the larger of its two dictionary sizes (V in {256, 4 096}): the int8 MFMA projection is 17 GOP
     "synth10k_d256_ham_v4096": dict(S=10000, D=256, V=4096, B=8192, mode=10, nb=1, ans="i8", sk=30.0, sv=30.0, su=30.0),
+    # config 5's other form ("also n = 8 bit-planes"): 8-bit codes, weighted Hamming V1 / plain V0, straight from the int8 keys
+    "synth10k_d256_v1_nb8": dict(S=10000, D=256, V=256, B=4096, mode=11, nb=8, ans="i8", sk=30.0, sv=30.0, su=30.0),
+    "synth10k_d256_v0_nb8": dict(S=10000, D=256, V=256, B=4096, mode=10, nb=8, ans="i8", sk=30.0, sv=30.0, su=30.0),
     "synth10k_d128_appx": dict(S=10000, D=128, V=256, B=8192, mode=3, nb=8, ans="f32", sk=30.0, sv=30.0, su=30.0),
     "synth10k_d128_float": dict(S=10000, D=128, V=256, B=4096, mode=1, nb=8, ans="f32", sk=3.5, sv=30.0, su=3.5),
     # between the bAbI cap and the long memories: the one-wavefront-workgroup form of the streaming kernel (65..256 slots)
@@ -656,9 +659,9 @@ def run_workload(args, name, dev, rank, world):
     u_out = torch.empty_like(u0)
     key_row_bytes = Dp
     planes = None
-    if mode in (10, 11):
+    if mode in (10, 11) and nb < 8:
         planes = net.pack_planes(keys, nb)      # packed binary codes: [H][rows][Dp/64][nb] uint64
-        key_row_bytes = Dp // 64 * nb * 8
+        key_row_bytes = Dp // 64 * nb * 8       # (8-bit codes: planes would be no smaller than the bytes, the kernel reads the int8 keys)
     torch.cuda.synchronize()
 
     def run_hops():
