@@ -91,3 +91,64 @@ def test_example_host_runs_and_matches_the_oracle(tmp_path, gold, oracle):
     assert checked >= nq - 2
     assert match == int((pred == ans).sum())
     assert cost == pytest.approx(want_cost, rel=1e-4)
+
+
+def write_set(path, records):
+    out = ["", "+NS+", str(len(records)), ""]
+    for i, (sens, q, a) in enumerate(records):
+        out += ["+I+", str(i), "+S+", str(len(sens))] + [x + " " for x in sens] + ["+Q+", q + " ", "+A+", a, ""]
+    path.write_text("\n".join(out) + "\n")
+
+
+def test_dataset_example_compiles(tmp_path):
+    load_pkg()
+    exe = tmp_path / "forward_dataset"
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", *INC, "-I/opt/rocm/include", str(ROOT / "examples" / "forward_dataset.c"),
+                        *LINK, "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_dataset_example_from_record_files_to_predictions(tmp_path, oracle):
+    """examples/forward_dataset.c: record files + weight files in, predictions out -- equal to the Python plumbing on the
+    same inputs (which the other tests tie to the oracle)"""
+    load_pkg()
+    import torch
+    import qmann_amd.abi as abi
+    import qmann_amd.model as model
+    exe = tmp_path / "forward_dataset"
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", *INC, "-I/opt/rocm/include", str(ROOT / "examples" / "forward_dataset.c"),
+                        *LINK, "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rng = np.random.default_rng(3)
+    vocab = [f"w{i}" for i in range(20)]
+    recs = lambda n: [([" ".join(rng.choice(vocab, rng.integers(1, 6))) for _ in range(rng.integers(1, 9))],
+                       " ".join(rng.choice(vocab, 2)), str(rng.choice(vocab))) for _ in range(n)]
+    write_set(tmp_path / "train", recs(200)); write_set(tmp_path / "test", recs(90))
+    ds = abi.load_dataset(tmp_path / "train", tmp_path / "test", 50)
+    V, D, H, iwl = ds["dim_input"], 60, 3, 5
+    cfg = model.babi_cfg(V, 2, 0, iwl=iwl)
+    wts = {"w_q": rng.normal(0, 0.8, (D, V)).astype(np.float32), "w_ans": rng.normal(0, 0.1, (V, D)).astype(np.float32),
+           "w_a": [rng.normal(0, 0.8, (D, V)).astype(np.float32) for _ in range(H)],
+           "w_c": [rng.normal(0, 0.8, (D, V)).astype(np.float32) for _ in range(H)],
+           "w_h": [rng.normal(0, 1.0, (D, D)).astype(np.float32) for _ in range(H)]}
+    wdir = tmp_path / "weights"; wdir.mkdir()
+    model.save_weights(wdir, wts, cfg, fixed=False)
+    r = subprocess.run([str(exe), str(tmp_path / "train"), str(tmp_path / "test"), str(wdir), str(iwl), str(tmp_path / "pred.bin")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    nq = ds["n_query"]
+    raw = (tmp_path / "pred.bin").read_bytes()
+    pred = np.frombuffer(raw[:4 * nq], np.uint32)
+    match = struct.unpack("<I", raw[4 * nq:4 * nq + 4])[0]
+    dev = torch.device("cuda:0")
+    hm = model.HostModel(cfg, wts)
+    n_sen = np.diff(ds["row_off"].astype(np.int64))
+    p2, _, m2 = hm.forward_words(torch.from_numpy(ds["story_words"].view(np.int16)).to(dev),
+                                 torch.from_numpy(ds["question_words"].view(np.int16)).to(dev),
+                                 torch.from_numpy(ds["row_off"].astype(np.int32)).to(dev), int(n_sen.max()),
+                                 torch.from_numpy(ds["answer"].astype(np.int64).astype(np.int32)).to(dev))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(pred, p2.cpu().numpy().astype(np.uint32))
+    assert match == int(m2.item())
+    hm.close()
