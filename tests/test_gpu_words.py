@@ -147,6 +147,7 @@ def oracle_sample(oracle, cfg, wts, sw, qw, n_sen, pred, u, pick):
             near |= bool(((np.abs(x - k) <= 1e-5 * np.maximum(1.0, np.abs(x))) & (k > 0)).any())
         assert near, f"story {i}: final state differs from the oracle's"
         excused += 1
+    print(f"oracle sample: {excused} of {len(pick)} stories excused (p on a truncation step)")
     assert excused <= max(2, len(pick) // 8), f"{excused} of {len(pick)} stories hit the p-on-a-step exclusion"
 
 
@@ -161,7 +162,7 @@ def test_full_qa1_test_set(env, oracle, mode, nb):
     cfg["num_bit"] = nb
     wts = weights(11, 3, 60, V)
     pred, u = run_both(env, cfg, wts, sw, qw, n_sen, ans)
-    oracle_sample(oracle, cfg, wts, sw, qw, n_sen, pred, u, list(range(0, 1000, 25)))
+    oracle_sample(oracle, cfg, wts, sw, qw, n_sen, pred, u, list(range(0, 1000, 5)))
 
 
 @pytest.mark.parametrize("mode,nb", [(11, 8), (10, 8), (3, 8), (2, 8)])
@@ -176,7 +177,7 @@ def test_full_joint_test_set(env, oracle, mode, nb):
     cfg["num_bit"] = nb
     wts = weights(12, 3, 60, V)
     pred, u = run_both(env, cfg, wts, sw, qw, n_sen, ans)
-    oracle_sample(oracle, cfg, wts, sw, qw, n_sen, pred, u, list(range(7, 20000, 400)))
+    oracle_sample(oracle, cfg, wts, sw, qw, n_sen, pred, u, list(range(7, 20000, 100)))
 
 
 def random_stories(rng, B, V, dd, W, S_list, dup_every=3):
