@@ -45,13 +45,27 @@ template <typename F> double timeit(F f, int reps)
     for (int r = 0; r < reps; r++) { CK(hipEventRecord(a)); f(); CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); float ms; CK(hipEventElapsedTime(&ms, a, b)); t.push_back(ms); }
     std::sort(t.begin(), t.end()); return t[t.size() / 2];
 }
-int main()
+int main(int argc, char **argv)
 {
     const size_t bytes = (size_t)24 << 30; const size_t n_vec = bytes / 16;
     i32x4 *src; int *out; CK(hipMalloc(&src, bytes)); CK(hipMalloc(&out, 4)); CK(hipMemset(src, 1, bytes));
     const size_t chunk = 1280000 / 16;    // one key plane of one query
     const int nblk = (int)(n_vec / chunk);
     printf("buffer %.1f GB, %d chunks of 1.28 MB\n", bytes / 1e9, nblk);
+    if (argc > 1) {
+        // "sustained": the best shape 60 times back to back -- does the read ceiling itself sag the way the hop kernel's rate does?
+        std::vector<float> t;
+        hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+        for (int r = 0; r < 60; r++) {
+            CK(hipEventRecord(a)); k_chunk<8, true><<<nblk, 256>>>(src, chunk, out); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+            float ms; CK(hipEventElapsedTime(&ms, a, b)); t.push_back(ms);
+        }
+        for (int r0 = 0; r0 < 60; r0 += 10) {
+            double s = 0; for (int r = r0; r < r0 + 10; r++) s += t[r];
+            printf("launches %2d..%2d  mean %.3f ms  %.0f GB/s\n", r0, r0 + 9, s / 10, (double)nblk * chunk * 16 / (s / 10) / 1e6);
+        }
+        return 0;
+    }
 #define RUN(name, launch) { launch; CK(hipDeviceSynchronize()); double ms = timeit([&] { launch; }, 7); printf("%-34s %.3f ms  %.0f GB/s\n", name, ms, (double)nblk * chunk * 16 / ms / 1e6); }
     RUN("chunk un4", (k_chunk<4, false><<<nblk, 256>>>(src, chunk, out)));
     RUN("chunk un8", (k_chunk<8, false><<<nblk, 256>>>(src, chunk, out)));
