@@ -359,6 +359,18 @@ __device__ __forceinline__ float sm_quot(float e, double total, const SmCfg &c)
     return e / (float)total;
 }
 
+// The reference's CPU softmax -- the 2^x and exp_plan bases, lib/layer.c:1195-1243 -- adds its terms to a FLOAT total in
+// slot order (`float tot`, :1161).  Where a memory fits a wavefront (slot r in lane r) that sum is reproduced as it is: S
+// dependent float additions.  (It matters at the truncation steps of Q(p): with one dominant slot and a runner-up 2^-24
+// below it the float total stays 1 and p = 1 exactly, a double total gives p = 1 - 2^-23 and Q(p) one code less.)  The
+// streaming kernels sum those bases in double: an order-free sum of 10 000 float terms cannot be the serial float one.
+__device__ __forceinline__ float wave_serial_sum_f32(float e, uint32_t S)
+{
+    float tot = 0.0f;
+    for (uint32_t r = 0; r < S; r++) tot += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e), (int)r));
+    return tot;
+}
+
 // Stages after the softmax, shared by every attention mode:
 //   read-out  o[c] = Qa( sum_r Qa( Qa(p[r]) . Qa(C[r][c]) ) )   (lib/layer_cuda.cu:547-635 via :2430/:2512)
 //             over the rows whose weight code Q(p) is non-zero (the others contribute exact zeros),

@@ -252,7 +252,8 @@ __device__ __forceinline__ void lean_hop(const HopArgs &a, const LeanArgs &la, u
         const float mx = wave_max_f32(xs);
         e = live ? sm_exp(xs - mx, smc) : 0.0f;
     }
-    total = wave_sum_f64((double)e);
+    total = smc.base == QMANN_SOFTMAX_EXP ? wave_sum_f64((double)e)            // the CUDA kernel's double total
+                                          : (double)wave_serial_sum_f32(e, S);     // the CPU softmax's float total, in slot order
     const float p = live ? sm_quot(e, total, smc) : 0.0f;
     // Q(p) for 0 <= p <= 1: trunc(p . 2^frac), saturated (qm_code without the cases a probability cannot reach)
     int kp = (int)__builtin_ldexpf(p, (int)fa.frac);

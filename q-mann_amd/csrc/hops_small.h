@@ -160,8 +160,12 @@ k_hops_small(const HopArgs a, const uint32_t key_row_bytes)
         for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
         const float e = live ? sm_exp(xs - mx, smc) : 0.0f;              // score - max, exact on the score grid
         double total = (double)e;
+        if (smc.base == QMANN_SOFTMAX_EXP) {             // the CUDA kernel's double total (lib/layer_cuda.cu:2024-2042)
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+            for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+        } else {
+            total = (double)wave_serial_sum_f32(e, S);     // the CPU softmax's float total, in slot order (hops_common.h)
+        }
         const float p = live ? sm_quot(e, total, smc) : 0.0f;
         const int kp = live ? qm_code(p, fa.iwl, fa.frac) : 0;
         if (live) {

@@ -24,7 +24,7 @@ def env():
     return e
 
 
-def both_paths(env, cfg, B, S_list, seed, sigma_k=30.0, sigma_u=20.0, sigma_h=1.0):
+def both_paths(env, cfg, B, S_list, seed, sigma_k=30.0, sigma_u=20.0, sigma_h=1.0, require_nonzero=True):
     torch, model = env.torch, env.model
     H, D, V = cfg["n_hop"], cfg["dim_emb"], cfg["dim_input"]
     rng = np.random.default_rng(seed)
@@ -58,7 +58,7 @@ def both_paths(env, cfg, B, S_list, seed, sigma_k=30.0, sigma_u=20.0, sigma_h=1.
     a, b = u_lean.cpu().numpy(), u_gen.cpu().numpy()
     bad = np.flatnonzero((a != b).any(1))
     assert bad.size == 0, f"{bad.size} of {B} queries differ, first {bad[:5]}, slots {n_slots[bad[:5]]}"
-    assert np.abs(b).sum() > 0
+    assert not require_nonzero or np.abs(b).sum() > 0             # (a test case that computes nothing tests nothing)
     return net
 
 
@@ -162,3 +162,41 @@ def test_lean_random_formats_hamming(env, seed):
     cfg.update(fmt=[inside() for _ in range(H)], fmt_w=[inside()] + [free() for _ in range(H - 1)], fmt_att=[att] * H,
                fmt_bin=free(), en_lin_map=bool(rng.integers(0, 5)))
     both_paths(env, cfg, B=64, S_list=[1, 5, 33, 64], seed=9600 + seed, sigma_k=40.0, sigma_u=40.0)
+
+
+def test_soak_find_pow2_total_on_a_float_rounding_boundary(env):
+    """found by tools/soak.py (case 12750221): 2^x base, one dominant slot and a runner-up exactly 2^-24 below it.  Two
+    double totals summed in different orders then round to different floats, Q(p) differs by a code and the two kernels
+    disagreed; both now add these bases the way the reference's CPU softmax does (a float total in slot order)."""
+    cfg = {'n_hop': 3, 'dim_emb': 20, 'dim_input': 40, 'attention_mode': 2, 'softmax_variant': 1, 'f_fixed': True, 'en_lin_map': False,
+           'fmt': [(0, 7), (1, 2), (3, 0)], 'fmt_w': [(4, 2), (2, 2), (3, 0)], 'fmt_att': [(0, 4), (6, 0), (3, 3)], 'fmt_bin': (6, 1),
+           'en_non_lin': True}
+    both_paths(env, cfg, B=184, S_list=[39, 41, 20, 5, 49, 8], seed=12750221, sigma_k=27.262290262548344,
+               sigma_u=68.24222274885791, sigma_h=5.570029277416961)
+
+
+@pytest.mark.parametrize("taps", [False, True])
+def test_pow2_total_is_the_reference_float_sum(env, oracle, taps):
+    """scores 63 and 39 on a Q6.0 grid, base 2^x: the terms are 1 and 2^-24.  The reference's float total is 1 (the small term
+    is rounded away), p = 1 exactly and Q1.2(p) = 4; a double total would give p = 1 - 2^-23 and the code 3.  Both
+    short-memory kernels must give the oracle's hop output (lean: no taps, general: taps)."""
+    torch, model = env.torch, env.model
+    D, V = 8, 10
+    cfg = dict(n_hop=1, dim_emb=D, dim_input=V, attention_mode=2, softmax_variant=1, f_fixed=True, en_lin_map=False,
+               fmt=[(1, 2)], fmt_w=[(6, 1)], fmt_att=[(6, 0)], fmt_bin=(6, 1))
+    wts = {"w_h": [np.zeros((D, D), np.float32)], "w_ans": np.zeros((V, D), np.float32)}
+    net = model.QNet(cfg, wts, device="cuda:0")
+    keys = np.zeros((1, 3, 64), np.int8); vals = np.zeros((1, 3, 64), np.int8)
+    keys[0, :, 0] = [63, 39, -5]
+    vals[0, 0, :D] = [7, -7, 5, 3, -1, 6, -6, 2]
+    vals[0, 1, :D] = [-7, 7, 1, 1, 1, 1, 1, 1]
+    u0 = np.zeros((1, D), np.float32); u0[0, 0] = 1.0
+    ro = torch.tensor([0, 3], dtype=torch.int32, device=env.dev)
+    dk = torch.from_numpy(model.to_signmag(keys)).to(env.dev); dv = torch.from_numpy(model.to_signmag(vals)).to(env.dev)
+    out = net.hops(dk, dv, ro, 3, torch.from_numpy(u0).to(env.dev), taps=taps)
+    u = (out[0] if taps else out).cpu().numpy()[0]
+    m = oracle.make_model(cfg, {**wts, "w_q": np.zeros((D, V), np.float32), "w_a": [np.zeros((D, V), np.float32)],
+                                "w_c": [np.zeros((D, V), np.float32)]})
+    _, t = oracle.forward_mem(m, keys[:, :, :D].astype(np.float32), vals[:, :, :D].astype(np.float32) / 4.0, u0[0])
+    assert t["probs"][0][0] == 1.0 and list(t["scores"][0]) == [63.0, 39.0, -5.0]
+    np.testing.assert_array_equal(u, t["u"][0])

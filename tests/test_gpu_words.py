@@ -56,7 +56,7 @@ def question_rows(qw, cfg):
     return out
 
 
-def run_both(env, cfg, wts, sw, qw, n_sen, ans=None, max_slots=None):
+def run_both(env, cfg, wts, sw, qw, n_sen, ans=None, max_slots=None, require_nonzero=True):
     """the host model's forward from word indices, and the same batch through bag-of-words rows -> k_embed_story ->
     general hop kernel -> answer layer; returns the host model's outputs"""
     torch, model = env.torch, env.model
@@ -99,7 +99,7 @@ def run_both(env, cfg, wts, sw, qw, n_sen, ans=None, max_slots=None):
     if ans is not None:
         assert mf == ms_
         assert cf == pytest.approx(cs, rel=1e-4, abs=1e-3)          # float atomics: the order of the adds differs
-    assert np.abs(us).sum() > 0
+    assert not require_nonzero or np.abs(us).sum() > 0
     return pf, uf
 
 

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Soak run on a GPU box: the random-configuration parity checks of tests/ with fresh seeds, for as long as asked.
+usage: python tools/soak.py [seconds]   (run from the repo root; prints one line per hundred cases)"""
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "tests"))
+import test_gpu_lean as TL                                   # noqa: E402
+import test_gpu_words as TW                                  # noqa: E402
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed_arg = int(sys.argv[2]) if len(sys.argv) > 2 else None        # reproduce: soak.py <seconds> <seed base> <first case>
+    n_first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    import torch
+    from conftest import load_pkg
+    load_pkg()
+    import qmann_amd.model as model
+
+    class Env:
+        pass
+    env = Env()
+    env.torch, env.model, env.dev = torch, model, torch.device("cuda:0")
+    t0, n = time.time(), n_first
+    seed = seed_arg if seed_arg is not None else int(t0) & 0xFFFFFF
+    print("soak seed base", seed, flush=True)
+    while time.time() - t0 < budget:
+        rng = np.random.default_rng(seed + n)
+        kind = n % 3
+        if kind == 0:                                        # lean kernel vs general kernel, random formats (fixed-point attention)
+            def fmt(lo=2, hi=7):
+                wl = int(rng.integers(lo, hi + 1)); iwl = int(rng.integers(0, wl + 1))
+                return (iwl, wl - iwl)
+            H = int(rng.integers(1, 5))
+            cfg = dict(n_hop=H, dim_emb=int(rng.choice([17, 20, 60, 64])), dim_input=40, attention_mode=2,
+                       softmax_variant=int(rng.integers(0, 3)), f_fixed=True, en_lin_map=bool(rng.integers(0, 4)),
+                       fmt=[fmt() for _ in range(H)], fmt_w=[fmt() for _ in range(H)], fmt_att=[fmt() for _ in range(H)],
+                       fmt_bin=fmt(1, 7), en_non_lin=bool(rng.integers(0, 2)))
+            S = [int(x) for x in rng.integers(0, 65, 6)]
+            args = dict(B=int(rng.integers(1, 200)), S_list=S, seed=seed + n, sigma_k=float(rng.uniform(3, 60)),
+                        sigma_u=float(rng.uniform(3, 80)), sigma_h=float(rng.uniform(0.3, 12)))
+            try:
+                TL.both_paths(env, cfg, require_nonzero=False, **args)
+            except AssertionError:
+                print("FAILED case", n, "seed base", seed, "cfg", cfg, "args", args, flush=True)
+                raise
+        elif kind == 1:                                      # Hamming / appx modes, default formats
+            mode, nb = [(3, 8), (10, 8), (10, 2), (10, 1), (11, 8), (11, 4)][int(rng.integers(0, 6))]
+            cfg = TL.cfg_of(mode, D=int(rng.choice([17, 60, 64])), nb=nb, iwl=int(rng.integers(2, 7)))
+            TL.both_paths(env, cfg, B=int(rng.integers(1, 200)), S_list=[int(x) for x in rng.integers(0, 65, 6)], seed=seed + n, require_nonzero=False)
+        else:                                                # whole forward from word lists vs the float chain
+            V = int(rng.choice([30, 70, 238, 300])); D = int(rng.choice([20, 60, 64])); W = int(rng.choice([5, 8, 12, 16]))
+            mode, nb = [(2, 8), (3, 8), (10, 2), (11, 4), (1, 8)][int(rng.integers(0, 5))]
+            B = int(rng.integers(1, 150))
+            slots = [int(x) for x in rng.integers(0, 65, 5)] + ([int(rng.integers(65, 400))] if rng.integers(0, 3) == 0 else [])
+            sw, qw, n_sen = TW.random_stories(rng, B, V, V - 12, W, slots)
+            cfg = model.babi_cfg(V, attention_mode=mode, D=D, en_mq=(mode == 2))
+            cfg["num_bit"] = nb
+            wts = TW.weights(seed + n, 3, D, V, float(rng.uniform(0.5, 2.0)))
+            if rng.integers(0, 3) == 0 and mode != 2:
+                wts = TW.tied(wts)
+            TW.run_both(env, cfg, wts, sw, qw, n_sen, rng.integers(0, V, B), require_nonzero=False)
+        n += 1
+        if n % 100 == 0:
+            print(f"{n} cases, {time.time() - t0:.0f} s", flush=True)
+    print(f"soak done: {n} cases in {time.time() - t0:.0f} s, all equal", flush=True)
+
+
+if __name__ == "__main__":
+    main()
