@@ -101,7 +101,7 @@ k_hops_ham(const HopArgs a, const uint32_t key_row_bytes, const uint32_t lds_slo
                 AppxConst c;
                 make_appx_const(c, ub, (lane % LPRK) * 16, D);
                 auto row_sum = [&](const i32x4 x) { return appx_lane_sum(x, c); };
-                auto retire_c = [&](uint32_t r, int v) { sc[r] = v > lim ? lim : (v < -lim ? -lim : v); };
+                auto retire_c = [&](uint32_t r, int v) { sc[r] = (score_t)appx_clamp(v, lim); };
                 if (S >= (kWave / LPRK) * 4) scan_rows<LPRK, 4, true, kWaves>(kb, S, row_sum, retire_c, lane, wave);
                 else scan_rows_short<LPRK>(kb, S, row_sum, retire_c, lane, wave, kWaves);
             } else if (mode_is_planes(MODE)) {

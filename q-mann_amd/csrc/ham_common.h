@@ -57,6 +57,15 @@ __device__ __forceinline__ int appx_lane_sum(const i32x4 x, const AppxConst &c)
     return dot + c.bias - (int)sad;
 }
 
+// Final quantisation of a mode-3 score, Q(iwl, 31-iwl) (lib/layer_cuda.cu:2515): saturation at +-2^iwl -- except that a sum of
+// EXACTLY -2^iwl is not below the macro's float limit (the limit (2^31 - 1) / 2^(31-iwl) rounds to 2^iwl itself), converts to
+// INT32_MIN, and the sign-magnitude word of INT32_MIN is "minus zero": the reference returns 0 there
+// (lib/layer_cuda.h:233-253; +2^iwl converts to INT32_MAX and stays 2^iwl).  v and lim in units of 2^-10.
+__device__ __forceinline__ int appx_clamp(int v, int lim)
+{
+    return v > lim ? lim : (v < -lim ? -lim : (v == -lim ? 0 : v));
+}
+
 // ---- V0 / V1: two 64-bit plane words per lane -------------------------------------------------
 struct PlaneConst {
     uint64_t u[2];      // query plane words at this lane's (group, plane) positions

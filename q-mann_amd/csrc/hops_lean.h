@@ -212,12 +212,12 @@ __device__ __forceinline__ void lean_hop(const HopArgs &a, const LeanArgs &la, u
     ScanConst csc;
     uint32_t csh = 0;
     float unit = 1.0f;
-    auto scan = [&](auto lane_sum, int lim) {
+    auto scan = [&](auto lane_sum, int lim, bool wrap = false) {         // wrap: mode 3's final quantiser (appx_clamp, ham_common.h)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if (j * 16 < (int)S) {                                // wavefront-uniform
                 const int v = row_lanes_sum<LPR>(lane_sum(key_of(j)));
-                if (chunk == 0) *(int16_t *)(lw + kLwSc + (j * 16 + sub) * 2) = (int16_t)(v > lim ? lim : (v < -lim ? -lim : v));
+                if (chunk == 0) *(int16_t *)(lw + kLwSc + (j * 16 + sub) * 2) = (int16_t)(v > lim ? lim : (v < -lim ? -lim : ((wrap && v == -lim) ? 0 : v)));
             }
         }
     };
@@ -229,7 +229,7 @@ __device__ __forceinline__ void lean_hop(const HopArgs &a, const LeanArgs &la, u
         unit = 1.0f / 1024.0f;
         AppxConst c;
         make_appx_const(c, lw + kLwUb, chunk * 16, D);
-        scan([&](const i32x4 x) { return appx_lane_sum(x, c); }, 1 << (fm.iwl + 10));
+        scan([&](const i32x4 x) { return appx_lane_sum(x, c); }, 1 << (fm.iwl + 10), true);
     } else {
         if (MODE == kModeV1Bytes) unit = qm_scale_down(1.0f, NB);
         HamByteConst c;

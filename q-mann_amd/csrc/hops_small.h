@@ -100,14 +100,14 @@ k_hops_small(const HopArgs a, const uint32_t key_row_bytes)
         float unit = 1.0f;
         if (S > 0) {
             const uint8_t *kb = (const uint8_t *)a.keys + (size_t)h * a.key_hop_stride + (size_t)r0 * key_row_bytes + chunkk * 16;
-            auto scan = [&](auto lane_sum, int lim) {
+            auto scan = [&](auto lane_sum, int lim, bool wrap = false) {     // wrap: mode 3's final quantiser (appx_clamp, ham_common.h)
                 if (PF) {
 #pragma unroll
                     for (int j = 0; j < NK; j++) {
                         const uint32_t r = j * RPWK + subk;
                         if (j * RPWK < S) {                                  // wavefront-uniform
                             const int v = row_lanes_sum<LPRK>(lane_sum(kq[j]));
-                            if (chunkk == 0 && r < S) sc[r] = (int16_t)(v > lim ? lim : (v < -lim ? -lim : v));
+                            if (chunkk == 0 && r < S) sc[r] = (int16_t)(v > lim ? lim : (v < -lim ? -lim : ((wrap && v == -lim) ? 0 : v)));
                         }
                     }
                     return;
@@ -117,7 +117,7 @@ k_hops_small(const HopArgs a, const uint32_t key_row_bytes)
                     i32x4 x = {0, 0, 0, 0};
                     if (r < S) x = *(const i32x4 *)(kb + (size_t)r * key_row_bytes);
                     const int v = row_lanes_sum<LPRK>(lane_sum(x));
-                    if (chunkk == 0 && r < S) sc[r] = (int16_t)(v > lim ? lim : (v < -lim ? -lim : v));
+                    if (chunkk == 0 && r < S) sc[r] = (int16_t)(v > lim ? lim : (v < -lim ? -lim : ((wrap && v == -lim) ? 0 : v)));
                 }
             };
             if (MODE == kModeFixed) {
@@ -128,7 +128,7 @@ k_hops_small(const HopArgs a, const uint32_t key_row_bytes)
                 unit = 1.0f / 1024.0f;                          // 2^-(n-1) . 2^ATTENTION_CONST_SCALE, n = 8
                 AppxConst c;
                 make_appx_const(c, ub, chunkk * 16, D);
-                scan([&](const i32x4 x) { return appx_lane_sum(x, c); }, 1 << (fm.iwl + 10));      // Q(iwl, 31-iwl) clamps at +-2^iwl
+                scan([&](const i32x4 x) { return appx_lane_sum(x, c); }, 1 << (fm.iwl + 10), true);  // Q(iwl, 31-iwl) clamps at +-2^iwl
             } else if (mode_is_planes(MODE)) {
                 if (MODE == kModeV1) unit = qm_scale_down(1.0f, NB);
                 PlaneConst c;

@@ -66,7 +66,11 @@ QM_HD float qm_decode(int32_t code, uint32_t frac)
 QM_HD float qm_quant(float x, uint32_t iwl, uint32_t frac)
 {
     if (iwl + frac == 0) return (x >= 0.0f) ? 1.0f : -1.0f;
-    return qm_decode(qm_code(x, iwl, frac), frac);
+    const int32_t k = qm_code(x, iwl, frac);
+    // iwl + frac == 31 only: x == -2^iwl is not below the float limit, converts to INT32_MIN, and the reference's
+    // sign-magnitude word of that is "minus zero" -- CUDA_FIXED2FLOAT gives 0 (lib/layer_cuda.h:246-253)
+    if (k == (int32_t)0x80000000) return 0.0f;
+    return qm_decode(k, frac);
 }
 
 // FIXED_MUL: Qa(Qa(a) * Qb(b))

@@ -1050,3 +1050,39 @@ def test_hops_hamming_random_formats(env, oracle, seed):
     S_list = [1, 5, 33, 64] if seed % 2 else [70, 300]
     from_bytes = (seed % 4 < 2 or (D <= 64 and nb == 1)) and mode != 3      # one plane of 64 columns is below a 16-byte row: bytes only
     run_hamming_case(env, oracle, mode, D, S_list, B=6, seed=8100 + seed, iwl=ia, num_bit=nb, extra=extra, from_bytes=from_bytes)
+
+
+def test_appx_score_of_exactly_minus_two_to_the_iwl_wraps_to_zero(env, oracle):
+    """found by tools/soak.py (case 12724684 + 1359): the mode-3 score is quantised to Q(iwl, 31-iwl); a row sum of EXACTLY
+    -2^iwl is not below the macro's float limit, converts to INT32_MIN, whose sign-magnitude word is "minus zero": the
+    reference returns 0, not -2^iwl (lib/layer_cuda.h:233-253).  Streaming, one-wavefront and lean kernels, and the
+    drop-in verb."""
+    extra = {'fmt': [(1, 2), (0, 5), (1, 3)], 'fmt_w': [(0, 4), (4, 0), (0, 6)], 'fmt_att': [(1, 6), (1, 6), (1, 6)], 'fmt_bin': (3, 0),
+             'en_lin_map': True}
+    run_hamming_case(env, oracle, 3, 128, [405, 309], B=3, seed=12726043, iwl=1, num_bit=2, extra=extra)
+    # a crafted row for the short-memory kernels: u = 0, so a positive key byte k gives 127 - k and a negative one -(127 - |k|);
+    # 16 columns of -(127 - 0)... : 16 x 128 = 2048 = 2^(1 + 10): use bytes of magnitude 0 with the sign set? those are "minus zero"
+    torch, model = env.torch, env.model
+    D = 64
+    cfg = dict(n_hop=1, dim_emb=D, dim_input=10, attention_mode=3, softmax_variant=0, f_fixed=True, en_lin_map=False,
+               fmt=[(1, 6)], fmt_w=[(1, 6)], fmt_att=[(1, 6)], fmt_bin=(1, 6), num_bit=8)
+    wts = {"w_h": [np.zeros((D, D), np.float32)], "w_ans": np.zeros((10, D), np.float32)}
+    net = model.QNet(cfg, wts, device="cuda:0")
+    # opposite signs, |k| + 0 < 128: term -(127 - |k|).  32 columns of k = -63 give -64 each = -2048; the other 32 columns: k = +127 -> 0
+    keys = np.zeros((1, 2, 64), np.int8)
+    keys[0, 0, :32] = -63; keys[0, 0, 32:] = 127
+    keys[0, 1, :32] = -62; keys[0, 1, 32:] = 127           # -65 each: below the limit, saturates to -2^iwl
+    vals = np.zeros((1, 2, 64), np.int8); vals[0, :, :4] = [[5, -5, 3, 1], [-7, 7, 1, 2]]
+    u0 = np.zeros((1, D), np.float32)
+    ro = torch.tensor([0, 2], dtype=torch.int32, device=env.dev)
+    dk = torch.from_numpy(model.to_signmag(keys)).to(env.dev); dv = torch.from_numpy(model.to_signmag(vals)).to(env.dev)
+    m = oracle.make_model(cfg, {**wts, "w_q": np.zeros((D, 10), np.float32), "w_a": [np.zeros((D, 10), np.float32)],
+                                "w_c": [np.zeros((D, 10), np.float32)]})
+    _, t = oracle.forward_mem(m, keys[:, :, :D].astype(np.float32) / 64.0, vals[:, :, :D].astype(np.float32) / 64.0, u0[0])
+    assert list(t["scores"][0]) == [0.0, -2.0]
+    for taps in (False, True):
+        out = net.hops(dk, dv, ro, 2, torch.from_numpy(u0).to(env.dev), taps=taps)
+        u = (out[0] if taps else out).cpu().numpy()[0]
+        np.testing.assert_array_equal(u, t["u"][0])
+        if taps:
+            np.testing.assert_array_equal(out[1].scores.cpu().numpy()[0], t["scores"][0])

@@ -11,6 +11,7 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "tests"))
 import test_gpu_lean as TL                                   # noqa: E402
 import test_gpu_words as TW                                  # noqa: E402
+import test_gpu_batch as TB                                  # noqa: E402
 
 
 def main():
@@ -26,12 +27,16 @@ def main():
         pass
     env = Env()
     env.torch, env.model, env.dev = torch, model, torch.device("cuda:0")
+    import qmann_amd.abi as abi
+    env.abi = abi
+    from pyoracle import Oracle
+    oracle = Oracle()
     t0, n = time.time(), n_first
     seed = seed_arg if seed_arg is not None else int(t0) & 0xFFFFFF
     print("soak seed base", seed, flush=True)
     while time.time() - t0 < budget:
         rng = np.random.default_rng(seed + n)
-        kind = n % 3
+        kind = n % 5        # (float attention is left out: its per-hop checks allow a statistical share of near-step cases)
         if kind == 0:                                        # lean kernel vs general kernel, random formats (fixed-point attention)
             def fmt(lo=2, hi=7):
                 wl = int(rng.integers(lo, hi + 1)); iwl = int(rng.integers(0, wl + 1))
@@ -53,7 +58,7 @@ def main():
             mode, nb = [(3, 8), (10, 8), (10, 2), (10, 1), (11, 8), (11, 4)][int(rng.integers(0, 6))]
             cfg = TL.cfg_of(mode, D=int(rng.choice([17, 60, 64])), nb=nb, iwl=int(rng.integers(2, 7)))
             TL.both_paths(env, cfg, B=int(rng.integers(1, 200)), S_list=[int(x) for x in rng.integers(0, 65, 6)], seed=seed + n, require_nonzero=False)
-        else:                                                # whole forward from word lists vs the float chain
+        elif kind == 2:                                      # whole forward from word lists vs the float chain
             V = int(rng.choice([30, 70, 238, 300])); D = int(rng.choice([20, 60, 64])); W = int(rng.choice([5, 8, 12, 16]))
             mode, nb = [(2, 8), (3, 8), (10, 2), (11, 4), (1, 8)][int(rng.integers(0, 5))]
             B = int(rng.integers(1, 150))
@@ -65,6 +70,48 @@ def main():
             if rng.integers(0, 3) == 0 and mode != 2:
                 wts = TW.tied(wts)
             TW.run_both(env, cfg, wts, sw, qw, n_sen, rng.integers(0, V, B), require_nonzero=False)
+        if kind == 3:                                        # every hop kernel family against the CPU oracle, fixed-point attention
+            def fmt(lo=2, hi=7):
+                wl = int(rng.integers(lo, hi + 1)); iwl = int(rng.integers(0, wl + 1))
+                return (iwl, wl - iwl)
+            H = int(rng.integers(1, 4))
+            D = int(rng.choice([20, 60, 64, 100, 128, 256]))
+            cfg = dict(n_hop=H, dim_emb=D, dim_input=40, attention_mode=2, softmax_variant=int(rng.integers(0, 3)), f_fixed=True,
+                       en_lin_map=bool(rng.integers(0, 4)), fmt=[fmt() for _ in range(H)], fmt_w=[fmt() for _ in range(H)],
+                       fmt_att=[fmt() for _ in range(H)], fmt_bin=fmt(1, 7), en_non_lin=bool(rng.integers(0, 2)))
+            S_list = [int(x) for x in rng.integers(1, 65, 4)] if rng.integers(0, 2) else [int(x) for x in rng.integers(65, 700, 3)]
+            try:
+                TB.run_case(env, oracle, cfg, B=int(rng.integers(1, 10)), S_list=S_list, seed=seed + n, sigma_u=float(rng.uniform(3, 60)),
+                            sigma_k=float(rng.uniform(3, 50)), sigma_h=float(rng.uniform(0.3, 8)))
+            except AssertionError:
+                print("FAILED oracle case", n, "seed base", seed, "cfg", cfg, "S_list", S_list, flush=True)
+                raise
+        if kind == 4:                                        # the Hamming family against the oracle: unrelated formats per role
+            ia = int(rng.integers(1, 7)); att = (ia, 7 - ia)
+
+            def inside():                                    # a format whose grid lies inside the attention grid
+                i = int(rng.integers(0, ia + 1)); f = int(rng.integers(0, 7 - ia + 1))
+                if i + f < 2:
+                    i, f = min(ia, 1), max(1, min(7 - ia, 1))
+                return (i, f)
+
+            def free():
+                wl = int(rng.integers(2, 8)); i = int(rng.integers(0, wl + 1))
+                return (i, wl - i)
+            H = 3
+            extra = dict(fmt=[inside() for _ in range(H)], fmt_w=[inside()] + [free() for _ in range(H - 1)],
+                         fmt_att=[att] * H, fmt_bin=free(), en_lin_map=bool(rng.integers(0, 5)))
+            mode = int(rng.choice([3, 10, 11])); nb = int(rng.choice([1, 2, 4, 8])); D = int(rng.choice([60, 128, 256]))
+            S_list = [int(x) for x in rng.integers(1, 65, 4)] if rng.integers(0, 2) else [int(x) for x in rng.integers(65, 500, 2)]
+            from_bytes = (bool(rng.integers(0, 2)) or (D <= 64 and nb == 1)) and mode != 3
+            Bh = int(rng.integers(1, 8))
+            try:
+                TB.run_hamming_case(env, oracle, mode, D, S_list, B=Bh, seed=seed + n, iwl=ia, num_bit=nb,
+                                    extra=extra, from_bytes=from_bytes)
+            except AssertionError:
+                print("FAILED hamming case", n, "seed base", seed, "args", dict(mode=mode, D=D, S_list=S_list, B=Bh, seed=seed + n, iwl=ia,
+                      num_bit=nb, extra=extra, from_bytes=from_bytes), flush=True)
+                raise
         n += 1
         if n % 100 == 0:
             print(f"{n} cases, {time.time() - t0:.0f} s", flush=True)
