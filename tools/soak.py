@@ -36,7 +36,7 @@ def main():
     print("soak seed base", seed, flush=True)
     while time.time() - t0 < budget:
         rng = np.random.default_rng(seed + n)
-        kind = n % 5        # (float attention is left out: its per-hop checks allow a statistical share of near-step cases)
+        kind = n % 7        # (float attention is left out: its per-hop checks allow a statistical share of near-step cases)
         if kind == 0:                                        # lean kernel vs general kernel, random formats (fixed-point attention)
             def fmt(lo=2, hi=7):
                 wl = int(rng.integers(lo, hi + 1)); iwl = int(rng.integers(0, wl + 1))
@@ -111,6 +111,20 @@ def main():
             except AssertionError:
                 print("FAILED hamming case", n, "seed base", seed, "args", dict(mode=mode, D=D, S_list=S_list, B=Bh, seed=seed + n, iwl=ia,
                       num_bit=nb, extra=extra, from_bytes=from_bytes), flush=True)
+                raise
+        if kind == 5:                                        # embedding kernels (float rows and word lists) against the oracle
+            sd = int(rng.integers(100, 1 << 30))
+            try:
+                TB.test_embedding_random_formats(env, oracle, sd)
+            except AssertionError:
+                print("FAILED embedding case", n, "seed base", seed, "test seed", sd, flush=True)
+                raise
+        elif kind == 6:                                      # answer layer against the oracle
+            V, D, base = int(rng.integers(2, 300)), int(rng.choice([20, 33, 60, 64, 128])), int(rng.integers(0, 3))
+            try:
+                TB.test_answer_layer_vs_oracle(env, oracle, V, D, base)
+            except AssertionError:
+                print("FAILED answer case", n, "seed base", seed, V, D, base, flush=True)
                 raise
         n += 1
         if n % 100 == 0:
