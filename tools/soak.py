@@ -66,6 +66,9 @@ def main():
             sw, qw, n_sen = TW.random_stories(rng, B, V, V - 12, W, slots)
             cfg = model.babi_cfg(V, attention_mode=mode, D=D, en_mq=(mode == 2))
             cfg["num_bit"] = nb
+            if mode == 2 and rng.integers(0, 2):             # one of the reference's options on top (tests/test_gpu_words.py::OPTIONS)
+                cfg = model.babi_cfg(V, attention_mode=2, D=D, en_mq=False)
+                cfg.update(TW.OPTIONS[sorted(TW.OPTIONS)[int(rng.integers(0, len(TW.OPTIONS)))]])
             wts = TW.weights(seed + n, 3, D, V, float(rng.uniform(0.5, 2.0)))
             if rng.integers(0, 3) == 0 and mode != 2:
                 wts = TW.tied(wts)
