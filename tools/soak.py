@@ -12,6 +12,7 @@ sys.path.insert(0, str(ROOT / "tests"))
 import test_gpu_lean as TL                                   # noqa: E402
 import test_gpu_words as TW                                  # noqa: E402
 import test_gpu_batch as TB                                  # noqa: E402
+import test_gpu_ops as TO                                    # noqa: E402
 
 
 def main():
@@ -31,12 +32,18 @@ def main():
     env.abi = abi
     from pyoracle import Oracle
     oracle = Oracle()
+    import ctypes as C
+    ops = Env()                                              # what tests/test_gpu_ops.py's fixture provides
+    ops.torch, ops.abi, ops.lib, ops.dev = torch, abi, abi.lib, env.dev
+    ops.up = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(env.dev)
+    ops.ptr = lambda t: C.c_void_p(t.data_ptr())
+    ops.empty = lambda *sh: torch.empty(sh, dtype=torch.float32, device=env.dev)
     t0, n = time.time(), n_first
     seed = seed_arg if seed_arg is not None else int(t0) & 0xFFFFFF
     print("soak seed base", seed, flush=True)
     while time.time() - t0 < budget:
         rng = np.random.default_rng(seed + n)
-        kind = n % 7        # (float attention is left out: its per-hop checks allow a statistical share of near-step cases)
+        kind = n % 8        # (float attention is left out: its per-hop checks allow a statistical share of near-step cases)
         if kind == 0:                                        # lean kernel vs general kernel, random formats (fixed-point attention)
             def fmt(lo=2, hi=7):
                 wl = int(rng.integers(lo, hi + 1)); iwl = int(rng.integers(0, wl + 1))
@@ -128,6 +135,13 @@ def main():
                 TB.test_answer_layer_vs_oracle(env, oracle, V, D, base)
             except AssertionError:
                 print("FAILED answer case", n, "seed base", seed, V, D, base, flush=True)
+                raise
+        if kind == 7:                                        # the drop-in forward verbs (boundary B) against the oracle
+            sd = int(rng.integers(100, 1 << 30))
+            try:
+                TO.test_forward_verbs_random_shapes_and_formats(ops, oracle, sd)
+            except AssertionError:
+                print("FAILED verbs case", n, "seed base", seed, "test seed", sd, flush=True)
                 raise
         n += 1
         if n % 100 == 0:
