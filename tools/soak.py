@@ -90,6 +90,8 @@ def main():
                        en_lin_map=bool(rng.integers(0, 4)), fmt=[fmt() for _ in range(H)], fmt_w=[fmt() for _ in range(H)],
                        fmt_att=[fmt() for _ in range(H)], fmt_bin=fmt(1, 7), en_non_lin=bool(rng.integers(0, 2)))
             S_list = [int(x) for x in rng.integers(1, 65, 4)] if rng.integers(0, 2) else [int(x) for x in rng.integers(65, 700, 3)]
+            if rng.integers(0, 12) == 0:
+                S_list = [int(rng.integers(700, 6000))]            # a long memory now and then (the four-wavefront streaming form)
             try:
                 TB.run_case(env, oracle, cfg, B=int(rng.integers(1, 10)), S_list=S_list, seed=seed + n, sigma_u=float(rng.uniform(3, 60)),
                             sigma_k=float(rng.uniform(3, 50)), sigma_h=float(rng.uniform(0.3, 8)))
