@@ -419,7 +419,7 @@ def test_hops_float_attention(env, oracle, D, S_list, B):
     run_float_case(env, oracle, D, S_list, B)
 
 
-def run_float_case(env, oracle, D, S_list, B, extra=None):
+def run_float_case(env, oracle, D, S_list, B, extra=None, seed=None, max_excused=None):
     torch, model = env.torch, env.model
     H, V, iwl = 3, 40, 5
     frac = 7 - iwl
@@ -428,8 +428,8 @@ def run_float_case(env, oracle, D, S_list, B, extra=None):
     cfg = dict(n_hop=H, dim_emb=D, dim_input=V, attention_mode=1, softmax_variant=0, f_fixed=True, en_lin_map=True,
                fmt=fmt, fmt_w=fmt_w, fmt_att=list(fmt), fmt_bin=(iwl, frac))
     cfg.update(extra or {})
-    rng = np.random.default_rng(D + B)
-    wts = weights(D, H, D, V, 1.0, with_emb=False)
+    rng = np.random.default_rng(D + B if seed is None else seed)
+    wts = weights(D if seed is None else seed, H, D, V, 1.0, with_emb=False)
     net = model.QNet(cfg, wts)
     Dp = net.Dp
     n_slots = np.array([S_list[i % len(S_list)] for i in range(B)], np.int64)
@@ -458,13 +458,14 @@ def run_float_case(env, oracle, D, S_list, B, extra=None):
             # float read-out: sum order differs from the reference's serial loop
             np.testing.assert_allclose(g_o[q, h], t["o"][h], rtol=1e-5, atol=2e-5)
             if not np.array_equal(g_u[q, h], t["u"][h]):
-                # only where lu + o sits within the float tolerance of a quantisation step
-                x = (t["lu"][h].astype(np.float64) + t["o"][h]) * (1 << frac)
+                # only where o sits within the float tolerance of a quantisation step: u' = Qa(Qa(lu) + Qa(o)) sees the read-out
+                # through Qa(o) alone (lu may live on a finer grid than the activations: hop 2 here)
+                x = t["o"][h].astype(np.float64) * (1 << frac)
                 bad = g_u[q, h] != t["u"][h]
                 assert np.all(np.abs(x[bad] - np.rint(x[bad])) < 1e-3), f"u differs away from a step q{q} h{h}"
                 excused += 1
                 break
-    assert excused <= max(1, B // 4)
+    assert excused <= (max(1, B // 4) if max_excused is None else max_excused)
 
 
 # ---------------------------------------------------------------------------------------------

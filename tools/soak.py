@@ -43,7 +43,7 @@ def main():
     print("soak seed base", seed, flush=True)
     while time.time() - t0 < budget:
         rng = np.random.default_rng(seed + n)
-        kind = n % 8        # (float attention is left out: its per-hop checks allow a statistical share of near-step cases)
+        kind = n % 9
         if kind == 0:                                        # lean kernel vs general kernel, random formats (fixed-point attention)
             def fmt(lo=2, hi=7):
                 wl = int(rng.integers(lo, hi + 1)); iwl = int(rng.integers(0, wl + 1))
@@ -144,6 +144,14 @@ def main():
                 TO.test_forward_verbs_random_shapes_and_formats(ops, oracle, sd)
             except AssertionError:
                 print("FAILED verbs case", n, "seed base", seed, "test seed", sd, flush=True)
+                raise
+        if kind == 8:                                        # float attention against the oracle (a cascade after a near-step case is excused)
+            D = int(rng.choice([60, 128, 256])); Bf = int(rng.integers(2, 8))
+            S_list = [int(x) for x in rng.integers(1, 400, 4)]
+            try:
+                TB.run_float_case(env, oracle, D, S_list, Bf, seed=seed + n, max_excused=Bf)
+            except AssertionError:
+                print("FAILED float case", n, "seed base", seed, D, S_list, Bf, flush=True)
                 raise
         n += 1
         if n % 100 == 0:
