@@ -87,6 +87,17 @@ WORKLOADS["babi_joint20_v1_tied"] = dict(S=64, D=60, V=238, B=262000, mode=11, n
 KERNEL_OF_MODE = {1: "k_hops_float", 2: "k_hops_fixed", 3: "k_hops_ham", 10: "k_hops_ham", 11: "k_hops_ham"}
 
 
+COMM = None                     # parallel.Comm of this rank (N > 1 on GPUs over RCCL), made in main()
+
+
+def with_bcast(out, bcast):
+    """attach the parameter-broadcast record (N > 1) to a result line"""
+    if bcast is not None:
+        out["param_broadcast_ms"] = bcast["ms"]
+        out["param_broadcast"] = bcast
+    return out
+
+
 def gauss_i8(shape, sigma, gen, dev, pad_from=None):
     """sign-magnitude int8 codes of clip(round(N(0, sigma)), +-127), generated on the device in chunks."""
     out = torch.empty(shape, dtype=torch.int8, device=dev)
@@ -239,7 +250,7 @@ def cpu_baseline(cfg, wts, pool, what, gpu_preds=None):
     return cpu_baseline_refport(cfg, wts, pool, what, gpu_preds) or cpu_baseline_port(cfg, wts, pool, what, gpu_preds)
 
 
-def run_bow(args, name, wl, net, cfg, wts, dev, rank, world, model):
+def run_bow(args, name, wl, net, cfg, wts, hm, dev, rank, world, model):
     """configs[1]: the full forward from bag-of-words stories (embedding + hops + answer)."""
     g = np.load(ROOT / "tests" / "golden" / "babi_qa1_test64.npz")
     n_sen = g["n_sen"].astype(np.int64)
@@ -266,9 +277,7 @@ def run_bow(args, name, wl, net, cfg, wts, dev, rank, world, model):
             return out
         sw = torch.from_numpy(np.tile(to_words(g["story"], dd, 8, True), (rep, 1)).view(np.int16)).to(dev)
         qw = torch.from_numpy(np.tile(to_words(g["question"], cfg["dim_input"], 8, False), (rep, 1)).view(np.int16)).to(dev)
-        net.make_tables()
-    hm = model.HostModel(cfg, wts, device=str(dev))              # the library's own host object: one call per batch
-    torch.cuda.synchronize()
+    torch.cuda.synchronize()                                     # hm: the library's own host object, one call per batch
 
     def step():
         if not use_idx:                                          # float rows in, as the reference's cuda_data_in pools hold them
@@ -338,7 +347,7 @@ def run_bow(args, name, wl, net, cfg, wts, dev, rank, world, model):
             # the same with the copy of batch i+1 overlapping the compute of batch i: two HIP streams, two
             # input buffers, events in both directions (every entry point of the library takes a stream)
             cs, ks = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
-            hm2 = model.HostModel(cfg, wts, device=str(dev), stream=ks.cuda_stream)
+            hm2 = model.HostModel.from_params(cfg, *hm.params(), device=str(dev), stream=ks.cuda_stream)   # a second replica from the same blob
             bufs = [[torch.empty_like(t, device=dev) for t in srcs] for _ in range(2)]
             copied = [torch.cuda.Event() for _ in range(2)]
             done = [torch.cuda.Event() for _ in range(2)]
@@ -390,7 +399,7 @@ def words_to_bow(words, V, dim_dict, with_time):
     return out
 
 
-def run_joint(args, name, wl, cfg, wts, dev, rank, world, model):
+def run_joint(args, name, wl, cfg, wts, hm, dev, rank, world, model):
     """configs[2]: 20-task joint bAbI stories, Hamming / dot attention, the whole forward in one library call."""
     g = np.load(ROOT / "tests" / "golden" / "babi_joint20_test2000.npz")
     n_sen = g["n_sen"].astype(np.int64)
@@ -403,7 +412,6 @@ def run_joint(args, name, wl, cfg, wts, dev, rank, world, model):
     ans = torch.from_numpy(np.tile(g["answer"].astype(np.int32), rep)).to(dev)
     row_off = torch.from_numpy(np.concatenate([[0], np.cumsum(np.tile(n_sen, rep))]).astype(np.int32)).to(dev)
     max_slots = int(n_sen.max())
-    hm = model.HostModel(cfg, wts, device=str(dev))
     torch.cuda.synchronize()
     for _ in range(args.warmup):
         out = hm.forward_words(sw, qw, row_off, max_slots, ans)
@@ -451,7 +459,6 @@ def run_joint(args, name, wl, cfg, wts, dev, rank, world, model):
         gp = out[0][:nfix].cpu().numpy()
         res["cpu_baseline"] = cpu_baseline(cfg, wts, pool, f"{len(pick)} fixture stories spread over the 20 tasks, whole forward",
                                            gpu_preds=[int(gp[i]) for i in pick])
-    hm.close()
     return res
 
 
@@ -464,6 +471,8 @@ def parse_args(argv=None):
     ap.add_argument("--queries", type=int, default=0, help="queries per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="default workload only: skip the |mem| = 50 figure")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the second, longer timing window")
+    ap.add_argument("--sustain-s", type=float, default=2.0, help="length of the sustained window in seconds (default 2)")
     return ap.parse_args(argv)
 
 
@@ -538,13 +547,20 @@ def main(argv=None):
         dev = torch.device(f"cuda:{local_rank}")
         torch.cuda.set_device(dev)
         load_pkg()
+        global COMM
+        comm_info = None
+        if world > 1 and not rehearse:
+            # the library's own communicator (ncclCommInitRank inside libqmann_hip.so); torch.distributed carried the id
+            from qmann_amd.parallel import Comm
+            COMM = Comm(rank, world, local_rank)
+            comm_info = COMM.info()
         out = run_workload(args, args.workload, dev, rank, world)
         # BASELINE.json quotes its metric at |mem| = 50 (the bAbI cap) and sets its target at |mem| = 10 000:
         # the default line is the 10 000-slot configuration and carries the 50-slot figure beside it
         if args.workload == "synth10k_d128" and not args.no_secondary:
             sec = run_workload(argparse.Namespace(**{**vars(args), "queries": 0}), "babi_mem50", dev, rank, world)
             if rank == 0:
-                out["mem50"] = {k: sec[k] for k in ("value", "unit", "ms_per_step", "config", "roofline", "cpu_baseline", "ranks") if k in sec}
+                out["mem50"] = {k: sec[k] for k in ("value", "unit", "ms_per_step", "config", "roofline", "sustained", "cpu_baseline", "ranks") if k in sec}
                 out["config"]["value_is"] = ("the |mem| = 10 000 shard (BASELINE.json configs[3], the configuration the north-star "
                                              "roofline target is set on); `mem50` is the |mem| = 50 size the metric string names")
     if rank == 0:
@@ -552,7 +568,11 @@ def main(argv=None):
             out["collective"] = {"backend": backend, "world_size_seen": world,
                                  "library": "RCCL over xGMI" if backend == "nccl" else "gloo (rehearsal / plumbing: not RCCL)",
                                  "self_launched": os.environ.get("QMANN_BENCH_SELF_LAUNCHED") == "1"}
+            if not plumbing and comm_info:
+                out["collective"]["qmann_comm"] = comm_info      # the C-level communicator the parameter broadcast ran on
         print(json.dumps(out), flush=True)
+    if COMM is not None:
+        COMM.close()
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
@@ -613,7 +633,8 @@ def run_workload(args, name, dev, rank, world):
     """One workload: W warm-up steps, K timed steps between barriers, max over ranks; returns the result dict."""
     import qmann_amd.abi as abi
     import qmann_amd.model as model
-    from qmann_amd.parallel import broadcast_params
+    from qmann_amd.parallel import replicate_model
+    SRC_SHA = sys.modules["qmann_amd"].kernel_sources_sha16()
     if world > 1:
         import torch.distributed as dist
 
@@ -626,28 +647,36 @@ def run_workload(args, name, dev, rank, world):
     if os.environ.get("QMANN_BENCH_NO_LINMAP"):            # experiment: what the in-kernel linear map costs
         cfg["en_lin_map"] = False
 
-    # parameters: created on rank 0, broadcast once over RCCL (xGMI) -- the only collective
-    wts = make_params(cfg, D, V, seed=0x51A44) if rank == 0 else None
-    wts, bcast_ms = broadcast_params(wts, cfg, dev, rank, world)
-    if wl.get("bow") or wl.get("joint"):         # embedding tables (seeded identically on every rank)
-        rng = np.random.default_rng(0xBAB1)
+    # parameters: created on rank 0 only, turned into the library's model object there, and replicated by ONE broadcast of
+    # the model's quantised parameter blob -- qmann_comm_broadcast_params (include/qmann_dist.h: ncclBroadcast inside the
+    # library, RCCL over xGMI), the same call a C host makes (examples/forward_sharded.c).  The only collective.
+    wts = None
+    ans_fmt = (1, 6)
+    hm = None
+    if rank == 0:
+        wts = make_params(cfg, D, V, seed=0x51A44)
+        rng = np.random.default_rng(0xBAB1)      # embedding matrices (the synthetic-memory workloads carry but do not use them)
         wts["w_q"] = rng.normal(0, 1.0, (D, V)).astype(np.float32)
         wts["w_a"] = [rng.normal(0, 1.0, (D, V)).astype(np.float32) for _ in range(H)]
         wts["w_c"] = [rng.normal(0, 1.0, (D, V)).astype(np.float32) for _ in range(H)]
-    ans_fmt = (1, 6)
-    if wl["ans"] == "i8":                       # answer matrix on an int8 grid -> the MFMA projection is exact
-        wts["w_ans"] = (np.clip(np.rint(wts["w_ans"] * 64.0 * 4), -127, 127) / 64.0).astype(np.float32)
-    if wl.get("tied"):
-        wts["w_a"] = [wts["w_a"][0]] * H
-        wts["w_c"] = [wts["w_c"][0]] * H
+        if not cfg["en_lin_map"]:
+            wts["w_h"] = None
+        if wl["ans"] == "i8":                       # answer matrix on an int8 grid -> the MFMA projection is exact
+            wts["w_ans"] = (np.clip(np.rint(wts["w_ans"] * 64.0 * 4), -127, 127) / 64.0).astype(np.float32)
+        if wl.get("tied"):
+            wts["w_a"] = [wts["w_a"][0]] * H
+            wts["w_c"] = [wts["w_c"][0]] * H
+        hm = model.HostModel(cfg, wts, device=str(dev))
+    hm, bcast_ms, bcast_how = replicate_model(hm, cfg, dev, rank, world, COMM, model)
+    bcast = None if bcast_ms is None else {"ms": bcast_ms, "how": bcast_how, "bytes": hm.params()[1]}
     if wl.get("joint"):
-        return run_joint(args, name, wl, cfg, wts, dev, rank, world, model)
-    net = model.QNet(cfg, wts, device=str(dev))
+        return with_bcast(run_joint(args, name, wl, cfg, wts, hm, dev, rank, world, model), bcast)
+    net = model.QNet.from_model(cfg, hm)         # hop / answer kernels read the linear maps and W_ans inside hm's blob
     Dp = net.Dp
     w_ans_i8 = net.quantize_i8(net.w_ans, ans_fmt, abi.CODE_TWOS) if wl["ans"] == "i8" else None
 
     if wl.get("bow"):
-        return run_bow(args, name, wl, net, cfg, wts, dev, rank, world, model)
+        return with_bcast(run_bow(args, name, wl, net, cfg, wts, hm, dev, rank, world, model), bcast)
 
     # synthetic per-query memories, resident in HBM before the timed region
     gen = torch.Generator(device=dev)
@@ -702,6 +731,29 @@ def run_workload(args, name, dev, rank, world):
 
     hop_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))    # dominant kernel, HIP events
     ans_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+
+    # A second, LONGER window of the same steps (>= 2 s back to back): a fresh box runs the first 0.1 s of a full-rate HBM
+    # stream 4-6 % faster than it sustains (clock / power management under 55 % VALU issue on top of the stream), so the
+    # short driver-specified window flatters.  Both figures go into the line; DESIGN.md quotes the sustained one first.
+    sustained = None
+    if not args.no_sustained:
+        n_sus = max(args.steps, int(np.ceil(args.sustain_s / max(elapsed_local / args.steps, 1e-6))))
+        n_sus = min(n_sus, 20000)
+        sev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * n_sus)]
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for i in range(n_sus):
+            sev[2 * i].record()
+            u = run_hops()
+            sev[2 * i + 1].record()
+            pred = run_answer(u)
+        torch.cuda.synchronize()
+        sus_elapsed = time.perf_counter() - ts
+        per = np.array([sev[2 * i].elapsed_time(sev[2 * i + 1]) for i in range(n_sus)])
+        sustained = {"steps": n_sus, "seconds": sus_elapsed, "ms_per_step": sus_elapsed / n_sus * 1e3,
+                     "queries_per_s": world * B * n_sus / sus_elapsed, "kernel_ms": float(per.mean()),
+                     "kernel_ms_first_tenth": float(per[: max(1, n_sus // 10)].mean()),
+                     "kernel_ms_last_tenth": float(per[-max(1, n_sus // 10):].mean())}
     bytes_per_query = H * S * key_row_bytes                           # key planes: the addressing scan
     if mode == 1:
         bytes_per_query += H * S * Dp                                 # float read-out streams every value row too
@@ -714,8 +766,14 @@ def run_workload(args, name, dev, rank, world):
     if tj.exists():
         rec = json.loads(tj.read_text()).get(name)
         if rec and B == wl["B"]:
-            traffic = rec["traffic_bytes_per_launch"]
-            traffic_source = f"{rec['source']} (a separate rocprofv3 --pmc FETCH_SIZE pass, x2 gfx950 correction; NOT measured in this run)"
+            # counter figures are quoted only while the kernel sources they were measured on are the loaded library's
+            if rec.get("kernel_sources_sha16") == SRC_SHA:
+                traffic = rec["traffic_bytes_per_launch"]
+                traffic_source = (f"{rec['source']} (a separate rocprofv3 --pmc FETCH_SIZE pass on kernel sources {SRC_SHA}, x2 gfx950 "
+                                  "correction; NOT measured in this run)")
+            else:
+                traffic_source = (f"dropped: {rec['source']} was collected on kernel sources {rec.get('kernel_sources_sha16', '(unstamped)')}, "
+                                  f"this library is built from {SRC_SHA}")
     # SURVEY.md 8(d) prices a query at keys + values; the quantised read-out touches only the <= 2^frac surviving
     # value rows (bit-identical to summing all rows), so `achieved` counts the key bytes the scan must stream
     survey_bytes = H * S * (key_row_bytes + Dp)
@@ -760,15 +818,22 @@ def run_workload(args, name, dev, rank, world):
         mj = ROOT / "profiles" / "mfma.json"
         if mj.exists():
             rec = json.loads(mj.read_text()).get(name)
-            if rec:      # matrix-pipe occupancy from the PMC counters of a separate rocprofv3 pass of this command (not measured in this run)
+            if rec and rec.get("kernel_sources_sha16") == SRC_SHA:   # matrix-pipe occupancy from a separate rocprofv3 --pmc pass of this command on these sources
                 al["mfma_busy_frac_counters"] = rec["mfma_busy_frac"]
-                al["mfma_counters_source"] = rec["source"]
+                al["mfma_counters_source"] = f"{rec['source']} (kernel sources {SRC_SHA}; not measured in this run)"
+            elif rec:
+                al["mfma_counters_source"] = f"dropped: {rec['source']} was collected on other kernel sources ({rec.get('kernel_sources_sha16', 'unstamped')} != {SRC_SHA})"
+    if sustained is not None:
+        gbs = bytes_per_query * B / (sustained["kernel_ms"] * 1e-3) / 1e9
+        sustained.update(achieved=gbs, frac=gbs / HBM_PEAK_GBS, frac_by_ms_per_step=bytes_per_query * B / (sustained["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         note="same steps as the timed region, run for >= %.1f s back to back on this rank; this rank's figure" % args.sustain_s)
+        out["sustained"] = sustained
+        out["roofline"]["frac_sustained"] = sustained["frac"]
     st = rank_stats(world, dev, roofline_frac=achieved / HBM_PEAK_GBS, kernel_ms=hop_ms,
                     queries_per_s=B * args.steps / elapsed_local)
     if st:
         out["ranks"] = st
-    if bcast_ms is not None:
-        out["param_broadcast_ms"] = bcast_ms
+    with_bcast(out, bcast)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         pool = mem_pool(cfg, keys, vals, u0, S, D)
         out["cpu_baseline"] = cpu_baseline(cfg, wts, pool, f"|mem| = {S}, D = {D}, {H} hops + answer layer",

@@ -43,7 +43,8 @@ extern "C" {
 #define QMANN_MAX_HOP 8
 
 enum { QMANN_OK = 0, QMANN_EINVAL = -1, QMANN_ERANGE = -2, QMANN_EUNSUPPORTED = -3, QMANN_EIO = -4,
-       QMANN_EHIP = -5 /* a HIP runtime call failed (message on stderr); the process goes on */ };
+       QMANN_EHIP = -5 /* a HIP runtime call failed (message on stderr); the process goes on */,
+       QMANN_ECOMM = -6 /* RCCL: the library could not be loaded or a collective call failed (qmann_dist.h) */ };
 
 /* attention_mode: MemN2N/define.h:10-15 (1..3) plus the packed-code Hamming forms */
 enum {
@@ -111,7 +112,7 @@ int qmann_quantize_i8(const float *src, int8_t *dst, size_t rows, uint32_t cols,
 
 /* The hot path: all hops of all queries in one launch (one workgroup per query).
  *   max_slots                  -- bound on row_off[q+1] - row_off[q]; sizes the per-query LDS.  A story longer than the bound
- *                                 is CUT (to max_slots, or to 64 when the bound is below 64): the call still returns 0 and
+ *                                 is CUT to max_slots by every kernel: the call still returns 0 and
  *                                 the result is that of the shortened story -- pass the true maximum (qmann_check_slots below
  *                                 verifies a bound on the device)
  *   u0    [n_query][D] float   -- question embedding (emb_q output)
@@ -204,6 +205,11 @@ int qmann_embed_query_rows(const qmann_net *net, const float *question, const ui
  * question row that carries the position weights). */
 int qmann_quantize_table_i8(const float *w, int8_t *table, uint32_t dim_emb, uint32_t dim_emb_pad,
                             uint32_t dim_input, qmann_fmt fmt, void *stream);
+/* The way back: a table's codes as the float matrix [D][V] of grid values (code . 2^-frac, exact).  Quantising that matrix
+ * again gives the same table, and the float embedding kernels (which quantise their weights on entry, as dense_mat_fwd does)
+ * give the same memories from it as from the original matrix -- so a model can live on its int8 tables alone. */
+int qmann_dequantize_table_f32(const int8_t *table, float *w, uint32_t dim_emb, uint32_t dim_emb_pad, uint32_t dim_input,
+                               qmann_fmt fmt, void *stream);
 int qmann_embed_story_idx(const qmann_net *net, const uint16_t *words, uint32_t rows_total, uint32_t max_words,
                           int time_last, const int8_t *const *t_a, const int8_t *const *t_c, int8_t *keys,
                           int8_t *vals, size_t hop_stride, void *stream);

@@ -17,8 +17,10 @@
  *   dim_input     dictionary size + max_line (EN_TIME, MemN2N.c:574-578);
  *   time entry    sentence j of n gets dim_dict + n - 1 - j, the most recent sentence index dim_dict (sample.c:474);
  *   answer        the index of the answer word (the rows are one-hot in every bAbI task).
- * One deliberate difference: a test word that is not in the training dictionary is dropped (0xFFFF / no label); the
- * reference's word_idx returns -1 there and the row write goes out of bounds (sample.c:838-848, :544).
+ * One deliberate difference: a test word that is not in the training dictionary is dropped (no label; in a question it
+ * leaves a 0xFFFF hole in ITS slot so that the other words keep their positions, which EN_PE weighs: sample.c:559); the
+ * reference's word_idx returns -1 there and the row write goes out of bounds (sample.c:838-848, :544).  A count line that is
+ * not a decimal number is a format error (QMANN_EIO), not a count of 0.
  * Host-only code (no GPU call); pinned against the fixtures the reference's own sample.c produced (tests/test_dataset_io.py).
  */
 #ifndef QMANN_DATASET_H
@@ -38,7 +40,7 @@ typedef struct qmann_dataset {
     uint32_t dim_dict, dim_input, max_line, dim_word;
     uint32_t *row_off;         /* [n_query + 1] first sentence of every story */
     uint16_t *story_words;     /* [rows_total][max_words]: the words in sentence order, then the time index; 0xFFFF unused */
-    uint16_t *question_words;  /* [n_query][max_q_words] in question order (EN_PE needs the positions) */
+    uint16_t *question_words;  /* [n_query][max_q_words]: slot k = word k of the question (EN_PE needs the positions), 0xFFFF = unknown word / unused */
     uint32_t *answer;          /* [n_query], 0xFFFFFFFF when the answer word is not in the dictionary */
 } qmann_dataset;
 

@@ -34,6 +34,35 @@ typedef struct qmann_model qmann_model;
 int qmann_model_create(qmann_model **out, const qmann_net *net, const qmann_weights *w, void *stream);
 void qmann_model_destroy(qmann_model *m);
 
+/* The same on a named GPU (hipSetDevice index; -1 = the calling thread's current device, which is what
+ * qmann_model_create uses).  A model is BOUND to its device: parameters and workspace live there, and every later call on
+ * the object runs there whatever the calling thread's current device is (it is switched for the length of the call and put
+ * back) -- `stream` and the data pointers of those calls must belong to that device.  One object per host thread / stream;
+ * different objects (on the same or on different GPUs) may be driven from different threads concurrently: this is how a
+ * host shards the reference's serial test loop (MemN2N/MemN2N.c:2378) over the GPUs of a node, one thread per GPU
+ * (examples/forward_sharded.c, qmann_dist.h). */
+int qmann_model_create_on(qmann_model **out, int device, const qmann_net *net, const qmann_weights *w, void *stream);
+int qmann_model_device(const qmann_model *m);
+
+/* The model's QUANTISED parameters as one position-independent blob in device memory (owned by the model, valid until it is
+ * destroyed): a header with the qmann_net (dimensions, modes, every Q-format, scale factors), the int8 embedding tables
+ * [V][Dp] of emb_q / emb_m[h] / emb_c[h], the sign-magnitude linear-map codes [D][Dp] and the float answer matrix [V][D]
+ * (ds_ans is a float layer, MemN2N.c:902-906).  About (1 + 2 H) V Dp + H D Dp + 4 V D bytes: 40 KB for bAbI task 1, 0.5 MB
+ * for D = V = 256.  This is what a multi-GPU host broadcasts once (qmann_comm_broadcast_params). */
+int qmann_model_params(const qmann_model *m, const void **blob, size_t *bytes);
+
+/* A replica from such a blob -- `blob` may be device memory of this or of a peer GPU, or host memory (a file read back);
+ * it is copied, the caller keeps ownership.  No float matrix and no quantisation step is involved: the replica computes
+ * from the very bytes the source model computes from, so its results are identical.  (The float embedding kernels that
+ * qmann_model_forward_bow uses for irregular rows get the tables' grid values, qmann_dequantize_table_f32.)
+ * Returns QMANN_EINVAL for a blob that is not one (magic, version, size or section offsets do not match). */
+int qmann_model_create_from_params(qmann_model **out, int device, const void *blob, size_t bytes, void *stream);
+
+/* The net as the model uses it -- lin_map[h] filled with the device pointers into the blob -- and the answer matrix: for
+ * hosts that drive qmann_hops_i8 / qmann_answer_f32 themselves on memories of their own but take the parameters from a
+ * (broadcast) model.  Pointers are valid until the model is destroyed. */
+int qmann_model_net(const qmann_model *m, qmann_net *net, const float **w_ans);
+
 /* Forward from word indices (qmann_embed_story_idx's wire format).
  *   story_words [rows_total][max_words] uint16, question_words [n_query][max_q_words] uint16,
  *   row_off [n_query + 1], max_slots >= every story's slot count,

@@ -18,4 +18,18 @@ ROOT = PKG_DIR.parent
 # QMANN_LIB_PATH: another build of the same library (A/B timing of two builds inside one GPU session)
 LIB_PATH = Path(os.environ["QMANN_LIB_PATH"]) if os.environ.get("QMANN_LIB_PATH") else PKG_DIR / "lib" / "libqmann_hip.so"
 
-__all__ = ["PKG_DIR", "ROOT", "LIB_PATH"]
+
+
+def kernel_sources_sha16() -> str:
+    """First 16 hex digits of the SHA-256 over the kernel sources (csrc/*.hip, csrc/*.h, in name order).  Counter figures
+    taken in a separate profiler pass (profiles/traffic.json, profiles/mfma.json) are stamped with it; bench.py quotes them
+    only while the sources they were measured on are the ones that built the loaded library."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted((PKG_DIR / "csrc").glob("*.h*")):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+__all__ = ["PKG_DIR", "ROOT", "LIB_PATH", "kernel_sources_sha16"]

@@ -143,6 +143,23 @@ _proto("qmann_embed_story_rows", C.c_int, [C.POINTER(Net), _vp, C.c_uint32, _vp,
 _proto("qmann_embed_query_rows", C.c_int, [C.POINTER(Net), _vp, _vp, _vp, _vp, _vp, C.c_uint32, _vp])
 _proto("qmann_model_create", C.c_int, [C.POINTER(_vp), C.POINTER(Net), C.POINTER(Weights), _vp])
 _proto("qmann_model_destroy", None, [_vp])
+_proto("qmann_model_create_on", C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(Net), C.POINTER(Weights), _vp])
+_proto("qmann_model_device", C.c_int, [_vp])
+_proto("qmann_model_params", C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)])
+_proto("qmann_model_create_from_params", C.c_int, [C.POINTER(_vp), C.c_int, _vp, C.c_size_t, _vp])
+_proto("qmann_model_net", C.c_int, [_vp, C.POINTER(Net), C.POINTER(_vp)])
+_proto("qmann_dequantize_table_f32", C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, Fmt, _vp])
+# ---- include/qmann_dist.h: shards, RCCL rendezvous, parameter broadcast ----
+COMM_ID_BYTES = 128
+_proto("qmann_shard_range", None, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)])
+_proto("qmann_comm_get_id", C.c_int, [_vp])
+_proto("qmann_comm_init_rank", C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, _vp, C.c_int])
+_proto("qmann_comm_destroy", None, [_vp])
+_proto("qmann_comm_info", C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)])
+_proto("qmann_comm_broadcast_params", C.c_int, [_vp, C.c_int, _vp, C.POINTER(_vp), C.POINTER(C.c_size_t), _vp])
+_proto("qmann_params_free", None, [_vp])
+_proto("qmann_comm_broadcast", C.c_int, [_vp, C.c_int, _vp, C.c_size_t, _vp])
+_proto("qmann_comm_allgather_u32", C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp])
 _proto("qmann_model_forward_words", C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, _vp, C.c_uint32, _vp, C.c_uint32,
                                               C.c_uint32, _vp, _vp, _vp, _vp, _vp])
 _proto("qmann_model_forward_bow", C.c_int, [_vp, _vp, C.c_uint32, _vp, _vp, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp, _vp])
@@ -182,9 +199,16 @@ def load_dataset(train_path, test_path, max_sen_len=50, n_train_cap=0, n_test_ca
 
 
 # include/qmann_batch.h return codes
-QMANN_OK, QMANN_EINVAL, QMANN_ERANGE, QMANN_EUNSUPPORTED, QMANN_EIO, QMANN_EHIP = 0, -1, -2, -3, -4, -5
+QMANN_OK, QMANN_EINVAL, QMANN_ERANGE, QMANN_EUNSUPPORTED, QMANN_EIO, QMANN_EHIP, QMANN_ECOMM = 0, -1, -2, -3, -4, -5, -6
 
 
 def check(rc: int, what: str):
     if rc != 0:
         raise RuntimeError(f"{what} failed with code {rc}")
+
+
+def shard_range(n_query: int, rank: int, world: int):
+    """qmann_shard_range: the contiguous [lo, hi) of `rank`."""
+    lo, hi = C.c_uint32(), C.c_uint32()
+    lib.qmann_shard_range(n_query, rank, world, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value

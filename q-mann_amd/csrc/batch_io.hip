@@ -1226,6 +1226,16 @@ __global__ void k_quantize_transpose(const float *__restrict__ src, int8_t *__re
     dst[i] = (c < D) ? (int8_t)qm_code(src[(size_t)c * V + v], f.iwl, f.frac) : (int8_t)0;
 }
 
+// the way back: int8 codes [V][Dp] -> the grid values as a float matrix [D][V] (exact: code . 2^-frac)
+__global__ void k_dequantize_transpose(const int8_t *__restrict__ src, float *__restrict__ dst, uint32_t D, uint32_t V,
+                                       uint32_t Dp, uint32_t frac)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D * V) return;
+    const uint32_t c = i / V, v = i % V;
+    dst[i] = qm_decode((int32_t)src[(size_t)v * Dp + c], frac);
+}
+
 inline bool fmt8(qmann_fmt f) { return f.iwl + f.frac >= 1 && f.iwl + f.frac <= 7; }
 
 }  // namespace
@@ -1437,6 +1447,19 @@ int qmann_quantize_table_i8(const float *w, int8_t *table, uint32_t dim_emb, uin
     if (n == 0) return QMANN_OK;
     k_quantize_transpose<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(w, table, dim_emb, dim_input, dim_emb_pad,
                                                                          QFmt{fmt.iwl, fmt.frac});
+    QM_LAUNCH_CHECK();
+    return qm_scope.rc();
+}
+
+int qmann_dequantize_table_f32(const int8_t *table, float *w, uint32_t dim_emb, uint32_t dim_emb_pad, uint32_t dim_input,
+                               qmann_fmt fmt, void *stream)
+{
+    QmBatched qm_scope;
+    if (!w || !table || dim_emb > dim_emb_pad) return QMANN_EINVAL;
+    if (!fmt8(fmt)) return QMANN_ERANGE;
+    const uint32_t n = dim_input * dim_emb;
+    if (n == 0) return QMANN_OK;
+    k_dequantize_transpose<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(table, w, dim_emb, dim_input, dim_emb_pad, fmt.frac);
     QM_LAUNCH_CHECK();
     return qm_scope.rc();
 }

@@ -46,6 +46,22 @@ bool next_line(FILE *f, std::string &line)
     return any;
 }
 
+// a count line: decimal digits (blanks around them allowed), nothing else -- "abc" or "" is a format error, not a 0
+bool parse_count(const std::string &line, uint32_t &out)
+{
+    size_t i = 0, n = line.size();
+    while (i < n && line[i] == ' ') i++;
+    while (n > i && line[n - 1] == ' ') n--;
+    if (i == n || n - i > 9) return false;
+    uint32_t v = 0;
+    for (; i < n; i++) {
+        if (line[i] < '0' || line[i] > '9') return false;
+        v = v * 10u + (uint32_t)(line[i] - '0');
+    }
+    out = v;
+    return true;
+}
+
 // record file -> samples; stories longer than max_len keep their LAST max_len sentences (sample.c:152-166)
 int read_records(const char *path, uint32_t max_len, uint32_t cap, std::vector<Record> &out)
 {
@@ -57,7 +73,7 @@ int read_records(const char *path, uint32_t max_len, uint32_t cap, std::vector<R
     while (next_line(f, line)) {                                            // header: blank line, "+NS+", count
         if (line == "+NS+") {
             if (!next_line(f, line)) break;
-            declared = (uint32_t)strtoul(line.c_str(), nullptr, 10);
+            if (!parse_count(line, declared)) { fclose(f); return QMANN_EIO; }
             have_count = true;
             break;
         }
@@ -71,7 +87,8 @@ int read_records(const char *path, uint32_t max_len, uint32_t cap, std::vector<R
         if (!next_line(f, line)) { rc = QMANN_EIO; break; }                 // the id: records are numbered by position (sample.c:145)
         if (!next_line(f, line) || line != "+S+") { rc = QMANN_EIO; break; }
         if (!next_line(f, line)) { rc = QMANN_EIO; break; }
-        const uint32_t n_ori = (uint32_t)strtoul(line.c_str(), nullptr, 10);
+        uint32_t n_ori = 0;
+        if (!parse_count(line, n_ori)) { rc = QMANN_EIO; break; }
         const uint32_t skip = n_ori > max_len ? n_ori - max_len : 0;
         for (uint32_t i = 0; i < n_ori && rc == QMANN_OK; i++) {
             if (!next_line(f, line)) { rc = QMANN_EIO; break; }
@@ -164,10 +181,9 @@ int qmann_dataset_load(const char *train_path, const char *test_path, uint32_t m
         }
         uint16_t *qd = out->question_words + q * pitch;
         const uint32_t qkeep = std::min<uint32_t>((uint32_t)r.question.size(), dim_word - 1);           // sample.c:365-371
-        for (uint32_t k = 0, slot = 0; k < qkeep; k++) {
-            const uint32_t w = index_of(r.question[k]);
-            if (w != 0xFFFFu) qd[slot++] = (uint16_t)w;
-        }
+        // a question word keeps its ORIGINAL slot (an unknown word leaves a 0xFFFF hole, which the kernels skip): with
+        // EN_PE the weight of a word is pe_w[word][k] with k its position in the question (sample.c:559)
+        for (uint32_t k = 0; k < qkeep; k++) qd[k] = (uint16_t)index_of(r.question[k]);
         out->answer[q] = 0xFFFFFFFFu;
         if (!r.answer.empty()) {
             const uint32_t w = index_of(r.answer[0]);

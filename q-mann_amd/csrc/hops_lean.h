@@ -347,8 +347,10 @@ k_hops_lean(const HopArgs a, const LeanArgs la)
     if (q >= n_query) return;
     uint32_t r0 = a.row_off[q], S;
     {
+        // a story longer than the caller's bound is cut to the bound (qmann_batch.h): the value tile holds
+        // round16(max_slots) rows per wavefront and max_slots <= 64 here (lean_supported)
         const uint32_t S_in = a.row_off[q + 1] - r0;
-        S = S_in < (uint32_t)kWave ? S_in : (uint32_t)kWave;
+        S = S_in < a.max_slots ? S_in : a.max_slots;
     }
     i32x4 kq[4];
     float u_next;
@@ -370,7 +372,7 @@ k_hops_lean(const HopArgs a, const LeanArgs la)
         if (qn < n_query) {
             r0n = a.row_off[qn];
             const uint32_t S_in = a.row_off[qn + 1] - r0n;
-            Sn = S_in < (uint32_t)kWave ? S_in : (uint32_t)kWave;
+            Sn = S_in < a.max_slots ? S_in : a.max_slots;
         }
         float u = u_next;
         for (uint32_t h = 0; h < H; h++) {

@@ -32,7 +32,7 @@ k_hops_small(const HopArgs a, const uint32_t key_row_bytes)
     const uint32_t q = blockIdx.x;
     const uint32_t r0 = a.row_off[q];
     const uint32_t S_in = a.row_off[q + 1] - r0;
-    const uint32_t S = S_in < (uint32_t)kWave ? S_in : (uint32_t)kWave;   // this kernel is launched for max_slots <= 64
+    const uint32_t S = S_in < a.max_slots ? S_in : a.max_slots;           // cut to the caller's bound (<= 64 for this kernel)
     const uint32_t D = a.D;
     const uint32_t subk = lane / LPRK, chunkk = lane % LPRK;
 

@@ -1,5 +1,11 @@
 // model_host.hip -- include/qmann_model.h: host-side C++ that owns a model's device parameters and
 // runs the whole test-phase forward of a batch through the batched kernels.  No kernels here.
+//
+// The parameters live in ONE device allocation, the "parameter blob": a header (dimensions, formats, options: the
+// qmann_net), the int8 embedding tables, the sign-magnitude linear-map codes and the float answer matrix -- i.e. the
+// QUANTISED model, position independent (offsets, no pointers).  It is what a multi-GPU host broadcasts
+// (qmann_dist.h: one ncclBroadcast of these bytes) and what qmann_model_create_from_params builds a replica from,
+// with no float embedding matrix and no re-quantisation on the receiving side.
 #include "qfmt.h"
 #include "rt.h"
 #include "../../include/qmann_model.h"
@@ -9,19 +15,74 @@
 #include <string.h>
 #include <vector>
 
+namespace {
+
+constexpr uint32_t kBlobMagic = 0x42504D51u;        // "QMPB"
+constexpr uint32_t kBlobVersion = 1u;
+constexpr size_t kBlobAlign = 256;
+
+struct BlobHeader {
+    uint32_t magic, version;
+    uint64_t bytes;                                  // the whole blob, header included
+    uint32_t tied, reserved;
+    qmann_net net;                                   // lin_map pointers are null in a blob (offsets below)
+    uint64_t off_tq, off_ta[QMANN_MAX_HOP], off_tc[QMANN_MAX_HOP], off_lm[QMANN_MAX_HOP], off_wans;
+};
+
+size_t align_up(size_t x) { return (x + kBlobAlign - 1) & ~(kBlobAlign - 1); }
+
+// section offsets of a model of these dimensions; returns the blob size
+size_t blob_layout(const qmann_net &n, BlobHeader *h)
+{
+    const size_t tab = align_up((size_t)n.dim_input * n.dim_emb_pad), lm = align_up((size_t)n.dim_emb * n.dim_emb_pad);
+    size_t o = align_up(sizeof(BlobHeader));
+    auto take = [&](size_t bytes) { const size_t at = o; o += bytes; return (uint64_t)at; };
+    const uint64_t tq = take(tab);
+    uint64_t ta[QMANN_MAX_HOP] = {}, tc[QMANN_MAX_HOP] = {}, l[QMANN_MAX_HOP] = {};
+    for (uint32_t i = 0; i < n.n_hop; i++) { ta[i] = take(tab); tc[i] = take(tab); }
+    for (uint32_t i = 0; i < n.n_hop; i++) l[i] = n.en_lin_map ? take(lm) : 0;
+    const uint64_t wa = take(align_up((size_t)n.dim_input * n.dim_emb * sizeof(float)));
+    if (h) {
+        h->off_tq = tq; h->off_wans = wa;
+        for (uint32_t i = 0; i < QMANN_MAX_HOP; i++) { h->off_ta[i] = ta[i]; h->off_tc[i] = tc[i]; h->off_lm[i] = l[i]; }
+        h->bytes = o;
+    }
+    return o;
+}
+
+// the calling thread's current device for the length of a call into a device-bound model
+struct DeviceScope {
+    int prev = -1;
+    bool changed = false;
+    explicit DeviceScope(int device)
+    {
+        if (device < 0) return;
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) { QM_HIP(hipSetDevice(device)); changed = true; }
+    }
+    ~DeviceScope() { if (changed && prev >= 0) (void)hipSetDevice(prev); }
+    DeviceScope(const DeviceScope &) = delete;
+};
+
+}  // namespace
+
 struct qmann_model {
     qmann_net net{};
-    qmann_net emb_net{};     // formats the embedding kernels quantise the memories to (see qmann_model_create)
+    qmann_net emb_net{};     // formats the embedding kernels quantise the memories to (see bind_sections)
     uint32_t H = 0, D = 0, Dp = 0, V = 0;
+    int device = 0;          // the GPU the parameters and the workspace live on; every call runs there
     // Layer-wise weight tying (TYPE_WEIGHT_TYING 2, MemN2N/define.h:287: after every update the reference copies hop 0's
     // embedding matrices over the other hops', MemN2N.c:1770-1773): with equal formats on every hop the hops' memories
     // are the same bytes, so they are embedded ONCE and every hop reads the one plane (hop stride 0)
     bool tied = false;
-    // parameters on the device
-    float *w_q = nullptr, *w_ans = nullptr;
-    float *w_a[QMANN_MAX_HOP] = {}, *w_c[QMANN_MAX_HOP] = {};
-    int8_t *lin_map[QMANN_MAX_HOP] = {};
-    int8_t *t_q = nullptr, *t_a[QMANN_MAX_HOP] = {}, *t_c[QMANN_MAX_HOP] = {};
+    // the parameter blob (one allocation) and the sections inside it
+    uint8_t *blob = nullptr;
+    size_t blob_bytes = 0;
+    const float *w_ans = nullptr;
+    const int8_t *t_q = nullptr, *t_a[QMANN_MAX_HOP] = {}, *t_c[QMANN_MAX_HOP] = {};
+    // float matrices [D][V] for the float embedding kernels (bag-of-words rows that are no plain bags of words): the grid
+    // values of the tables, made on the first qmann_model_forward_bow
+    float *w_q = nullptr, *w_a[QMANN_MAX_HOP] = {}, *w_c[QMANN_MAX_HOP] = {};
     // workspace, grown on demand
     int8_t *keys = nullptr, *vals = nullptr;
     uint64_t *planes = nullptr;
@@ -36,20 +97,60 @@ namespace {
 
 bool packed_mode(const qmann_net &n) { return n.attention_mode == QMANN_ATT_HAMMING_V0 || n.attention_mode == QMANN_ATT_HAMMING_V1; }
 
+// false when the allocation failed (the pointer is then null and the caller must not record the new capacity)
 template <typename T>
-void regrow(T **p, size_t n)
+bool regrow(T **p, size_t n)
 {
     if (*p) QM_HIP(hipFree(*p));
     *p = nullptr;
-    QM_HIP(hipMalloc((void **)p, (n ? n : 1) * sizeof(T)));
+    const hipError_t e = hipMalloc((void **)p, (n ? n : 1) * sizeof(T));
+    if (e != hipSuccess) {
+        fprintf(stderr, "[*E] HIP : qmann_model workspace of %zu bytes : %s\n", (n ? n : 1) * sizeof(T), hipGetErrorString(e));
+        (void)hipGetLastError();
+        *p = nullptr;
+        return false;
+    }
+    return true;
 }
 
 float *upload(const float *host, size_t n, hipStream_t st)
 {
     float *d = nullptr;
     QM_HIP(hipMalloc((void **)&d, n * sizeof(float)));
+    if (!d) return nullptr;                  // (recorded by QM_HIP: the entry point returns QMANN_EHIP)
     QM_HIP(hipMemcpyAsync(d, host, n * sizeof(float), hipMemcpyHostToDevice, st));
     return d;
+}
+
+int check_net(const qmann_net *net)
+{
+    if (net->n_hop == 0 || net->n_hop > QMANN_MAX_HOP || net->dim_emb == 0 || net->dim_emb > net->dim_emb_pad || net->dim_input == 0)
+        return QMANN_EINVAL;
+    if (net->dim_emb_pad != 64 && net->dim_emb_pad != 128 && net->dim_emb_pad != 256) return QMANN_EUNSUPPORTED;
+    return QMANN_OK;
+}
+
+// dimensions, the embedding formats and the section pointers of a model whose blob is in place
+void bind_sections(qmann_model *m, const BlobHeader &h)
+{
+    m->net = h.net;
+    m->emb_net = h.net;
+    // mode 1 runs its attention on the embedding outputs as they are (weight grid, no attention
+    // re-quantisation: lib/layer.c:177-195 forces f_fixed = false on both dot_mat_vec layers)
+    if (h.net.attention_mode == QMANN_ATT_FLOAT)
+        for (uint32_t i = 0; i < h.net.n_hop; i++) m->emb_net.att[i] = m->emb_net.act[i] = h.net.w[i];
+    m->H = h.net.n_hop; m->D = h.net.dim_emb; m->Dp = h.net.dim_emb_pad; m->V = h.net.dim_input;
+    m->tied = h.tied != 0;
+    if (m->tied) m->emb_net.n_hop = 1;       // the embedding kernels fill one plane
+    m->blob_bytes = (size_t)h.bytes;
+    m->t_q = (const int8_t *)(m->blob + h.off_tq);
+    m->w_ans = (const float *)(m->blob + h.off_wans);
+    for (uint32_t i = 0; i < m->H; i++) {
+        m->t_a[i] = (const int8_t *)(m->blob + h.off_ta[i]);
+        m->t_c[i] = (const int8_t *)(m->blob + h.off_tc[i]);
+        m->net.lin_map[i] = h.net.en_lin_map ? (const int8_t *)(m->blob + h.off_lm[i]) : nullptr;
+    }
+    for (uint32_t i = m->H; i < QMANN_MAX_HOP; i++) m->net.lin_map[i] = nullptr;
 }
 
 // packed planes pay off when they are smaller than the bytes (num_bit < 8) and the memory is long enough for
@@ -62,23 +163,50 @@ bool use_planes(const qmann_model *m, uint32_t max_slots)
 
 int ensure(qmann_model *m, size_t rows, uint32_t n_query, bool planes)
 {
+    // A capacity is recorded only when every buffer it describes exists: after a failed allocation the next call tries again
+    // (the test is on every pointer, not only the first of a group) and this one returns QMANN_EHIP.
     const size_t n_plane = m->tied ? 1 : m->H;          // hop planes held
-    if (rows > m->cap_rows || !m->keys) {               // (a first batch may hold no rows at all: the planes still exist)
+    if (rows > m->cap_rows || !m->keys || !m->vals) {   // (a first batch may hold no rows at all: the planes still exist)
         const size_t cap = rows + rows / 4 + 1;
-        regrow(&m->keys, n_plane * cap * m->Dp);
-        regrow(&m->vals, n_plane * cap * m->Dp);
+        m->cap_rows = 0;
+        const bool ok_k = regrow(&m->keys, n_plane * cap * m->Dp), ok_v = regrow(&m->vals, n_plane * cap * m->Dp);
+        if (!ok_k || !ok_v) return QMANN_EHIP;
         m->cap_rows = cap;
     }
     if (planes) {
         const size_t words = n_plane * m->cap_rows * (m->Dp / 64) * m->net.num_bit;
-        if (words > m->cap_plane_words || !m->planes) { regrow(&m->planes, words); m->cap_plane_words = words; }
+        if (words > m->cap_plane_words || !m->planes) {
+            m->cap_plane_words = 0;
+            if (!regrow(&m->planes, words)) return QMANN_EHIP;
+            m->cap_plane_words = words;
+        }
     }
-    if (n_query > m->cap_query || !m->u0) {
+    if (n_query > m->cap_query || !m->u0 || !m->u) {
         const size_t cap = (size_t)n_query + n_query / 4;
-        regrow(&m->u0, cap * m->D);
-        regrow(&m->u, cap * m->D);
+        m->cap_query = 0;
+        const bool ok_0 = regrow(&m->u0, cap * m->D), ok_u = regrow(&m->u, cap * m->D);
+        if (!ok_0 || !ok_u) return QMANN_EHIP;
         m->cap_query = cap;
     }
+    return QMANN_OK;
+}
+
+// the float matrices of the float embedding kernels: the tables' grid values (qmann_dequantize_table_f32)
+int ensure_float_matrices(qmann_model *m, void *stream)
+{
+    if (m->w_q) return QMANN_OK;
+    const size_t DV = (size_t)m->D * m->V;
+    float *all = nullptr;
+    if (!regrow(&all, DV * (1 + 2 * (size_t)m->H))) return QMANN_EHIP;
+    int rc = qmann_dequantize_table_f32(m->t_q, all, m->D, m->Dp, m->V, m->net.w[0], stream);
+    for (uint32_t h = 0; h < m->H && rc == QMANN_OK; h++) {
+        float *a = all + DV * (1 + 2 * (size_t)h), *c = a + DV;
+        rc = qmann_dequantize_table_f32(m->t_a[h], a, m->D, m->Dp, m->V, m->net.w[h], stream);
+        if (rc == QMANN_OK) rc = qmann_dequantize_table_f32(m->t_c[h], c, m->D, m->Dp, m->V, m->net.w[h], stream);
+        m->w_a[h] = a; m->w_c[h] = c;
+    }
+    if (rc != QMANN_OK) { QM_HIP(hipFree(all)); for (uint32_t h = 0; h < m->H; h++) m->w_a[h] = m->w_c[h] = nullptr; return rc; }
+    m->w_q = all;                            // (owns the one allocation)
     return QMANN_OK;
 }
 
@@ -101,66 +229,122 @@ int hops_and_answer(qmann_model *m, uint32_t rows_total, const uint32_t *row_off
     return qmann_answer_f32(&m->net, m->w_ans, m->u, answer, pred, nullptr, cost, match, n_query, stream);
 }
 
+int resolve_device(int device, int *out)
+{
+    if (device < 0) return hipGetDevice(out) == hipSuccess ? QMANN_OK : QMANN_EHIP;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return QMANN_EHIP;
+    if (device >= n) return QMANN_EINVAL;
+    *out = device;
+    return QMANN_OK;
+}
+
 }  // namespace
 
 extern "C" {
 
-int qmann_model_create(qmann_model **out, const qmann_net *net, const qmann_weights *w, void *stream)
+int qmann_model_create_on(qmann_model **out, int device, const qmann_net *net, const qmann_weights *w, void *stream)
 {
     QmBatched qm_scope;
     if (!out || !net || !w) return QMANN_EINVAL;
     *out = nullptr;
-    if (net->n_hop == 0 || net->n_hop > QMANN_MAX_HOP || net->dim_emb == 0 || net->dim_emb > net->dim_emb_pad) return QMANN_EINVAL;
-    if (net->dim_emb_pad != 64 && net->dim_emb_pad != 128 && net->dim_emb_pad != 256) return QMANN_EUNSUPPORTED;
+    int rc = check_net(net);
+    if (rc) return rc;
     if (w->n_hop != net->n_hop || w->dim_emb != net->dim_emb || w->dim_input != net->dim_input) return QMANN_EINVAL;
     if (!w->w_q || !w->w_ans) return QMANN_EINVAL;
     for (uint32_t h = 0; h < net->n_hop; h++)
         if (!w->w_a[h] || !w->w_c[h] || (net->en_lin_map && !w->w_h[h])) return QMANN_EINVAL;
+    int dev = 0;
+    if ((rc = resolve_device(device, &dev)) != QMANN_OK) return rc;
+    DeviceScope on(dev);
 
     qmann_model *m = new (std::nothrow) qmann_model();
     if (!m) return QMANN_ERANGE;
-    m->net = *net;
-    m->emb_net = *net;
-    // mode 1 runs its attention on the embedding outputs as they are (weight grid, no attention
-    // re-quantisation: lib/layer.c:177-195 forces f_fixed = false on both dot_mat_vec layers)
-    if (net->attention_mode == QMANN_ATT_FLOAT)
-        for (uint32_t h = 0; h < net->n_hop; h++) m->emb_net.att[h] = m->emb_net.act[h] = net->w[h];
-    m->H = net->n_hop; m->D = net->dim_emb; m->Dp = net->dim_emb_pad; m->V = net->dim_input;
-    hipStream_t st = (hipStream_t)stream;
-    const size_t DV = (size_t)m->D * m->V, DD = (size_t)m->D * m->D;
-    m->tied = net->n_hop > 1 && !getenv("QMANN_NO_TIED");
-    for (uint32_t h = 1; h < net->n_hop && m->tied; h++) {
-        const qmann_net &e = m->emb_net;
-        m->tied = e.w[h].iwl == e.w[0].iwl && e.w[h].frac == e.w[0].frac && e.att[h].iwl == e.att[0].iwl && e.att[h].frac == e.att[0].frac &&
-                  e.act[h].iwl == e.act[0].iwl && e.act[h].frac == e.act[0].frac &&
-                  memcmp(w->w_a[h], w->w_a[0], DV * sizeof(float)) == 0 && memcmp(w->w_c[h], w->w_c[0], DV * sizeof(float)) == 0;
+    m->device = dev;
+    BlobHeader hd{};
+    hd.magic = kBlobMagic; hd.version = kBlobVersion;
+    hd.net = *net;
+    for (uint32_t h = 0; h < QMANN_MAX_HOP; h++) hd.net.lin_map[h] = nullptr;
+    blob_layout(*net, &hd);
+    const uint32_t H = net->n_hop, D = net->dim_emb, Dp = net->dim_emb_pad, V = net->dim_input;
+    const size_t DV = (size_t)D * V, DD = (size_t)D * D;
+    // tied embedding matrices (see the struct); mode 1 compares the formats its embedding really uses
+    bool tied = H > 1 && !getenv("QMANN_NO_TIED");
+    for (uint32_t h = 1; h < H && tied; h++) {
+        const bool fl = net->attention_mode == QMANN_ATT_FLOAT;
+        const qmann_fmt a0 = fl ? net->w[0] : net->att[0], ah = fl ? net->w[h] : net->att[h];
+        const qmann_fmt c0 = fl ? net->w[0] : net->act[0], ch = fl ? net->w[h] : net->act[h];
+        tied = net->w[h].iwl == net->w[0].iwl && net->w[h].frac == net->w[0].frac && ah.iwl == a0.iwl && ah.frac == a0.frac &&
+               ch.iwl == c0.iwl && ch.frac == c0.frac &&
+               memcmp(w->w_a[h], w->w_a[0], DV * sizeof(float)) == 0 && memcmp(w->w_c[h], w->w_c[0], DV * sizeof(float)) == 0;
     }
-    if (m->tied) m->emb_net.n_hop = 1;       // the embedding kernels fill one plane
-    std::vector<float *> staged;             // float copies needed only for the conversion below
-    m->w_q = upload(w->w_q, DV, st);
-    m->w_ans = upload(w->w_ans, DV, st);
-    QM_HIP(hipMalloc((void **)&m->t_q, (size_t)m->V * m->Dp));
-    int rc = qmann_quantize_table_i8(m->w_q, m->t_q, m->D, m->Dp, m->V, net->w[0], stream);
-    for (uint32_t h = 0; h < m->H && rc == QMANN_OK; h++) {
-        m->w_a[h] = upload(w->w_a[h], DV, st);
-        m->w_c[h] = upload(w->w_c[h], DV, st);
-        QM_HIP(hipMalloc((void **)&m->t_a[h], (size_t)m->V * m->Dp));
-        QM_HIP(hipMalloc((void **)&m->t_c[h], (size_t)m->V * m->Dp));
-        rc = qmann_quantize_table_i8(m->w_a[h], m->t_a[h], m->D, m->Dp, m->V, net->w[h], stream);
-        if (rc == QMANN_OK) rc = qmann_quantize_table_i8(m->w_c[h], m->t_c[h], m->D, m->Dp, m->V, net->w[h], stream);
-        m->net.lin_map[h] = nullptr;
+    hd.tied = tied ? 1u : 0u;
+
+    hipStream_t st = (hipStream_t)stream;
+    QM_HIP(hipMalloc((void **)&m->blob, (size_t)hd.bytes));
+    if (!m->blob) { delete m; return QMANN_EHIP; }
+    QM_HIP(hipMemsetAsync(m->blob, 0, (size_t)hd.bytes, st));                 // (padding bytes are part of what is broadcast)
+    QM_HIP(hipMemcpyAsync(m->blob, &hd, sizeof hd, hipMemcpyHostToDevice, st));
+    bind_sections(m, hd);
+    std::vector<float *> staged;             // float copies needed only for the conversions below
+    auto table = [&](const float *host, const int8_t *dst, qmann_fmt f) {
+        float *d = upload(host, DV, st);
+        if (!d) return (int)QMANN_EHIP;
+        staged.push_back(d);
+        return qmann_quantize_table_i8(d, (int8_t *)dst, D, Dp, V, f, stream);
+    };
+    rc = table(w->w_q, m->t_q, net->w[0]);                                    // emb_q uses the first hop's format (MemN2N.c:826)
+    for (uint32_t h = 0; h < H && rc == QMANN_OK; h++) {
+        rc = table(w->w_a[h], m->t_a[h], net->w[h]);
+        if (rc == QMANN_OK) rc = table(w->w_c[h], m->t_c[h], net->w[h]);
         if (rc == QMANN_OK && net->en_lin_map) {
             float *wh = upload(w->w_h[h], DD, st);
+            if (!wh) { rc = QMANN_EHIP; break; }
             staged.push_back(wh);
-            QM_HIP(hipMalloc((void **)&m->lin_map[h], (size_t)m->D * m->Dp));
-            rc = qmann_quantize_i8(wh, m->lin_map[h], m->D, m->D, m->Dp, net->w[h], QMANN_CODE_SIGNMAG, stream);
-            m->net.lin_map[h] = m->lin_map[h];
+            rc = qmann_quantize_i8(wh, (int8_t *)m->net.lin_map[h], D, D, Dp, net->w[h], QMANN_CODE_SIGNMAG, stream);
         }
     }
+    if (rc == QMANN_OK) QM_HIP(hipMemcpyAsync((void *)m->w_ans, w->w_ans, DV * sizeof(float), hipMemcpyHostToDevice, st));
     QM_HIP(hipStreamSynchronize(st));        // the host arrays and the staged floats are free again
     for (float *p : staged) QM_HIP(hipFree(p));
-    if (rc == QMANN_OK) rc = qm_scope.rc();
+    if (qm_scope.rc() != QMANN_OK) rc = qm_scope.rc();     // (a failed allocation shows up as EHIP, not as the EINVAL of the null it left)
     if (rc != QMANN_OK) { qmann_model_destroy(m); return rc; }
+    *out = m;
+    return QMANN_OK;
+}
+
+int qmann_model_create(qmann_model **out, const qmann_net *net, const qmann_weights *w, void *stream)
+{
+    return qmann_model_create_on(out, -1, net, w, stream);
+}
+
+int qmann_model_create_from_params(qmann_model **out, int device, const void *blob, size_t bytes, void *stream)
+{
+    QmBatched qm_scope;
+    if (!out || !blob || bytes < sizeof(BlobHeader)) return QMANN_EINVAL;
+    *out = nullptr;
+    int dev = 0, rc;
+    if ((rc = resolve_device(device, &dev)) != QMANN_OK) return rc;
+    DeviceScope on(dev);
+    hipStream_t st = (hipStream_t)stream;
+    BlobHeader hd;
+    QM_HIP(hipMemcpyAsync(&hd, blob, sizeof hd, hipMemcpyDefault, st));
+    QM_HIP(hipStreamSynchronize(st));
+    if (qm_scope.rc()) return qm_scope.rc();
+    if (hd.magic != kBlobMagic || hd.version != kBlobVersion || hd.bytes != bytes) return QMANN_EINVAL;
+    if ((rc = check_net(&hd.net)) != QMANN_OK) return rc;
+    BlobHeader want = hd;
+    if (blob_layout(hd.net, &want) != bytes || memcmp(&want, &hd, sizeof hd) != 0) return QMANN_EINVAL;   // offsets must be the canonical ones
+
+    qmann_model *m = new (std::nothrow) qmann_model();
+    if (!m) return QMANN_ERANGE;
+    m->device = dev;
+    QM_HIP(hipMalloc((void **)&m->blob, bytes));
+    if (!m->blob) { delete m; return QMANN_EHIP; }
+    QM_HIP(hipMemcpyAsync(m->blob, blob, bytes, hipMemcpyDefault, st));       // (same device, a peer device, or host memory)
+    QM_HIP(hipStreamSynchronize(st));
+    bind_sections(m, hd);
+    if (qm_scope.rc()) { qmann_model_destroy(m); return qm_scope.rc(); }
     *out = m;
     return QMANN_OK;
 }
@@ -168,11 +352,28 @@ int qmann_model_create(qmann_model **out, const qmann_net *net, const qmann_weig
 void qmann_model_destroy(qmann_model *m)
 {
     if (!m) return;
+    DeviceScope on(m->device);
     auto drop = [](void *p) { if (p) QM_HIP(hipFree(p)); };
-    drop(m->w_q); drop(m->w_ans); drop(m->t_q);
-    for (uint32_t h = 0; h < QMANN_MAX_HOP; h++) { drop(m->w_a[h]); drop(m->w_c[h]); drop(m->lin_map[h]); drop(m->t_a[h]); drop(m->t_c[h]); }
+    drop(m->blob); drop(m->w_q);             // (w_a / w_c point into w_q's allocation)
     drop(m->keys); drop(m->vals); drop(m->planes); drop(m->u0); drop(m->u); drop(m->bow_words); drop(m->bow_irr);
     delete m;
+}
+
+int qmann_model_device(const qmann_model *m) { return m ? m->device : -1; }
+
+int qmann_model_params(const qmann_model *m, const void **blob, size_t *bytes)
+{
+    if (!m || !blob || !bytes) return QMANN_EINVAL;
+    *blob = m->blob; *bytes = m->blob_bytes;
+    return QMANN_OK;
+}
+
+int qmann_model_net(const qmann_model *m, qmann_net *net, const float **w_ans)
+{
+    if (!m || !net) return QMANN_EINVAL;
+    *net = m->net;
+    if (w_ans) *w_ans = m->w_ans;
+    return QMANN_OK;
 }
 
 int qmann_model_forward_words(qmann_model *m, const uint16_t *story_words, uint32_t rows_total, uint32_t max_words,
@@ -184,6 +385,7 @@ int qmann_model_forward_words(qmann_model *m, const uint16_t *story_words, uint3
     if (!m) return QMANN_EINVAL;
     if (n_query == 0) return QMANN_OK;                  // (an empty batch needs no arrays)
     if ((!story_words && rows_total) || !question_words || !row_off || !pred) return QMANN_EINVAL;   // (every story may be empty)
+    DeviceScope on(m->device);
     int rc = ensure(m, rows_total, n_query, use_planes(m, max_slots));
     if (rc) return rc;
     rc = qmann_embed_story_idx(&m->emb_net, story_words, rows_total, max_words, 1, m->t_a, m->t_c, m->keys, m->vals,
@@ -203,16 +405,19 @@ int qmann_model_forward_bow(qmann_model *m, const float *story, uint32_t rows_to
     if (!m) return QMANN_EINVAL;
     if (n_query == 0) return QMANN_OK;
     if ((!story && rows_total) || !question || !row_off || !pred) return QMANN_EINVAL;
+    DeviceScope on(m->device);
     int rc = ensure(m, rows_total, n_query, use_planes(m, max_slots));
     if (rc) return rc;
+    if ((rc = ensure_float_matrices(m, stream)) != QMANN_OK) return rc;
     // Rows that are plain bags of words (integer counts) go through the word-index kernels -- the int8 gather / matrix-core
     // path, bit-identical to the float path and several times faster; the others (fractional entries: position encoding,
     // long rows) are listed on the device and redone by the float kernels.  No host round trip.
     const size_t n_all = (size_t)rows_total + n_query;
-    if (n_all > m->cap_bow || !m->bow_words) {
+    if (n_all > m->cap_bow || !m->bow_words || !m->bow_irr) {
         const size_t cap = n_all + n_all / 4 + 1;
-        regrow(&m->bow_words, cap * 16);
-        regrow(&m->bow_irr, cap + 2);
+        m->cap_bow = 0;
+        const bool ok_w = regrow(&m->bow_words, cap * 16), ok_i = regrow(&m->bow_irr, cap + 2);
+        if (!ok_w || !ok_i) return QMANN_EHIP;
         m->cap_bow = cap;
     }
     hipStream_t st = (hipStream_t)stream;

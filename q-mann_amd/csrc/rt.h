@@ -12,7 +12,9 @@
 inline thread_local int qm_batched_depth = 0;
 inline thread_local int qm_batched_err = 0;
 struct QmBatched {
-    QmBatched() { if (qm_batched_depth++ == 0) qm_batched_err = 0; }
+    // The outermost scope starts clean: hipGetLastError() reads AND clears the thread's last error, so a failure an earlier
+    // call reported (or one the host application left behind) is not reported again by this call's launch checks.
+    QmBatched() { if (qm_batched_depth++ == 0) { qm_batched_err = 0; (void)hipGetLastError(); } }
     ~QmBatched() { --qm_batched_depth; }
     QmBatched(const QmBatched &) = delete;
     int rc(int ok = 0) const { return qm_batched_err ? -5 /* QMANN_EHIP */ : ok; }
@@ -29,7 +31,8 @@ struct QmBatched {
         }                                                                             \
     } while (0)
 
-#define QM_LAUNCH_CHECK() QM_HIP(hipPeekAtLastError())
+// (hipGetLastError, not hipPeekAtLastError: the error is consumed when it is reported, a later valid call is not blamed for it)
+#define QM_LAUNCH_CHECK() QM_HIP(hipGetLastError())
 
 static inline void qm_fail(const char *fn, const char *msg)
 {

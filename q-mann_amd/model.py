@@ -42,6 +42,13 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+class _DevArray:
+    """a raw device pointer as something torch.as_tensor can alias (no copy; the owner keeps the memory alive)"""
+
+    def __init__(self, ptr: int, shape, typestr: str):
+        self.__cuda_array_interface__ = {"data": (int(ptr), False), "shape": tuple(shape), "typestr": typestr, "version": 2}
+
+
 def babi_cfg(dim_input, attention_mode=2, softmax_base=0, iwl=5, n_hop=3, D=60, en_mq=True):
     """run.sh default iwl=5 (MemN2N/run.sh:6,18); EN_MQ shifts the weight formats of hops 0 and 2
     (MemN2N/MemN2N.c:748-754)."""
@@ -152,6 +159,21 @@ class QNet:
                 wf = up(weights["w_h"][h])
                 self.lin_map_i8.append(self.quantize_i8(wf, cfg["fmt_w"][h], abi.CODE_SIGNMAG))
                 n.lin_map[h] = self.lin_map_i8[h].data_ptr()
+
+    @classmethod
+    def from_model(cls, cfg: dict, hm: "HostModel", stream=None):
+        """A QNet that computes from the parameters of a library model object (qmann_model_net): the linear-map codes and
+        the answer matrix are the ones inside `hm`'s parameter blob -- e.g. a replica built from a broadcast blob."""
+        self = cls.__new__(cls)
+        self.cfg, self.dev, self.stream = cfg, hm.dev, stream
+        self.H, self.D, self.V = cfg["n_hop"], cfg["dim_emb"], cfg["dim_input"]
+        self.Dp = pad16(self.D)
+        self.net, wa = hm.net_and_w_ans()
+        self._owner = hm                                   # keeps the blob alive
+        self.w_ans = torch.as_tensor(_DevArray(wa, (self.V, self.D), "<f4"), device=self.dev)
+        self.w_q = self.w_a = self.w_c = None
+        self.lin_map_i8 = []
+        return self
 
     # ---- helpers -------------------------------------------------------------------------
     def _s(self):
@@ -308,8 +330,41 @@ class HostModel:
         self._net = _net_from_cfg(cfg)
         ws = _weights_struct(w, H, D, V, bool(cfg.get("en_lin_map", True)))
         h = C.c_void_p()
-        abi.check(abi.lib.qmann_model_create(C.byref(h), C.byref(self._net), C.byref(ws), self._s()), "qmann_model_create")
+        idx = self.dev.index if self.dev.index is not None else -1
+        abi.check(abi.lib.qmann_model_create_on(C.byref(h), idx, C.byref(self._net), C.byref(ws), self._s()), "qmann_model_create_on")
         self.h = h
+
+    @classmethod
+    def from_params(cls, cfg: dict, blob_ptr: int, nbytes: int, device="cuda:0", stream=None):
+        """qmann_model_create_from_params: a replica from a parameter blob (device or host pointer)."""
+        self = cls.__new__(cls)
+        self.cfg, self.dev, self.stream = cfg, torch.device(device), stream
+        self.D = cfg["dim_emb"]
+        h = C.c_void_p()
+        idx = self.dev.index if self.dev.index is not None else -1
+        abi.check(abi.lib.qmann_model_create_from_params(C.byref(h), idx, C.c_void_p(blob_ptr), nbytes, self._s()),
+                  "qmann_model_create_from_params")
+        self.h = h
+        return self
+
+    def params(self):
+        """(device pointer, bytes) of the model's quantised parameter blob (owned by the model)."""
+        p, n = C.c_void_p(), C.c_size_t()
+        abi.check(abi.lib.qmann_model_params(self.h, C.byref(p), C.byref(n)), "qmann_model_params")
+        return p.value, n.value
+
+    def params_bytes(self) -> bytes:
+        """the blob copied to the host (through boundary B's own D2H verb)"""
+        p, n = self.params()
+        buf = np.empty((n + 3) // 4, np.float32)
+        abi.lib.cuda_copy_dev2host(buf.ctypes.data_as(C.c_void_p), C.c_void_p(p), (n + 3) // 4)
+        return buf.tobytes()[:n]
+
+    def net_and_w_ans(self):
+        """(abi.Net with the device lin_map pointers of this model, device pointer of its answer matrix)"""
+        net, wa = abi.Net(), C.c_void_p()
+        abi.check(abi.lib.qmann_model_net(self.h, C.byref(net), C.byref(wa)), "qmann_model_net")
+        return net, wa.value
 
     def _s(self):
         return C.c_void_p(self.stream) if self.stream else None

@@ -1,6 +1,11 @@
 """Multi-GPU plumbing: queries are independent, so ranks never exchange activations.  The one
-collective is a broadcast of the parameter blob from rank 0 at start-up (RCCL over xGMI on the
-GPU box, gloo in the CPU tests); shards are contiguous query ranges."""
+collective is a broadcast of the parameters from rank 0 at start-up; shards are contiguous query ranges.
+
+On GPUs the broadcast is the LIBRARY's (include/qmann_dist.h, csrc/dist.hip): rank 0's model hands out its QUANTISED
+parameter blob (int8 tables, linear-map codes, formats, float answer matrix), `qmann_comm_broadcast_params` moves it with
+ncclBroadcast (RCCL over xGMI) and every other rank builds its replica from the bytes (`replicate_model`).  torch.distributed
+only carries the 128-byte rendezvous id.  The float-blob functions below (`broadcast_params`) remain for the CPU-only plumbing
+test over gloo, where no GPU model can exist."""
 from __future__ import annotations
 
 import time
@@ -81,3 +86,82 @@ def gather_predictions(pred_local: torch.Tensor, n_query: int, rank: int, world:
     parts = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(parts, buf)
     return torch.cat([parts[r][: sizes[r][1] - sizes[r][0]] for r in range(world)])
+
+
+class Comm:
+    """include/qmann_dist.h communicator of this rank: the id comes from rank 0 through the process group (any backend),
+    the communicator itself is the library's (ncclCommInitRank inside libqmann_hip.so)."""
+
+    def __init__(self, rank: int, world: int, device_index: int):
+        import ctypes as C
+        import os
+        import torch.distributed as dist
+        from . import abi
+        # one RCCL per process: the copy PyTorch ships and has already loaded, unless the caller chose another
+        tl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if os.path.exists(tl):
+            os.environ.setdefault("QMANN_RCCL_PATH", tl)
+        self.abi, self.rank, self.world, self.device_index = abi, rank, world, device_index
+        ident = np.zeros(abi.COMM_ID_BYTES, np.uint8)
+        if rank == 0:
+            abi.check(abi.lib.qmann_comm_get_id(ident.ctypes.data_as(C.c_void_p)), "qmann_comm_get_id")
+        on_gpu = dist.get_backend() == "nccl"
+        t = torch.from_numpy(ident)
+        if on_gpu:
+            t = t.to(torch.device("cuda", device_index))
+        dist.broadcast(t, src=0)
+        ident = t.cpu().numpy().copy()
+        h = C.c_void_p()
+        abi.check(abi.lib.qmann_comm_init_rank(C.byref(h), world, rank, ident.ctypes.data_as(C.c_void_p), device_index),
+                  "qmann_comm_init_rank")
+        self.h = h
+
+    def info(self):
+        import ctypes as C
+        r, n, d, v = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        self.abi.lib.qmann_comm_info(self.h, C.byref(r), C.byref(n), C.byref(d), C.byref(v))
+        return dict(rank=r.value, n_ranks=n.value, device=d.value, rccl_version=v.value)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.abi.lib.qmann_comm_destroy(self.h)
+            self.h = None
+
+
+def replicate_model(hm, cfg, dev, rank: int, world: int, comm: "Comm | None", model_mod):
+    """Rank 0 holds `hm` (a model.HostModel); every rank returns a HostModel computing from the same quantised bytes.
+    comm given: the library's RCCL broadcast of the blob; comm None with world > 1 (one-GPU rehearsal over gloo): the blob
+    bytes travel through the process group and the replica is built from host memory.  Returns (model, ms, how)."""
+    if world == 1:
+        return hm, None, "single rank"
+    import ctypes as C
+    import torch.distributed as dist
+    from . import abi
+    if comm is not None:
+        blob, n = C.c_void_p(), C.c_size_t()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        abi.check(abi.lib.qmann_comm_broadcast_params(comm.h, 0, hm.h if rank == 0 else None, C.byref(blob), C.byref(n), None),
+                  "qmann_comm_broadcast_params")
+        ms = (time.perf_counter() - t0) * 1e3
+        try:
+            if rank != 0:
+                hm = model_mod.HostModel.from_params(cfg, blob.value, n.value, device=str(dev))
+        finally:
+            abi.lib.qmann_params_free(blob)
+        return hm, ms, f"qmann_comm_broadcast_params: ncclBroadcast of the quantised blob ({n.value} bytes)"
+    # rehearsal: same blob, carried by the process group
+    size = torch.zeros(1, dtype=torch.int64)
+    raw = hm.params_bytes() if rank == 0 else b""
+    if rank == 0:
+        size[0] = len(raw)
+    dist.broadcast(size, src=0)
+    buf = torch.frombuffer(bytearray(raw), dtype=torch.uint8) if rank == 0 else torch.zeros(int(size[0]), dtype=torch.uint8)
+    t0 = time.perf_counter()
+    dist.broadcast(buf, src=0)
+    ms = (time.perf_counter() - t0) * 1e3
+    if rank != 0:
+        host = buf.numpy()
+        hm = model_mod.HostModel.from_params(cfg, host.ctypes.data, host.size, device=str(dev))
+    return hm, ms, f"process-group broadcast of the quantised blob ({int(size[0])} bytes; rehearsal, not RCCL)"

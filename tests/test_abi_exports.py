@@ -22,7 +22,8 @@ def test_library_loads_and_reports_66(abi):
 def test_every_declared_symbol_is_exported(abi):
     declared = (abi.header_symbols("qmann_abi.h") + abi.header_symbols("qmann_batch.h")
                 + abi.header_symbols("qmann_weights.h") + abi.header_symbols("qmann_model.h")
-                + abi.header_symbols("qmann_dataset.h"))
+                + abi.header_symbols("qmann_dataset.h") + abi.header_symbols("qmann_dist.h"))
+    assert "qmann_comm_broadcast_params" in declared and "qmann_model_create_from_params" in declared
     assert "qmann_weights_save" in declared and "qmann_weights_load" in declared
     assert "qmann_model_create" in declared and "qmann_model_forward_words" in declared
     cuda = [s for s in declared if s.startswith("cuda_")]
@@ -37,7 +38,7 @@ def test_symbols_are_unmangled_c(abi):
     names = {l.split()[-1] for l in out.splitlines() if " T " in l}
     for s in (abi.header_symbols("qmann_abi.h") + abi.header_symbols("qmann_batch.h")
               + abi.header_symbols("qmann_weights.h") + abi.header_symbols("qmann_model.h")
-                + abi.header_symbols("qmann_dataset.h")):
+                + abi.header_symbols("qmann_dataset.h") + abi.header_symbols("qmann_dist.h")):
         assert s in names, s
 
 
@@ -82,3 +83,24 @@ def test_lds_sizing_helper(abi):
     assert small % 16 == 0 and big % 16 == 0
     assert big - small == 10000 - 64 + 0 or big > small
     assert big < 160 * 1024
+
+
+def test_rccl_is_not_a_load_time_dependency(abi):
+    """librccl (0.5 GB) is loaded with dlopen by the first qmann_comm_* call, never by loading the library: the reference's
+    single-GPU host links the drop-in verbs and must not pay for it"""
+    needed = subprocess.run(["readelf", "-d", str(abi.LIB_PATH)], capture_output=True, text=True, check=True).stdout
+    assert "rccl" not in needed and "nccl" not in needed
+    und = _nm_undefined(abi.LIB_PATH)
+    assert not [s for s in und if s.startswith("nccl")], und
+
+
+def test_shard_ranges_tile_the_batch(abi):
+    """qmann_shard_range (C) = the contiguous split the Python plumbing uses; ranges tile [0, n) in rank order"""
+    from qmann_amd.parallel import shard_range
+    for n in (0, 1, 7, 1000, 65536, 65537):
+        for world in (1, 2, 3, 8):
+            got = [abi.shard_range(n, r, world) for r in range(world)]
+            assert got == [shard_range(n, r, world) for r in range(world)]
+            assert got[0][0] == 0 and got[-1][1] == n and all(got[i][1] == got[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in got]
+            assert max(sizes) - min(sizes) <= 1

@@ -15,7 +15,7 @@ LINK = ["-L", str(ROOT / "q-mann_amd" / "lib"), "-lqmann_hip", "-L/opt/rocm/lib"
 
 def test_headers_are_strict_c99(tmp_path):
     src = tmp_path / "hdr.c"
-    src.write_text('#include "qmann_abi.h"\n#include "qmann_batch.h"\n#include "qmann_weights.h"\n#include "qmann_model.h"\n#include "qmann_dataset.h"\n'
+    src.write_text('#include "qmann_abi.h"\n#include "qmann_batch.h"\n#include "qmann_weights.h"\n#include "qmann_model.h"\n#include "qmann_dataset.h"\n#include "qmann_dist.h"\n'
                    "int main(void) { qmann_net n = {0}; qmann_weights w = {0}; (void)n; (void)w; return (int)sizeof(qmann_taps) * 0; }\n")
     r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", *INC, "-fsyntax-only", str(src)],
                        capture_output=True, text=True)
@@ -106,6 +106,21 @@ def test_dataset_example_compiles(tmp_path):
     r = subprocess.run(["gcc", "-std=c99", "-Wall", *INC, "-I/opt/rocm/include", str(ROOT / "examples" / "forward_dataset.c"),
                         *LINK, "-o", str(exe)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_sharded_example_compiles_and_uses_the_dist_entry_points(tmp_path):
+    """examples/forward_sharded.c (one host thread per shard, RCCL broadcast of the quantised blob) is plain C99 + pthreads;
+    it runs on the GPU in tests/test_gpu_dist.py"""
+    load_pkg()
+    exe = tmp_path / "forward_sharded"
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", *INC, "-I/opt/rocm/include", str(ROOT / "examples" / "forward_sharded.c"),
+                        *LINK, "-lpthread", "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    und = subprocess.run(["nm", "-D", "--undefined-only", str(exe)], capture_output=True, text=True, check=True).stdout
+    used = {l.split()[-1] for l in und.splitlines() if " U qmann_" in l}
+    assert {"qmann_model_create_on", "qmann_model_create_from_params", "qmann_model_params", "qmann_comm_get_id", "qmann_comm_init_rank",
+            "qmann_comm_broadcast_params", "qmann_shard_range", "qmann_model_forward_words", "qmann_dataset_load"} <= used
+    assert not [l for l in und.splitlines() if " U nccl" in l]        # RCCL is reached through the library only
 
 
 @pytest.mark.gpu

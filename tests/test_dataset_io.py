@@ -107,3 +107,30 @@ def test_missing_file_is_an_error_code(abi, tmp_path):
     assert abi.lib.qmann_dataset_load(str(tmp_path / "nope").encode(), b"/dev/null", 50, 0, 0, C.byref(ds)) == abi.QMANN_EIO
     (tmp_path / "bad").write_text("garbage\n")
     assert abi.lib.qmann_dataset_load(str(tmp_path / "bad").encode(), str(tmp_path / "bad").encode(), 50, 0, 0, C.byref(ds)) == abi.QMANN_EIO
+
+
+def test_unknown_question_word_keeps_the_positions_of_the_others(abi, tmp_path):
+    """EN_PE weighs a question word by its POSITION in the question (sample.c:559: pe_w[word][k]); an unknown word must leave a
+    0xFFFF hole in its slot, not shift the words after it"""
+    train = [(["mary went home now"], "where is mary now", "home")]          # dim_word 5: a question keeps 4 words
+    test = [(["mary went home"], "where zebra mary now", "home")]
+    write_set(tmp_path / "tr", train); write_set(tmp_path / "te", test)
+    ds = abi.load_dataset(tmp_path / "tr", tmp_path / "te", 50)
+    words = ["null", "mary", "went", "home", "now", "where", "is"]
+    ix = {w: i for i, w in enumerate(words)}
+    assert [int(w) for w in ds["question_words"][0][:4]] == [ix["where"], 0xFFFF, ix["mary"], ix["now"]]
+
+
+@pytest.mark.parametrize("where", ["samples", "sentences"])
+def test_count_line_that_is_no_number_is_a_format_error(abi, tmp_path, where):
+    import ctypes as C
+    good = "\n+NS+\n1\n\n+I+\n0\n+S+\n1\nmary went home \n+Q+\nwhere is mary \n+A+\nhome\n\n"
+    (tmp_path / "good").write_text(good)
+    bad = good.replace("+NS+\n1\n", "+NS+\nmany\n") if where == "samples" else good.replace("+S+\n1\n", "+S+\n\n")
+    (tmp_path / "bad").write_text(bad)
+    ds = abi.Dataset()
+    g, b = str(tmp_path / "good").encode(), str(tmp_path / "bad").encode()
+    assert abi.lib.qmann_dataset_load(g, g, 50, 0, 0, C.byref(ds)) == 0
+    abi.lib.qmann_dataset_free(C.byref(ds))
+    assert abi.lib.qmann_dataset_load(b, g, 50, 0, 0, C.byref(ds)) == abi.QMANN_EIO
+    assert abi.lib.qmann_dataset_load(g, b, 50, 0, 0, C.byref(ds)) == abi.QMANN_EIO

@@ -164,3 +164,47 @@ def test_workspace_regrows_between_batches(env):
         np.testing.assert_array_equal(p, p_all[q0:q1])
         np.testing.assert_array_equal(u, u_all[q0:q1])
     hm.close()
+
+
+def test_stale_hip_error_of_the_host_is_not_blamed_on_the_next_call(env):
+    """A HIP error the host application left behind on this thread (here: hipSetDevice on a device that does not exist)
+    must not make the next, valid qmann_* call return QMANN_EHIP: the launch checks consume errors (hipGetLastError) and a
+    batched entry point starts from a clean state (csrc/rt.h)."""
+    torch, abi = env.torch, env.abi
+    hip = C.CDLL("libamdhip64.so")
+    src = torch.linspace(-3, 3, 64 * 8, device=env.dev).reshape(8, 64).contiguous()
+    dst = torch.empty((8, 64), dtype=torch.int8, device=env.dev)
+
+    def call():
+        return abi.lib.qmann_quantize_i8(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), 8, 64, 64, abi.Fmt(5, 2), 1, None)
+    assert call() == 0
+    want = dst.cpu().numpy().copy()
+    assert hip.hipSetDevice(1234) != 0                               # leaves a "last error" behind
+    assert call() == 0
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(dst.cpu().numpy(), want)
+
+
+def test_failed_workspace_allocation_returns_ehip_and_the_model_recovers(env):
+    """qmann_model: a workspace that cannot be allocated (4 G story rows) comes back as QMANN_EHIP -- not as a later
+    QMANN_EINVAL from a null pointer --, no capacity is recorded for it, and the next valid call on the same object
+    allocates afresh and gives the usual result."""
+    torch, model, abi = env.torch, env.model, env.abi
+    V, D, B = 30, 60, 5
+    cfg = model.babi_cfg(V, attention_mode=2, D=D)
+    hm = model.HostModel(cfg, weights(3, 3, D, V))
+    rng = np.random.default_rng(5)
+    sw = np.full((B * 4, 8), 0xFFFF, np.uint16); sw[:, :3] = rng.integers(1, 20, (B * 4, 3)); sw[:, 3] = 20 + np.arange(B * 4) % 4
+    qw = np.full((B, 8), 0xFFFF, np.uint16); qw[:, :2] = rng.integers(1, 20, (B, 2))
+    d_sw = torch.from_numpy(sw.view(np.int16)).to(env.dev); d_qw = torch.from_numpy(qw.view(np.int16)).to(env.dev)
+    ro = torch.arange(0, B * 4 + 1, 4, dtype=torch.int32, device=env.dev)
+    pred0, _, _ = hm.forward_words(d_sw, d_qw, ro, 4)
+    torch.cuda.synchronize()
+    pred = torch.empty(B, dtype=torch.int32, device=env.dev)
+    rc = abi.lib.qmann_model_forward_words(hm.h, C.c_void_p(d_sw.data_ptr()), 0xFFFFFFF0, 8, C.c_void_p(d_qw.data_ptr()), 8,
+                                           C.c_void_p(ro.data_ptr()), 4, B, None, C.c_void_p(pred.data_ptr()), None, None, None)
+    assert rc == -5, rc                                              # QMANN_EHIP
+    pred1, _, _ = hm.forward_words(d_sw, d_qw, ro, 4)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(pred1.cpu().numpy(), pred0.cpu().numpy())
+    hm.close()

@@ -200,3 +200,46 @@ def test_pow2_total_is_the_reference_float_sum(env, oracle, taps):
     _, t = oracle.forward_mem(m, keys[:, :, :D].astype(np.float32), vals[:, :, :D].astype(np.float32) / 4.0, u0[0])
     assert t["probs"][0][0] == 1.0 and list(t["scores"][0]) == [63.0, 39.0, -5.0]
     np.testing.assert_array_equal(u, t["u"][0])
+
+
+@pytest.mark.parametrize("mode", [2, 3, 11])
+@pytest.mark.parametrize("max_slots", [10, 16, 33])
+def test_story_longer_than_the_bound_is_cut_not_spilled(env, mode, max_slots):
+    """qmann_batch.h: a story longer than max_slots is CUT to max_slots.  The lean kernel sizes a wavefront's value tile
+    by round16(max_slots); a longer story must neither write past the tile (its neighbours in the workgroup would read
+    garbage) nor change any in-bound query.  Every query must equal the same batch with the long stories shortened by
+    hand, in the lean kernel (no taps) and the general one (taps)."""
+    torch, model = env.torch, env.model
+    cfg = cfg_of(mode)
+    H, D, V, B = cfg["n_hop"], cfg["dim_emb"], cfg["dim_input"], 400
+    rng = np.random.default_rng(4400 + mode * 100 + max_slots)
+    wts = {"w_h": [rng.normal(0, 1.0, (D, D)).astype(np.float32) for _ in range(H)],
+           "w_ans": rng.normal(0, 0.1, (V, D)).astype(np.float32)}
+    net = model.QNet(cfg, wts, device="cuda:0")
+    Dp = net.Dp
+    n_slots = rng.integers(0, max_slots + 1, B)
+    long_q = rng.choice(B, 40, replace=False)
+    n_slots[long_q] = rng.integers(max_slots + 1, 65, long_q.size)         # up to 64: the worst case for the tile
+    n_slots[long_q[:4]] = [64, 63, max_slots + 1, 200]                     # (also one beyond a wavefront)
+    row_off = np.concatenate([[0], np.cumsum(n_slots)]).astype(np.int64)
+    R = int(row_off[-1])
+    keys = np.zeros((H, R, Dp), np.int8); vals = np.zeros((H, R, Dp), np.int8)
+    keys[:, :, :D] = np.clip(np.rint(rng.normal(0, 30, (H, R, D))), -127, 127)
+    vals[:, :, :D] = np.clip(np.rint(rng.normal(0, 30, (H, R, D))), -127, 127)
+    u0 = (np.clip(np.rint(rng.normal(0, 20, (B, D))), -127, 127) / 4.0).astype(np.float32)
+    # the same batch with the long stories cut by hand
+    keep = np.concatenate([np.arange(row_off[q], row_off[q] + min(n_slots[q], max_slots)) for q in range(B)]).astype(np.int64)
+    cut_off = np.concatenate([[0], np.cumsum(np.minimum(n_slots, max_slots))]).astype(np.int32)
+    sk, sv = model.to_signmag(keys), model.to_signmag(vals)
+    dev = env.dev
+    du0 = torch.from_numpy(u0).to(dev)
+    full = [torch.from_numpy(x).to(dev) for x in (sk, sv)]
+    cut = [torch.from_numpy(np.ascontiguousarray(x[:, keep])).to(dev) for x in (sk, sv)]
+    ro_full = torch.from_numpy(row_off.astype(np.int32)).to(dev); ro_cut = torch.from_numpy(cut_off).to(dev)
+    want = net.hops(cut[0], cut[1], ro_cut, max_slots, du0, taps=True)[0].cpu().numpy()
+    got_lean = net.hops(full[0], full[1], ro_full, max_slots, du0).cpu().numpy()
+    got_gen = net.hops(full[0], full[1], ro_full, max_slots, du0, taps=True)[0].cpu().numpy()
+    for name, got in (("lean", got_lean), ("general", got_gen)):
+        bad = np.flatnonzero((got != want).any(1))
+        assert bad.size == 0, f"{name}: {bad.size} queries differ (long ones among them: {np.intersect1d(bad, long_q).size})"
+    assert np.abs(want).sum() > 0

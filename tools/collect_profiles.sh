@@ -13,13 +13,13 @@ cd /tmp && export TMPDIR=/tmp
 # counter files are cut down to our kernels' rows
 prune() { find "$1" -type f ! -name '*kernel_stats.csv' ! -name '*counter_collection.csv' -delete; 
           for c in $(find "$1" -name '*counter_collection.csv'); do { head -1 "$c"; grep -E 'k_hops|k_answer|k_embed|k_logits|k_fwd' "$c" || true; } > "$c.tmp"; mv "$c.tmp" "$c"; done; }
-rocprofv3 --kernel-trace --stats --output-format csv -d $P/${tag}_stats -- python3 $R/bench.py --workload $wl --steps 10 --no-cpu-baseline --no-secondary > $P/${tag}_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/${tag}_stats -- python3 $R/bench.py --workload $wl --steps 10 --no-cpu-baseline --no-secondary --no-sustained > $P/${tag}_stats.log 2>&1
 prune $P/${tag}_stats
 for pass in "$@"; do
   case $pass in
-    fetch) rocprofv3 --pmc FETCH_SIZE --output-format csv -d $P/${tag}_pmc_fetch -- python3 $R/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $P/${tag}_pmc_fetch.log 2>&1; prune $P/${tag}_pmc_fetch ;;
-    mfma) rocprofv3 --pmc SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU --output-format csv -d $P/${tag}_pmc_mfma -- python3 $R/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $P/${tag}_pmc_mfma.log 2>&1; prune $P/${tag}_pmc_mfma ;;
-    sq) rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $P/${tag}_pmc_sq -- python3 $R/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $P/${tag}_pmc_sq.log 2>&1; prune $P/${tag}_pmc_sq ;;
+    fetch) rocprofv3 --pmc FETCH_SIZE --output-format csv -d $P/${tag}_pmc_fetch -- python3 $R/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-sustained > $P/${tag}_pmc_fetch.log 2>&1; prune $P/${tag}_pmc_fetch ;;
+    mfma) rocprofv3 --pmc SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU --output-format csv -d $P/${tag}_pmc_mfma -- python3 $R/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-sustained > $P/${tag}_pmc_mfma.log 2>&1; prune $P/${tag}_pmc_mfma ;;
+    sq) rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $P/${tag}_pmc_sq -- python3 $R/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-sustained > $P/${tag}_pmc_sq.log 2>&1; prune $P/${tag}_pmc_sq ;;
   esac
 done
 echo "$tag $wl done"

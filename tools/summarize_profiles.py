@@ -9,12 +9,16 @@ tag, workload, alg = sys.argv[1], sys.argv[2], float(sys.argv[3])
 src = ROOT / "gpurun_out" / "prof"
 out = ROOT / "profiles"; out.mkdir(exist_ok=True)
 kernel = sys.argv[4] if len(sys.argv) > 4 else "k_hops"
+import importlib.util
+_spec = importlib.util.spec_from_file_location("qmann_pkg_init", ROOT / "q-mann_amd" / "__init__.py")
+_pkg = importlib.util.module_from_spec(_spec); _spec.loader.exec_module(_pkg)
+SRC_SHA = _pkg.kernel_sources_sha16()      # the sources the profiled library was built from (run this before editing them)
 
 st = glob.glob(str(src / f"{tag}_stats" / "*" / "*kernel_stats.csv"))
 if st:
     rows = list(csv.DictReader(open(st[0])))
     with open(out / f"{tag}_kernel_stats_{workload}.csv", "w") as f:
-        f.write(f"# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --workload {workload} --steps 10 --no-cpu-baseline --no-secondary   (MI355X)\n")
+        f.write(f"# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --workload {workload} --steps 10 --no-cpu-baseline --no-secondary --no-sustained   (MI355X)\n")
         f.write("# kernel names cut to 100 chars; torch kernels are the synthetic-data generation\n")
         w = csv.writer(f); w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
         for r in rows:
@@ -33,7 +37,7 @@ if pf:
     m = sum(v) / len(v)
     traffic = 2 * m * 1024
     with open(out / f"{tag}_pmc_fetch_{workload}.txt", "w") as f:
-        f.write(f"rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --workload {workload} --steps 3 --warmup 1 --no-cpu-baseline --no-secondary (MI355X)\n")
+        f.write(f"rocprofv3 --pmc FETCH_SIZE --output-format csv -- python3 bench.py --workload {workload} --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-sustained (MI355X)\n")
         f.write(f"dominant kernel: {kname}; {len(v)} dispatches\n")
         f.write(f"FETCH_SIZE per dispatch (KiB, raw): {[round(x, 1) for x in v]}\n")
         f.write(f"mean raw = {m:.1f} KiB = {m * 1024 / 1e9:.3f} GB\n")
@@ -44,7 +48,8 @@ if pf:
     tj = out / "traffic.json"
     d = json.loads(tj.read_text()) if tj.exists() else {}
     d[workload] = {"traffic_bytes_per_launch": traffic, "algorithmic_bytes_per_launch": alg, "source": f"profiles/{tag}_pmc_fetch_{workload}.txt",
-                   "method": "rocprofv3 --pmc FETCH_SIZE (own pass), KiB x 1024 x 2 (gfx950 wide-stream correction)"}
+                   "method": "rocprofv3 --pmc FETCH_SIZE (own pass), KiB x 1024 x 2 (gfx950 wide-stream correction)",
+                   "kernel_sources_sha16": SRC_SHA}
     tj.write_text(json.dumps(d, indent=1) + "\n")
 
 sq = glob.glob(str(src / f"{tag}_pmc_sq" / "*" / "*counter_collection.csv"))
@@ -54,7 +59,7 @@ if sq:
         if kernel in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     with open(out / f"{tag}_pmc_sq_{workload}.txt", "w") as f:
-        f.write(f"rocprofv3 --pmc <SQ counters> --output-format csv -- python3 bench.py --workload {workload} --steps 3 --warmup 1 --no-cpu-baseline --no-secondary (MI355X)\n")
+        f.write(f"rocprofv3 --pmc <SQ counters> --output-format csv -- python3 bench.py --workload {workload} --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-sustained (MI355X)\n")
         f.write("the k_hops_* kernel, mean per dispatch (SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles)\n")
         for k, v in sorted(agg.items()):
             f.write(f"{k:24s} {sum(v) / len(v):16.0f}\n")
@@ -82,7 +87,7 @@ if mf:
         sq_busy = sum(agg["SQ_BUSY_CYCLES"]) / len(agg["SQ_BUSY_CYCLES"])
         frac = busy / 1024.0 / (avg_ns * 1e-9 * 2.1e9)
         with open(out / f"{tag}_pmc_mfma_{workload}.txt", "w") as f:
-            f.write(f"rocprofv3 --pmc SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU --output-format csv -- python3 bench.py --workload {workload} --steps 3 --warmup 1 --no-cpu-baseline --no-secondary (MI355X)\n")
+            f.write(f"rocprofv3 --pmc SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU --output-format csv -- python3 bench.py --workload {workload} --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-sustained (MI355X)\n")
             f.write("k_answer_i8_part (int8 MFMA projection + softmax statistics + arg-max), mean per dispatch\n")
             for k, v in sorted(agg.items()):
                 f.write(f"{k:28s} {sum(v) / len(v):16.0f}\n")
@@ -93,5 +98,6 @@ if mf:
         print(open(out / f"{tag}_pmc_mfma_{workload}.txt").read())
         mj = out / "mfma.json"
         d = json.loads(mj.read_text()) if mj.exists() else {}
-        d[workload] = {"mfma_busy_frac": frac, "mfma_insts": insts, "kernel_us": avg_ns / 1e3, "source": f"profiles/{tag}_pmc_mfma_{workload}.txt"}
+        d[workload] = {"mfma_busy_frac": frac, "mfma_insts": insts, "kernel_us": avg_ns / 1e3, "source": f"profiles/{tag}_pmc_mfma_{workload}.txt",
+                       "kernel_sources_sha16": SRC_SHA}
         mj.write_text(json.dumps(d, indent=1) + "\n")
