@@ -288,6 +288,34 @@ void qmann_abi_set_softmax_base(int base);
 /* Number of `cuda_*` symbols of boundary B this build exports (66). */
 unsigned int qmann_abi_symbol_count(void);
 
+/* Deferred execution of the forward verbs.  The host drives the test and validation phases one query at a time, 31 verbs
+ * per query, and reads nothing back until the accumulators are fetched after the loop (MemN2N/MemN2N.c:2378-2702;
+ * lib/layer_cuda.cu:3813-3851).  By default the nine forward verbs (cuda_dense_fwd, cuda_dense_mat_fwd,
+ * cuda_dot_mat_vec_fwd, cuda_dot_mat_vec_fwd_appx, cuda_softmax_fwd, cuda_sum_vec_fwd, cuda_scale_fwd, cuda_activation_fwd,
+ * cuda_cross_entropy_run) therefore only RECORD their call; every other cuda_* verb first drains the record.  Whole queries
+ * are recognised by their pointer wiring and a run of them becomes one call of the batched forward (qmann_model.h) on the
+ * host's own device pools, the match count and cost going into the accumulators the verbs named; anything else (training
+ * steps, unusual layer orders, options the batched kernels refuse) is executed verb by verb as before.  After a batched run
+ * the last query is replayed verb by verb so that every layer's device buffer holds what the serial loop leaves there.
+ * CONTRACT: device buffers written by forward verbs are up to date after the next non-forward cuda_* verb (as for the
+ * reference host, which reads only through cuda_cross_entropy_*_load / cuda_copy_dev2host) or after qmann_abi_flush();
+ * a host that reads them with its own hipMemcpy must call qmann_abi_flush() first, or switch the queue off.
+ *   mode 0: off -- every verb launches at once;  1: on (default);  2: verify -- every recognised run is computed BOTH ways,
+ *   the verb-by-verb result goes into the accumulators and a line comparing the two match counts is printed on stderr.
+ * Environment: QMANN_DEFER=0|1|verify (QMANN_NO_DEFER=1 = 0), QMANN_DEFER_STATS=1 prints the counters below at exit,
+ * QMANN_SAVE_WEIGHTS_DIR=<dir> writes, when a TEST-phase run is dispatched, the matrices it is tested with as weight files
+ * (include/qmann_weights.h: the reference's disabled EN_WRITE_WEIGHT layout, MemN2N.c:2853-2978) and the model's quantised
+ * parameter blob (<dir>/qmann_params.bin, qmann_model_create_from_params). */
+typedef struct qmann_defer_stats {
+    unsigned long long ops_queued, ops_replayed;        /* forward verbs recorded / executed one by one */
+    unsigned long long queries_batched, batches;        /* queries that went through the batched forward, in how many calls */
+    unsigned long long models_built, verify_runs, verify_mismatch;
+    double ms_batched, ms_replayed, ms_model;           /* wall time (device-synchronised only with QMANN_DEFER_STATS / verify) */
+} qmann_defer_stats;
+void qmann_abi_set_defer(int mode);
+void qmann_abi_flush(void);
+void qmann_abi_defer_stats(qmann_defer_stats *out);
+
 #ifdef __cplusplus
 }
 #endif

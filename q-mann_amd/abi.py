@@ -120,6 +120,27 @@ _proto("cuda_activation_bwd", None, [_vp, _vp, _vp, C.c_char_p, _u, _b, _u, _u, 
 _proto("qmann_abi_set_softmax_base", None, [C.c_int])
 _proto("qmann_abi_symbol_count", _u, [])
 
+
+class DeferStats(C.Structure):
+    """include/qmann_abi.h: qmann_defer_stats"""
+    _fields_ = [(n, C.c_ulonglong) for n in ("ops_queued", "ops_replayed", "queries_batched", "batches", "models_built",
+                                             "verify_runs", "verify_mismatch")] + [(n, C.c_double) for n in ("ms_batched", "ms_replayed", "ms_model")]
+
+
+_proto("qmann_abi_set_defer", None, [C.c_int])
+_proto("qmann_abi_flush", None, [])
+_proto("qmann_abi_defer_stats", None, [C.POINTER(DeferStats)])
+# The tests and bench.py drive single verbs and then look at the device buffers through torch, not through a cuda_* verb:
+# for this plumbing the forward verbs launch at once (the deferred queue is the default for C hosts; tests of the queue
+# itself switch it on again or run the reference's host programs as subprocesses).
+lib.qmann_abi_set_defer(0)
+
+
+def defer_stats() -> dict:
+    st = DeferStats()
+    lib.qmann_abi_defer_stats(C.byref(st))
+    return {n: getattr(st, n) for n, _ in DeferStats._fields_}
+
 # ---- batched int8 API (include/qmann_batch.h) ----
 _proto("qmann_hops_lds_bytes", C.c_size_t, [C.c_uint32])
 _proto("qmann_check_slots", C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp, _vp])

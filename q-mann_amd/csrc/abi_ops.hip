@@ -14,6 +14,7 @@
 // differs from the reference's serial loop (documented tolerance 1e-5 rel.).
 #include "qfmt.h"
 #include "rt.h"
+#include "defer.h"
 #include "../../include/qmann_abi.h"
 
 #include <string.h>
@@ -178,7 +179,6 @@ k_softmax(const float *__restrict__ in, float *__restrict__ out, float *__restri
             for (unsigned i = threadIdx.x; i < dim; i += kBlock) out[i] = (float)((double)out[i] / total);
         }
     } else {
-        float part = 0.0f;
         for (unsigned i = threadIdx.x; i < dim; i += kBlock) {
             float e;
             if (base == 2) {                          // piece-wise linear exp (lib/common.c:51-73)
@@ -189,9 +189,19 @@ k_softmax(const float *__restrict__ in, float *__restrict__ out, float *__restri
                 e = shift_based ? exp2f(in[i] - mx + 1.0f) : exp2f(in[i] - mx);
             }
             out[i] = e;
-            part += e;
         }
-        const float total = block_reduce<float>(part, sf, false);
+        // The CPU softmax these bases come from adds its total in a FLOAT, slot by slot (`float tot`, lib/layer.c:1161, :1236):
+        // one thread walks the terms in that order.  A tree sum differs from it in the last bit, which decides Q(p) where p
+        // sits on a truncation step -- e.g. a dominant slot with a runner-up 2^-24 below it: the serial float total is 1,
+        // p = 1 exactly (tools/soak.py case 12750221; the short-memory kernels of the batched path do the same).
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float tot = 0.0f;
+            for (unsigned i = 0; i < dim; i++) tot += out[i];
+            sf[0] = tot;
+        }
+        __syncthreads();
+        const float total = sf[0];
         for (unsigned i = threadIdx.x; i < dim; i += kBlock) out[i] = out[i] / total;
     }
 }
@@ -305,9 +315,85 @@ inline void free_dev(void *p)
 
 }  // namespace
 
+// the launches behind the nine forward verbs (called at once, or when the deferred queue is drained op by op)
+void qmdefer::run_now(const Op &op)
+{
+    switch (op.kind) {
+    case kDot: {
+        if (op.r == 0 || op.c == 0) return;
+        float *in_mat = const_cast<float *>(op.in), *in_vec = const_cast<float *>(op.in2);
+        if (op.trans) {
+            const unsigned grid = qm_cdiv(op.c, kWave);
+            if (op.fixed) k_cols_dot<true><<<grid, kBlock, 0, 0>>>(in_vec, in_mat, op.out, op.r, op.c, op.fa, op.fa);
+            else k_cols_dot<false><<<grid, kBlock, 0, 0>>>(in_vec, in_mat, op.out, op.r, op.c, op.fa, op.fa);
+        } else {
+            const unsigned grid = qm_cdiv(op.r, kBlock / kWave);
+            if (op.fixed) k_rows_dot<true><<<grid, kBlock, 0, 0>>>(in_mat, in_vec, op.out, op.r, op.c, 1, op.fa, op.fb, op.fa);
+            else k_rows_dot<false><<<grid, kBlock, 0, 0>>>(in_mat, in_vec, op.out, op.r, op.c, 1, op.fa, op.fb, op.fa);
+        }
+        break;
+    }
+    case kDotAppx:
+        if (op.r == 0 || op.c == 0) return;
+        if (op.fa.iwl > 30) qm_fail("cuda_dot_mat_vec_fwd_appx", "iwl > 30 leaves no fraction bits");
+        k_appx_scores<<<qm_cdiv(op.r, kBlock / kWave), kBlock, 0, 0>>>(op.in, op.in2, op.out, op.r, op.c, op.fa.iwl, op.k);
+        break;
+    case kSoftmax:
+        if (op.r == 0) return;
+        k_softmax<<<1, kBlock, 0, 0>>>(op.in, op.out, op.aux, op.r, g_softmax_base, op.shift);
+        break;
+    case kSumVec:
+        if (op.r == 0) return;
+        k_vec_sum<<<qm_cdiv(op.r, kBlock), kBlock, 0, 0>>>(op.in, op.in2, op.out, op.r, op.fixed, op.fa);
+        break;
+    case kDense: {
+        if (op.c == 0 || op.r == 0) return;
+        const unsigned grid = qm_cdiv(op.r, kBlock / kWave);
+        if (op.fixed) k_rows_dot<true><<<grid, kBlock, 0, 0>>>(op.w, op.in, op.out, op.r, op.c, 1, op.fb, op.fa, op.fb);
+        else k_rows_dot<false><<<grid, kBlock, 0, 0>>>(op.w, op.in, op.out, op.r, op.c, 1, op.fb, op.fa, op.fb);
+        if (op.act != kActNull)
+            k_activation<<<qm_cdiv(op.r, kBlock), kBlock, 0, 0>>>(op.out, op.out, op.r, op.act, op.fixed, op.fb);
+        break;
+    }
+    case kDenseMat: {
+        if (op.c == 0 || op.k == 0 || op.r == 0) return;
+        const unsigned n_out = op.r * op.k;
+        const unsigned grid = qm_cdiv(n_out, kBlock / kWave);
+        if (op.fixed) k_rows_dot<true><<<grid, kBlock, 0, 0>>>(op.in, op.w, op.out, n_out, op.c, op.k, op.fa, op.fa, op.fa);
+        else k_rows_dot<false><<<grid, kBlock, 0, 0>>>(op.in, op.w, op.out, n_out, op.c, op.k, op.fa, op.fa, op.fa);
+        break;
+    }
+    case kCrossEntropy: {
+        if (op.r == 0) return;
+        const unsigned i = op.mode - 1u;
+        k_cross_entropy<<<1, kBlock, 0, 0>>>(op.in, op.in2, op.cost[i], op.cnt[i], op.pred, op.out, op.r);
+        break;
+    }
+    case kAct:
+        if (op.r == 0) return;
+        k_activation<<<qm_cdiv(op.r, kBlock), kBlock, 0, 0>>>(op.in, op.out, op.r, op.act, op.fixed, op.fa);
+        break;
+    case kScale:
+        if (op.r == 0) return;
+        k_vec_scale<<<qm_cdiv(op.r, kBlock), kBlock, 0, 0>>>(op.in, op.w, op.out, op.r);
+        break;
+    default:
+        qm_fail("qmdefer::run_now", "unknown op");
+    }
+    QM_LAUNCH_CHECK();
+}
+
+int qmdefer::softmax_base() { return g_softmax_base; }
+
+using qmdefer::Op;
+
 extern "C" {
 
-void qmann_abi_set_softmax_base(int base) { g_softmax_base = (base == 1 || base == 2) ? base : 0; }
+void qmann_abi_set_softmax_base(int base)
+{
+    QM_SYNC_WRITES();                       // queued softmax ops run with the base they were issued under
+    g_softmax_base = (base == 1 || base == 2) ? base : 0;
+}
 unsigned int qmann_abi_symbol_count(void) { return 66u; }
 
 // ---------------------------------------------------------------- dot_mat_vec
@@ -315,6 +401,7 @@ void cuda_dot_mat_vec_constructor(float **dev_out_vec, float **dev_grad_out_vec,
                                   float **dev_f_overflow, float **dev_cliff_marker, unsigned int r,
                                   unsigned int c, bool f_trans)
 {
+    QM_SYNC_WRITES();
     qm_alloc(dev_out_vec, f_trans ? c : r);
     qm_alloc(dev_grad_out_vec, f_trans ? r : c);
     qm_alloc(dev_f_overflow, f_trans ? c : r);
@@ -326,6 +413,7 @@ void cuda_dot_mat_vec_init(float *dev_out_vec, float *dev_grad_out_vec, float *d
                            float *dev_f_overflow, float *dev_cliff_marker, unsigned int r, unsigned int c,
                            bool f_trans)
 {
+    QM_SYNC_WRITES();
     zero_f(dev_out_vec, f_trans ? c : r);
     zero_f(dev_grad_out_vec, f_trans ? r : c);
     zero_f(dev_f_overflow, f_trans ? c : r);
@@ -339,18 +427,10 @@ void cuda_dot_mat_vec_fwd(float *dev_in_mat, float *dev_in_vec, float *dev_out_v
                           bool verbose)
 {
     (void)dev_f_overflow; (void)f_mode; (void)verbose;
-    if (r == 0 || c == 0) return;
-    const QFmt fm{iwl_m, frac_m}, fv{iwl_v, frac_v};
-    if (f_trans) {
-        const unsigned grid = qm_cdiv(c, kWave);
-        if (f_fixed) k_cols_dot<true><<<grid, kBlock, 0, 0>>>(dev_in_vec, dev_in_mat, dev_out_vec, r, c, fm, fm);
-        else k_cols_dot<false><<<grid, kBlock, 0, 0>>>(dev_in_vec, dev_in_mat, dev_out_vec, r, c, fm, fm);
-    } else {
-        const unsigned grid = qm_cdiv(r, kBlock / kWave);
-        if (f_fixed) k_rows_dot<true><<<grid, kBlock, 0, 0>>>(dev_in_mat, dev_in_vec, dev_out_vec, r, c, 1, fm, fv, fm);
-        else k_rows_dot<false><<<grid, kBlock, 0, 0>>>(dev_in_mat, dev_in_vec, dev_out_vec, r, c, 1, fm, fv, fm);
-    }
-    QM_LAUNCH_CHECK();
+    Op op{};
+    op.kind = qmdefer::kDot; op.in = dev_in_mat; op.in2 = dev_in_vec; op.out = dev_out_vec; op.r = r; op.c = c;
+    op.trans = f_trans; op.fixed = f_fixed; op.fa = QFmt{iwl_m, frac_m}; op.fb = QFmt{iwl_v, frac_v};
+    if (!qmdefer::submit(op)) qmdefer::run_now(op);
 }
 
 void cuda_dot_mat_vec_fwd_appx(float *dev_in_mat, float *dev_in_vec, float *dev_out_vec, float *dev_f_overflow,
@@ -359,21 +439,21 @@ void cuda_dot_mat_vec_fwd_appx(float *dev_in_mat, float *dev_in_vec, float *dev_
                                unsigned int num_bit_attention, bool f_trans, bool verbose)
 {
     (void)dev_cliff_marker;
-    if (f_trans) {
+    if (f_trans) {                               // the read-out of an ATTENTION_MODE 3 build is the plain weighted sum
         cuda_dot_mat_vec_fwd(dev_in_mat, dev_in_vec, dev_out_vec, dev_f_overflow, r, c, true, f_fixed, iwl, frac,
                              iwl, frac, f_mode, verbose);
         return;
     }
-    if (r == 0 || c == 0) return;
-    if (iwl > 30) qm_fail(__func__, "iwl > 30 leaves no fraction bits");
-    k_appx_scores<<<qm_cdiv(r, kBlock / kWave), kBlock, 0, 0>>>(dev_in_mat, dev_in_vec, dev_out_vec, r, c, iwl,
-                                                              num_bit_attention);
-    QM_LAUNCH_CHECK();
+    Op op{};
+    op.kind = qmdefer::kDotAppx; op.in = dev_in_mat; op.in2 = dev_in_vec; op.out = dev_out_vec; op.r = r; op.c = c;
+    op.k = num_bit_attention; op.fixed = f_fixed; op.fa = QFmt{iwl, frac};
+    if (!qmdefer::submit(op)) qmdefer::run_now(op);
 }
 
 void cuda_dot_mat_vec_destructor(float *dev_out_vec, float *dev_grad_out_vec, float *dev_grad_out_mat,
                                  float *dev_f_overflow, float *dev_cliff_marker)
 {
+    QM_SYNC_WRITES();
     free_dev(dev_out_vec); free_dev(dev_grad_out_vec); free_dev(dev_grad_out_mat);
     free_dev(dev_f_overflow); free_dev(dev_cliff_marker);
 }
@@ -381,6 +461,7 @@ void cuda_dot_mat_vec_destructor(float *dev_out_vec, float *dev_grad_out_vec, fl
 // -------------------------------------------------------------------- softmax
 void cuda_softmax_constructor(float **dev_out_vec, float **dev_grad_out, float **dev_max, unsigned int dim)
 {
+    QM_SYNC_WRITES();
     qm_alloc(dev_out_vec, dim);
     qm_alloc(dev_grad_out, dim);
     qm_alloc(dev_max, 1);
@@ -388,6 +469,7 @@ void cuda_softmax_constructor(float **dev_out_vec, float **dev_grad_out, float *
 
 void cuda_softmax_init(float *dev_out_vec, float *dev_grad_out, float *dev_max, unsigned int dim)
 {
+    QM_SYNC_WRITES();
     zero_f(dev_out_vec, dim);
     zero_f(dev_grad_out, dim);
     zero_f(dev_max, 1);
@@ -397,25 +479,28 @@ void cuda_softmax_fwd(float *dev_out_vec, float *dev_in_vec, float *out_vec, flo
                       unsigned int dim, bool f_shift_based, bool verbose)
 {
     (void)out_vec; (void)in_vec; (void)verbose;
-    if (dim == 0) return;
-    k_softmax<<<1, kBlock, 0, 0>>>(dev_in_vec, dev_out_vec, dev_max, dim, g_softmax_base, f_shift_based);
-    QM_LAUNCH_CHECK();
+    Op op{};
+    op.kind = qmdefer::kSoftmax; op.in = dev_in_vec; op.out = dev_out_vec; op.aux = dev_max; op.r = dim; op.shift = f_shift_based;
+    if (!qmdefer::submit(op)) qmdefer::run_now(op);
 }
 
 void cuda_softmax_destructor(float *dev_out_vec, float *dev_grad_out, float *dev_max)
 {
+    QM_SYNC_WRITES();
     free_dev(dev_out_vec); free_dev(dev_grad_out); free_dev(dev_max);
 }
 
 // -------------------------------------------------------------------- sum_vec
 void cuda_sum_vec_constructor(float **dev_out_vec, float **dev_grad_out, unsigned int dim)
 {
+    QM_SYNC_WRITES();
     qm_alloc(dev_out_vec, dim);
     qm_alloc(dev_grad_out, dim);
 }
 
 void cuda_sum_vec_init(float *dev_out_vec, float *dev_grad_out, unsigned int dim)
 {
+    QM_SYNC_WRITES();
     zero_f(dev_out_vec, dim);
     zero_f(dev_grad_out, dim);
 }
@@ -424,14 +509,15 @@ void cuda_sum_vec_fwd(float *dev_in_vec_a, float *dev_in_vec_b, float *dev_out_v
                       bool f_fixed, unsigned int iwl, unsigned int frac, unsigned int f_mode, bool verbose)
 {
     (void)f_mode; (void)verbose;
-    if (dim == 0) return;
-    k_vec_sum<<<qm_cdiv(dim, kBlock), kBlock, 0, 0>>>(dev_in_vec_a, dev_in_vec_b, dev_out_vec, dim, f_fixed,
-                                                    QFmt{iwl, frac});
-    QM_LAUNCH_CHECK();
+    Op op{};
+    op.kind = qmdefer::kSumVec; op.in = dev_in_vec_a; op.in2 = dev_in_vec_b; op.out = dev_out_vec; op.r = dim;
+    op.fixed = f_fixed; op.fa = QFmt{iwl, frac};
+    if (!qmdefer::submit(op)) qmdefer::run_now(op);
 }
 
 void cuda_sum_vec_destructor(float *dev_out_vec, float *dev_grad_out)
 {
+    QM_SYNC_WRITES();
     free_dev(dev_out_vec); free_dev(dev_grad_out);
 }
 
@@ -441,6 +527,7 @@ void cuda_dense_constructor(float **dev_w_mat, float **dev_w_mat_del, float **de
                             float **dev_grad_l2_norm, float **dev_grad_bias_l2_norm, float **dev_f_overflow,
                             unsigned int dim_in, unsigned int dim_out)
 {
+    QM_SYNC_WRITES();
     const size_t nw = (size_t)dim_in * dim_out;
     qm_alloc(dev_w_mat, nw);
     qm_alloc(dev_w_mat_del, nw);
@@ -458,6 +545,7 @@ void cuda_dense_init(float *dev_out_vec, float *dev_grad_out, float *dev_w_mat_d
                      float *dev_bias, float *dev_bias_del, float *w_mat, float *bias, float *dev_f_overflow,
                      unsigned int dim_in, unsigned int dim_out)
 {
+    QM_SYNC_WRITES();
     const size_t nw = (size_t)dim_in * dim_out;
     zero_f(dev_out_vec, dim_out);
     zero_f(dev_grad_out, dim_in);
@@ -474,23 +562,19 @@ void cuda_dense_fwd(float *dev_w_mat, float *dev_bias, float *dev_in_vec, float 
                     unsigned int frac_w, unsigned int f_mode, bool verbose)
 {
     (void)dev_bias; (void)dev_f_overflow; (void)f_mode; (void)verbose;
-    if (dim_in == 0 || dim_out == 0) return;
     if (f_fixed && iwl_w + frac_w == 0)
         qm_fail(__func__, "binary-weight (iwl_w+frac_w==0) rescale path is not part of this library");
-    const QFmt fw{iwl_w, frac_w}, fi{iwl_in, frac_in};
-    const unsigned grid = qm_cdiv(dim_out, kBlock / kWave);
-    if (f_fixed) k_rows_dot<true><<<grid, kBlock, 0, 0>>>(dev_w_mat, dev_in_vec, dev_out_vec, dim_out, dim_in, 1, fw, fi, fw);
-    else k_rows_dot<false><<<grid, kBlock, 0, 0>>>(dev_w_mat, dev_in_vec, dev_out_vec, dim_out, dim_in, 1, fw, fi, fw);
-    const int act = act_id(activation);
-    if (act != kActNull)
-        k_activation<<<qm_cdiv(dim_out, kBlock), kBlock, 0, 0>>>(dev_out_vec, dev_out_vec, dim_out, act, f_fixed, fw);
-    QM_LAUNCH_CHECK();
+    Op op{};
+    op.kind = qmdefer::kDense; op.w = dev_w_mat; op.in = dev_in_vec; op.out = dev_out_vec; op.r = dim_out; op.c = dim_in;
+    op.act = act_id(activation); op.fixed = f_fixed; op.fa = QFmt{iwl_in, frac_in}; op.fb = QFmt{iwl_w, frac_w};
+    if (!qmdefer::submit(op)) qmdefer::run_now(op);
 }
 
 void cuda_dense_destructor(float *dev_w_mat, float *dev_w_mat_del, float *dev_w_mat_best, float *dev_out_vec,
                            float *dev_grad_out, float *dev_grad_l2_norm, float *dev_grad_bias_l2_norm,
                            float *dev_f_overflow)
 {
+    QM_SYNC_WRITES();
     // the reference's constructor never allocates dev_grad_bias_l2_norm and its
     // destructor never frees dev_bias/dev_bias_del; free only what is certainly ours
     (void)dev_grad_bias_l2_norm;
@@ -505,6 +589,7 @@ void cuda_dense_mat_constructor(float **dev_w_mat, float **dev_w_mat_del, float 
                                 float **dev_f_overflow, unsigned int dim_in, unsigned int dim_out,
                                 unsigned int dim_len)
 {
+    QM_SYNC_WRITES();
     const size_t nw = (size_t)dim_in * dim_out;
     qm_alloc(dev_w_mat, nw);
     qm_alloc(dev_w_mat_del, nw);
@@ -523,6 +608,7 @@ void cuda_dense_mat_init(float *dev_out_mat, float *dev_grad_out, float *dev_w_m
                          float *dev_f_overflow, unsigned int dim_in, unsigned int dim_out,
                          unsigned int dim_len)
 {
+    QM_SYNC_WRITES();
     const size_t nw = (size_t)dim_in * dim_out;
     zero_f(dev_out_mat, (size_t)dim_len * dim_out);
     zero_f(dev_grad_out, (size_t)dim_len * dim_in);
@@ -538,21 +624,19 @@ void cuda_dense_mat_fwd(float *dev_w_mat, float *dev_bias, float *dev_in_mat, fl
                         bool f_fixed, unsigned int iwl, unsigned int frac, unsigned int f_mode, bool verbose)
 {
     (void)dev_bias; (void)dev_f_overflow; (void)f_mode; (void)verbose;
-    if (dim_in == 0 || dim_out == 0 || dim_len == 0) return;
     if (f_fixed && iwl + frac == 0)
         qm_fail(__func__, "binary-weight (iwl+frac==0) rescale path is not part of this library");
-    const QFmt f{iwl, frac};
-    const unsigned n_out = dim_len * dim_out;
-    const unsigned grid = qm_cdiv(n_out, kBlock / kWave);
-    if (f_fixed) k_rows_dot<true><<<grid, kBlock, 0, 0>>>(dev_in_mat, dev_w_mat, dev_out_mat, n_out, dim_in, dim_out, f, f, f);
-    else k_rows_dot<false><<<grid, kBlock, 0, 0>>>(dev_in_mat, dev_w_mat, dev_out_mat, n_out, dim_in, dim_out, f, f, f);
-    QM_LAUNCH_CHECK();
+    Op op{};
+    op.kind = qmdefer::kDenseMat; op.w = dev_w_mat; op.in = dev_in_mat; op.out = dev_out_mat; op.r = dim_len; op.c = dim_in;
+    op.k = dim_out; op.fixed = f_fixed; op.fa = QFmt{iwl, frac};
+    if (!qmdefer::submit(op)) qmdefer::run_now(op);
 }
 
 void cuda_dense_mat_destructor(float *dev_w_mat, float *dev_w_mat_del, float *dev_w_mat_best,
                                float *dev_out_mat, float *dev_grad_out, float *dev_grad_l2_norm,
                                float *dev_f_overflow)
 {
+    QM_SYNC_WRITES();
     free_dev(dev_w_mat); free_dev(dev_w_mat_del); free_dev(dev_w_mat_best); free_dev(dev_out_mat);
     free_dev(dev_grad_out); free_dev(dev_grad_l2_norm); free_dev(dev_f_overflow);
 }
@@ -563,6 +647,7 @@ void cuda_cross_entropy_constructor(float **dev_cost_train, float **dev_cost_val
                                     unsigned int **dev_m_cnt_test, unsigned int **dev_pred_i,
                                     float **dev_grad_out, unsigned int dim)
 {
+    QM_SYNC_WRITES();
     qm_alloc(dev_cost_train, 1); qm_alloc(dev_cost_valid, 1); qm_alloc(dev_cost_test, 1);
     qm_alloc(dev_m_cnt_train, 1); qm_alloc(dev_m_cnt_valid, 1); qm_alloc(dev_m_cnt_test, 1);
     qm_alloc(dev_pred_i, 1);
@@ -573,6 +658,7 @@ void cuda_cross_entropy_init(float *dev_cost_train, float *dev_cost_valid, float
                              unsigned int *dev_m_cnt_train, unsigned int *dev_m_cnt_valid,
                              unsigned int *dev_m_cnt_test, float *dev_grad_out, unsigned int dim)
 {
+    QM_SYNC_WRITES();
     zero_f(dev_cost_train, 1); zero_f(dev_cost_valid, 1); zero_f(dev_cost_test, 1);
     zero_f((float *)dev_m_cnt_train, 1); zero_f((float *)dev_m_cnt_valid, 1); zero_f((float *)dev_m_cnt_test, 1);
     zero_f(dev_grad_out, dim);
@@ -585,17 +671,18 @@ void cuda_cross_entropy_run(float *dev_cost_train, float *dev_cost_valid, float 
                             unsigned int dim, unsigned int mode)
 {
     (void)cost; (void)h; (void)y; (void)grad_out;
-    if (dim == 0) return;
-    float *c = mode == 1 ? dev_cost_train : mode == 2 ? dev_cost_valid : dev_cost_test;
-    unsigned *m = mode == 1 ? dev_m_cnt_train : mode == 2 ? dev_m_cnt_valid : dev_m_cnt_test;
     if (mode < 1 || mode > 3) qm_fail(__func__, "mode must be 1 (train), 2 (valid) or 3 (test)");
-    k_cross_entropy<<<1, kBlock, 0, 0>>>(dev_h, dev_y, c, m, dev_pred_i, dev_grad_out, dim);
-    QM_LAUNCH_CHECK();
+    Op op{};
+    op.kind = qmdefer::kCrossEntropy; op.in = dev_h; op.in2 = dev_y; op.out = dev_grad_out; op.r = dim; op.mode = mode;
+    op.cost[0] = dev_cost_train; op.cost[1] = dev_cost_valid; op.cost[2] = dev_cost_test;
+    op.cnt[0] = dev_m_cnt_train; op.cnt[1] = dev_m_cnt_valid; op.cnt[2] = dev_m_cnt_test; op.pred = dev_pred_i;
+    if (!qmdefer::submit(op)) qmdefer::run_now(op);
 }
 
 void cuda_cross_entropy_cost_load(float *dev_cost_train, float *dev_cost_valid, float *dev_cost_test,
                                   float *cost_train, float *cost_valid, float *cost_test)
 {
+    QM_SYNC_READS();
     QM_HIP(hipMemcpy(cost_train, dev_cost_train, sizeof(float), hipMemcpyDeviceToHost));
     QM_HIP(hipMemcpy(cost_valid, dev_cost_valid, sizeof(float), hipMemcpyDeviceToHost));
     QM_HIP(hipMemcpy(cost_test, dev_cost_test, sizeof(float), hipMemcpyDeviceToHost));
@@ -606,6 +693,7 @@ void cuda_cross_entropy_m_cnt_load(unsigned int *dev_m_cnt_train, unsigned int *
                                    unsigned int *dev_m_cnt_test, unsigned int *m_cnt_train,
                                    unsigned int *m_cnt_valid, unsigned int *m_cnt_test)
 {
+    QM_SYNC_READS();
     QM_HIP(hipMemcpy(m_cnt_train, dev_m_cnt_train, sizeof(unsigned), hipMemcpyDeviceToHost));
     QM_HIP(hipMemcpy(m_cnt_valid, dev_m_cnt_valid, sizeof(unsigned), hipMemcpyDeviceToHost));
     QM_HIP(hipMemcpy(m_cnt_test, dev_m_cnt_test, sizeof(unsigned), hipMemcpyDeviceToHost));
@@ -616,6 +704,7 @@ void cuda_cross_entropy_destructor(float *dev_cost_train, float *dev_cost_valid,
                                    float *dev_m_cnt_train, float *dev_m_cnt_valid, float *dev_m_cnt_test,
                                    float *dev_pred_i, float *dev_grad_out)
 {
+    QM_SYNC_WRITES();
     free_dev(dev_cost_train); free_dev(dev_cost_valid); free_dev(dev_cost_test);
     free_dev(dev_m_cnt_train); free_dev(dev_m_cnt_valid); free_dev(dev_m_cnt_test);
     free_dev(dev_pred_i); free_dev(dev_grad_out);
@@ -624,12 +713,14 @@ void cuda_cross_entropy_destructor(float *dev_cost_train, float *dev_cost_valid,
 // --------------------------------------------------------- activation / scale
 void cuda_activation_constructor(float **dev_out, float **dev_grad_out, unsigned int dim)
 {
+    QM_SYNC_WRITES();
     qm_alloc(dev_out, dim);
     qm_alloc(dev_grad_out, dim);
 }
 
 void cuda_activation_init(float *dev_out, float *dev_grad_out, unsigned int dim)
 {
+    QM_SYNC_WRITES();
     zero_f(dev_out, dim);
     zero_f(dev_grad_out, dim);
 }
@@ -638,20 +729,22 @@ void cuda_activation_fwd(float *dev_in, float *dev_out, char *type_act, unsigned
                          unsigned int iwl, unsigned int frac, unsigned int f_mode)
 {
     (void)f_mode;
-    if (dim == 0) return;
-    k_activation<<<qm_cdiv(dim, kBlock), kBlock, 0, 0>>>(dev_in, dev_out, dim, act_id(type_act), f_fixed,
-                                                       QFmt{iwl, frac});
-    QM_LAUNCH_CHECK();
+    Op op{};
+    op.kind = qmdefer::kAct; op.in = dev_in; op.out = dev_out; op.act = act_id(type_act); op.r = dim; op.fixed = f_fixed;
+    op.fa = QFmt{iwl, frac};
+    if (!qmdefer::submit(op)) qmdefer::run_now(op);
 }
 
 void cuda_activation_destructor(float *dev_out, float *dev_grad_out)
 {
+    QM_SYNC_WRITES();
     free_dev(dev_out); free_dev(dev_grad_out);
 }
 
 void cuda_scale_constructor(float **dev_w, float **dev_w_del, float **dev_w_best, float **dev_out,
                             float **dev_grad_out, unsigned int dim)
 {
+    QM_SYNC_WRITES();
     qm_alloc(dev_w, 1); qm_alloc(dev_w_del, 1); qm_alloc(dev_w_best, 1);
     qm_alloc(dev_out, dim);
     qm_alloc(dev_grad_out, dim);
@@ -660,6 +753,7 @@ void cuda_scale_constructor(float **dev_w, float **dev_w_del, float **dev_w_best
 void cuda_scale_init(float *dev_w, float *dev_w_del, float *dev_out, float *dev_grad_out, float *w,
                      unsigned int dim)
 {
+    QM_SYNC_WRITES();
     zero_f(dev_w_del, 1);
     zero_f(dev_out, dim);
     zero_f(dev_grad_out, dim);
@@ -670,14 +764,15 @@ void cuda_scale_fwd(float *dev_in, float *dev_w, float *dev_out, unsigned int di
                     unsigned int iwl, unsigned int frac, unsigned int f_mode, bool verbose)
 {
     (void)f_fixed; (void)iwl; (void)frac; (void)f_mode; (void)verbose;
-    if (dim == 0) return;
-    k_vec_scale<<<qm_cdiv(dim, kBlock), kBlock, 0, 0>>>(dev_in, dev_w, dev_out, dim);
-    QM_LAUNCH_CHECK();
+    Op op{};
+    op.kind = qmdefer::kScale; op.in = dev_in; op.w = dev_w; op.out = dev_out; op.r = dim;
+    if (!qmdefer::submit(op)) qmdefer::run_now(op);
 }
 
 void cuda_scale_destructor(float *dev_w, float *dev_w_del, float *dev_w_best, float *dev_out,
                            float *dev_grad_out)
 {
+    QM_SYNC_WRITES();
     free_dev(dev_w); free_dev(dev_w_del); free_dev(dev_w_best); free_dev(dev_out); free_dev(dev_grad_out);
 }
 
@@ -685,28 +780,33 @@ void cuda_scale_destructor(float *dev_w, float *dev_w_del, float *dev_w_best, fl
 void cuda_mult_e_vec_constructor(float **dev_out_vec, float **dev_grad_out_a, float **dev_grad_out_b,
                                  unsigned int dim)
 {
+    QM_SYNC_WRITES();
     qm_alloc(dev_out_vec, dim); qm_alloc(dev_grad_out_a, dim); qm_alloc(dev_grad_out_b, dim);
 }
 
 void cuda_mult_e_vec_init(float *dev_out_vec, float *dev_grad_out_a, float *dev_grad_out_b, unsigned int dim)
 {
+    QM_SYNC_WRITES();
     zero_f(dev_out_vec, dim); zero_f(dev_grad_out_a, dim); zero_f(dev_grad_out_b, dim);
 }
 
 void cuda_mult_e_vec_fwd(float *dev_in_vec_a, float *dev_in_vec_b, float *dev_out_vec, float *in_vec_a,
                          float *in_vec_b, float *out_vec, unsigned int dim)
 {
+    QM_SYNC_WRITES();
     (void)in_vec_a; (void)in_vec_b; (void)out_vec;
     if (dim == 0) return;
     k_vec_mul<<<qm_cdiv(dim, kBlock), kBlock, 0, 0>>>(dev_in_vec_a, dev_in_vec_b, dev_out_vec, dim);
     QM_LAUNCH_CHECK();
 }
 
-void cuda_mult_e_vec_destructor(void) {}
+void cuda_mult_e_vec_destructor(void) {
+    QM_SYNC_WRITES();}
 
 void cuda_mult_e_mat_constructor(float **dev_out_mat, float **dev_grad_out_a, float **dev_grad_out_b,
                                  unsigned int dim_row, unsigned int dim_col)
 {
+    QM_SYNC_WRITES();
     const size_t n = (size_t)dim_row * dim_col;
     qm_alloc(dev_out_mat, n); qm_alloc(dev_grad_out_a, n); qm_alloc(dev_grad_out_b, n);
 }
@@ -714,6 +814,7 @@ void cuda_mult_e_mat_constructor(float **dev_out_mat, float **dev_grad_out_a, fl
 void cuda_mult_e_mat_init(float *dev_out_mat, float *dev_grad_out_a, float *dev_grad_out_b,
                           unsigned int dim_row, unsigned int dim_col)
 {
+    QM_SYNC_WRITES();
     const size_t n = (size_t)dim_row * dim_col;
     zero_f(dev_out_mat, n); zero_f(dev_grad_out_a, n); zero_f(dev_grad_out_b, n);
 }
@@ -721,6 +822,7 @@ void cuda_mult_e_mat_init(float *dev_out_mat, float *dev_grad_out_a, float *dev_
 void cuda_mult_e_mat_fwd(float *dev_in_mat_a, float *dev_in_mat_b, float *dev_out_mat, float *in_mat_a,
                          float *in_mat_b, float *out_mat, unsigned int dim_row, unsigned int dim_col)
 {
+    QM_SYNC_WRITES();
     (void)in_mat_a; (void)in_mat_b; (void)out_mat;
     const unsigned n = dim_row * dim_col;
     if (n == 0) return;
@@ -728,12 +830,14 @@ void cuda_mult_e_mat_fwd(float *dev_in_mat_a, float *dev_in_mat_b, float *dev_ou
     QM_LAUNCH_CHECK();
 }
 
-void cuda_mult_e_mat_destructor(void) {}
+void cuda_mult_e_mat_destructor(void) {
+    QM_SYNC_WRITES();}
 
 // ------------------------------------------------- helpers MemN2N.o calls itself
 void cuda_data_constructor(float **dev_m, float **dev_q, float **dev_a, unsigned int dim_len,
                            unsigned int dim_in, unsigned int num_sample)
 {
+    QM_SYNC_WRITES();
     qm_alloc(dev_m, (size_t)dim_len * dim_in);
     qm_alloc(dev_q, (size_t)num_sample * dim_in);
     qm_alloc(dev_a, (size_t)num_sample * dim_in);
@@ -742,6 +846,7 @@ void cuda_data_constructor(float **dev_m, float **dev_q, float **dev_a, unsigned
 void cuda_data_in(float *dev_m, float *dev_q, float *dev_a, float *m, float *q, float *a, unsigned int dim_len,
                   unsigned int dim_in, unsigned int num_sample)
 {
+    QM_SYNC_WRITES();
     QM_HIP(hipMemcpy(dev_m, m, (size_t)dim_len * dim_in * sizeof(float), hipMemcpyHostToDevice));
     QM_HIP(hipMemcpy(dev_q, q, (size_t)num_sample * dim_in * sizeof(float), hipMemcpyHostToDevice));
     QM_HIP(hipMemcpy(dev_a, a, (size_t)num_sample * dim_in * sizeof(float), hipMemcpyHostToDevice));
@@ -749,18 +854,22 @@ void cuda_data_in(float *dev_m, float *dev_q, float *dev_a, float *m, float *q, 
 
 void cuda_data_destructor(float *dev_m, float *dev_q, float *dev_a)
 {
+    QM_SYNC_WRITES();
     free_dev(dev_m); free_dev(dev_q); free_dev(dev_a);
 }
 
 void cuda_dup_grad_constructor(float **dev_dup_grad, unsigned int num_hop, unsigned int dim)
 {
+    QM_SYNC_WRITES();
     qm_alloc(dev_dup_grad, (size_t)num_hop * dim);
 }
 
-void cuda_dup_grad_destructor(float *dev_dup_grad) { free_dev(dev_dup_grad); }
+void cuda_dup_grad_destructor(float *dev_dup_grad) {
+    QM_SYNC_WRITES(); free_dev(dev_dup_grad); }
 
 void cuda_copy_mat(float *dev_src, float *dev_dest, unsigned int dim_col, unsigned int dim_row, bool f_trans)
 {
+    QM_SYNC_WRITES();
     const unsigned n = dim_col * dim_row;
     if (n == 0) return;
     k_copy_mat<false><<<qm_cdiv(n, kBlock), kBlock, 0, 0>>>(dev_src, dev_dest, dim_col, dim_row, f_trans);
@@ -769,6 +878,7 @@ void cuda_copy_mat(float *dev_src, float *dev_dest, unsigned int dim_col, unsign
 
 void cuda_accum_mat(float *dev_src, float *dev_dest, unsigned int dim_col, unsigned int dim_row, bool f_trans)
 {
+    QM_SYNC_WRITES();
     const unsigned n = dim_col * dim_row;
     if (n == 0) return;
     k_copy_mat<true><<<qm_cdiv(n, kBlock), kBlock, 0, 0>>>(dev_src, dev_dest, dim_col, dim_row, f_trans);
@@ -777,6 +887,7 @@ void cuda_accum_mat(float *dev_src, float *dev_dest, unsigned int dim_col, unsig
 
 void cuda_set_value(float *dest, float value, unsigned int dim, unsigned int start_idx, unsigned int stride)
 {
+    QM_SYNC_WRITES();
     if (dim == 0 || stride == 0) return;
     k_set_value<<<qm_cdiv(dim, kBlock), kBlock, 0, 0>>>(dest, value, dim, start_idx, stride);
     QM_LAUNCH_CHECK();
@@ -784,6 +895,7 @@ void cuda_set_value(float *dest, float value, unsigned int dim, unsigned int sta
 
 void cuda_copy_dev2host(float *host, float *dev, unsigned int size)
 {
+    QM_SYNC_READS();
     QM_HIP(hipMemcpy(host, dev, (size_t)size * sizeof(float), hipMemcpyDeviceToHost));
 }
 

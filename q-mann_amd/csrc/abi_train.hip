@@ -14,6 +14,7 @@
 // :4265/:4396 (mult_e).
 #include "qfmt.h"
 #include "rt.h"
+#include "defer.h"
 #include "../../include/qmann_abi.h"
 
 #include <string.h>
@@ -267,6 +268,7 @@ void cuda_dot_mat_vec_bwd(float *dev_in_mat, float *dev_in_vec, float *dev_grad_
                           bool f_fixed, unsigned int iwl_m, unsigned int frac_m, unsigned int iwl_v, unsigned int frac_v,
                           unsigned int f_mode, bool verbose)
 {
+    QM_SYNC_WRITES();
     (void)dev_f_overflow; (void)iwl_v; (void)frac_v; (void)f_mode; (void)verbose;
     if (r == 0 || c == 0) return;
     const QFmt fm{iwl_m, frac_m}, fg{1u, iwl_m + frac_m - 1u};
@@ -290,6 +292,7 @@ void cuda_dot_mat_vec_bwd_appx(float *dev_in_mat, float *dev_in_vec, float *dev_
                                unsigned int c, bool f_fixed, unsigned int iwl, unsigned int frac, unsigned int f_mode,
                                unsigned int num_bit_attention, bool f_trans, bool verbose, unsigned int hop)
 {
+    QM_SYNC_WRITES();
     (void)dev_cliff_marker; (void)hop;
     if (f_trans) {
         cuda_dot_mat_vec_bwd(dev_in_mat, dev_in_vec, dev_grad_in, dev_grad_out_mat, dev_grad_out_vec, dev_f_overflow, r,
@@ -308,6 +311,7 @@ void cuda_dot_mat_vec_bwd_appx(float *dev_in_mat, float *dev_in_vec, float *dev_
 void cuda_softmax_bwd(float *dev_grad_in, float *dev_out_vec, float *dev_grad_out, float *dev_in_vec, unsigned int dim,
                       bool f_shift_based, bool verbose)
 {
+    QM_SYNC_WRITES();
     (void)dev_in_vec; (void)verbose;
     if (dim == 0) return;
     k_softmax_bwd<<<1, kBlock, 0, 0>>>(dev_out_vec, dev_grad_in, dev_grad_out, dim, f_shift_based);
@@ -316,6 +320,7 @@ void cuda_softmax_bwd(float *dev_grad_in, float *dev_out_vec, float *dev_grad_ou
 
 void cuda_sum_vec_bwd(float *dev_grad_out, float *dev_grad_in, float *grad_in, float *grad_out, unsigned int dim)
 {
+    QM_SYNC_WRITES();
     (void)grad_in; (void)grad_out;
     if (dim == 0) return;
     k_copy<<<cdiv(dim, kBlock), kBlock, 0, 0>>>(dev_grad_in, dev_grad_out, dim);
@@ -327,6 +332,7 @@ void cuda_dense_bwd(float *dev_w_mat, float *dev_w_mat_del, float *dev_bias, flo
                     unsigned int dim_in, unsigned int dim_out, char *activation, bool f_fixed, unsigned int iwl_in,
                     unsigned int frac_in, unsigned int iwl_w, unsigned int frac_w, unsigned int f_mode, bool verbose)
 {
+    QM_SYNC_WRITES();
     (void)dev_bias; (void)dev_bias_del; (void)dev_f_overflow; (void)f_mode; (void)verbose;
     if (dim_in == 0 || dim_out == 0) return;
     const QFmt fw{iwl_w, frac_w}, fi{iwl_in, frac_in}, fg{1u, iwl_w + frac_w - 1u};
@@ -360,6 +366,7 @@ void cuda_dense_w_up(float *dev_w_mat, float *dev_w_mat_del, float *dev_bias, fl
                      unsigned int batch_size, float *lr, float *lambda, float *max_grad_l2_norm, bool f_fixed,
                      unsigned int iwl, unsigned int frac, unsigned int f_mode, bool verbose)
 {
+    QM_SYNC_WRITES();
     (void)dev_bias; (void)dev_bias_del; (void)dev_grad_bias_l2_norm; (void)f_mode; (void)verbose;
     mat_w_up(dev_w_mat, dev_w_mat_del, dev_grad_l2_norm, dim_in, dim_out, batch_size, *lr, *lambda, *max_grad_l2_norm,
              f_fixed, iwl, frac);
@@ -370,6 +377,7 @@ void cuda_dense_mat_bwd(float *dev_in_mat, float *dev_w_mat, float *dev_w_mat_de
                         unsigned int dim_out, unsigned int dim_len, bool f_fixed, unsigned int iwl, unsigned int frac,
                         unsigned int f_mode, bool verbose)
 {
+    QM_SYNC_WRITES();
     (void)dev_bias; (void)dev_bias_del; (void)dev_f_overflow; (void)f_mode; (void)verbose;
     if (dim_in == 0 || dim_out == 0 || dim_len == 0) return;
     const QFmt f{iwl, frac}, fg{1u, iwl + frac - 1u};
@@ -388,6 +396,7 @@ void cuda_dense_mat_w_up(float *dev_w_mat, float *dev_w_mat_del, float *dev_bias
                          float *max_grad_l2_norm, bool f_fixed, unsigned int iwl, unsigned int frac, unsigned int f_mode,
                          bool verbose)
 {
+    QM_SYNC_WRITES();
     (void)dev_bias; (void)dev_bias_del; (void)dev_grad_bias_l2_norm; (void)w_mat; (void)w_mat_del; (void)f_mode; (void)verbose;
     mat_w_up(dev_w_mat, dev_w_mat_del, dev_grad_l2_norm, dim_in, dim_out, batch_size, *lr, *lambda, *max_grad_l2_norm,
              f_fixed, iwl, frac);
@@ -396,6 +405,7 @@ void cuda_dense_mat_w_up(float *dev_w_mat, float *dev_w_mat_del, float *dev_bias
 void cuda_activation_bwd(float *dev_out, float *dev_grad_in, float *dev_grad_out, char *type_act, unsigned int dim,
                          bool f_fixed, unsigned int iwl, unsigned int frac, unsigned int f_mode)
 {
+    QM_SYNC_WRITES();
     (void)f_mode;
     if (dim == 0) return;
     k_act_bwd<<<cdiv(dim, kBlock), kBlock, 0, 0>>>(dev_out, dev_grad_in, dev_grad_out, dim, act_id(type_act), f_fixed,
@@ -406,6 +416,7 @@ void cuda_activation_bwd(float *dev_out, float *dev_grad_in, float *dev_grad_out
 void cuda_scale_bwd(float *dev_in, float *dev_grad_in, float *dev_w, float *dev_w_del, float *dev_grad_out,
                     unsigned int dim, bool f_fixed, unsigned int iwl, unsigned int frac, unsigned int f_mode, bool verbose)
 {
+    QM_SYNC_WRITES();
     (void)f_fixed; (void)iwl; (void)frac; (void)f_mode; (void)verbose;
     if (dim == 0) return;
     k_scale_bwd<<<cdiv(dim, kBlock), kBlock, 0, 0>>>(dev_grad_in, dev_in, dev_w, dev_w_del, dev_grad_out, dim);
@@ -415,6 +426,7 @@ void cuda_scale_bwd(float *dev_in, float *dev_grad_in, float *dev_w, float *dev_
 void cuda_scale_w_up(float *dev_w, float *dev_w_del, unsigned int dim, unsigned int batch_size, float *lr,
                      float *lambda, bool f_fixed, unsigned int iwl, unsigned int frac, unsigned int f_mode, bool verbose)
 {
+    QM_SYNC_WRITES();
     (void)f_fixed; (void)iwl; (void)frac; (void)f_mode; (void)verbose;
     k_scalar_w_up<<<1, 1, 0, 0>>>(dev_w, dev_w_del, batch_size * dim, *lr, *lambda);
     QM_LAUNCH_CHECK();
@@ -423,6 +435,7 @@ void cuda_scale_w_up(float *dev_w, float *dev_w_del, unsigned int dim, unsigned 
 void cuda_mult_e_vec_bwd(float *dev_in_vec_a, float *dev_in_vec_b, float *dev_grad_out_a, float *dev_grad_out_b,
                          float *dev_grad_in, float *grad_in, float *grad_out_a, float *grad_out_b, unsigned int dim)
 {
+    QM_SYNC_WRITES();
     (void)grad_in; (void)grad_out_a; (void)grad_out_b;
     if (dim == 0) return;
     k_vec_mul<<<cdiv(dim, kBlock), kBlock, 0, 0>>>(dev_grad_in, dev_in_vec_b, dev_grad_out_a, dim);
@@ -434,6 +447,7 @@ void cuda_mult_e_mat_bwd(float *dev_in_mat_a, float *dev_in_mat_b, float *dev_gr
                          float *dev_grad_in, float *grad_in, float *grad_out_a, float *grad_out_b, unsigned int dim_row,
                          unsigned int dim_col)
 {
+    QM_SYNC_WRITES();
     cuda_mult_e_vec_bwd(dev_in_mat_a, dev_in_mat_b, dev_grad_out_a, dev_grad_out_b, dev_grad_in, grad_in, grad_out_a,
                         grad_out_b, dim_row * dim_col);
 }
@@ -441,6 +455,7 @@ void cuda_mult_e_mat_bwd(float *dev_in_mat_a, float *dev_in_mat_b, float *dev_gr
 void cuda_dup_grad_bwd(float *dev_dup_grad, float *dotmv_dev_grad_out_vec, float *sv_dev_grad_out_vec, float *dup_grad,
                        unsigned int dim, bool f_fixed, unsigned int iwl, unsigned int frac, unsigned int f_mode)
 {
+    QM_SYNC_WRITES();
     (void)dup_grad; (void)f_mode;
     if (dim == 0) return;
     k_vec_sum_q<<<cdiv(dim, kBlock), kBlock, 0, 0>>>(dotmv_dev_grad_out_vec, sv_dev_grad_out_vec, dev_dup_grad, dim,

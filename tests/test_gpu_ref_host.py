@@ -17,8 +17,18 @@ pytestmark = pytest.mark.gpu
 BIN = ROOT / "oracle" / "_ref" / "ref_host_infer"
 
 
+# how the host reads results back x what the library does with the forward verbs (include/qmann_abi.h, "Deferred execution"):
+#   each / off      every verb launches at once (the round-1/2 behaviour)
+#   each / on       the host fetches pred and u after every query: every drain holds ONE query (a batch of one through the
+#                   batched kernels for the accumulators, then its replay verb by verb for the buffers)
+#   loop / on       nothing is read back inside the loop, as in MemN2N.c's own test loop: ONE batched forward for all queries
+#   loop / verify   the same run computed both ways inside the library, which prints the two match counts
+HOST_MODES = [("each", "0"), ("each", "1"), ("loop", "1"), ("loop", "verify")]
+
+
+@pytest.mark.parametrize("host,defer", HOST_MODES)
 @pytest.mark.parametrize("att_mode,iwl,en_mq", [(2, 2, 1), (2, 2, 0), (3, 2, 0), (2, 5, 1)])
-def test_reference_layer_api_drives_our_library(oracle, gold, tmp_path, att_mode, iwl, en_mq):
+def test_reference_layer_api_drives_our_library(oracle, gold, tmp_path, att_mode, iwl, en_mq, host, defer):
     if not BIN.exists():
         pytest.skip("oracle/_ref/ref_host_infer not built (needs /root/reference at build time)")
     b = gold("babi_qa1_test64.npz")
@@ -33,8 +43,20 @@ def test_reference_layer_api_drives_our_library(oracle, gold, tmp_path, att_mode
     with open(fin, "wb") as f:
         f.write(struct.pack("8I", V, D, H, nq, iwl, att_mode, en_mq, 4242))
         f.write(n_sen.tobytes()); f.write(story.tobytes()); f.write(ques.tobytes()); f.write(ans.tobytes())
-    r = subprocess.run([str(BIN), str(fin), str(fout)], capture_output=True, text=True, timeout=300)
+    import os
+    env = dict(os.environ, QMANN_DEFER=defer, QMANN_DEFER_STATS="1")
+    r = subprocess.run([str(BIN), str(fin), str(fout)] + (["deferred"] if host == "loop" else []), capture_output=True, text=True,
+                       timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
+    stats = [l for l in r.stderr.splitlines() if l.startswith("[qmann defer]")]
+    if defer == "0":
+        assert not stats or "queries batched 0 " in stats[0]
+    else:
+        batched = int(stats[0].split("queries batched ")[1].split()[0]); runs = int(stats[0].split(" in ")[1].split()[0])
+        assert batched == nq and runs == (nq if host == "each" else 1), stats[0]
+    if defer == "verify":
+        v = [l for l in r.stderr.splitlines() if l.startswith("[qmann defer verify]")]
+        assert len(v) == 1 and v[0].endswith("equal") and f"{nq} queries" in v[0], r.stderr[-1500:]
     raw = np.fromfile(fout, dtype=np.uint8)
     off = 0
 
@@ -74,28 +96,34 @@ def test_reference_layer_api_drives_our_library(oracle, gold, tmp_path, att_mode
         ns = int(n_sen[q])
         opred, t = oracle.forward(m, story[o:o + ns], ques[q], taps=("u", "probs", "out_probs"))
         o += ns
+        y = int(ans[q].argmax())
+        want_cost -= float(t["out_probs"][y])
+        if host == "loop" and q < nq - 1:           # (nothing was read back for this query; the oracle's prediction counts)
+            n_match += int(opred == y)
+            continue
         # hop outputs are exact unless an attention weight sat on a truncation step (none here)
         np.testing.assert_array_equal(us[q], t["u"][H - 1], err_msg=f"final u, query {q}")
         top2 = np.sort(t["out_probs"])[-2:]
         if top2[1] - top2[0] > 1e-6:
             assert preds[q] == opred, f"prediction, query {q}"
-        y = int(ans[q].argmax())
         n_match += int(preds[q] == y)
-        want_cost -= float(t["out_probs"][y])
     assert match == n_match
     assert cost == pytest.approx(want_cost, rel=1e-4)
 
 
 # (binary, attention mode it prints, required drop of the training error, cap on the test error)
-@pytest.mark.parametrize("binary,mode_name,drop,cap", [
-    ("MemN2N_ref", "quantized", 0.2, 0.75),
-    ("MemN2N_ref_mode3", "approximate", 0.1, 0.95),
-    ("MemN2N_ref_cfg1", "normal", 0.2, 0.75),          # BASELINE config 1: float dot attention, no fixed point, one hop
+# last column: does the validation / test phase of this build go through the batched forward (deferred queue)?
+#   mode3 with EN_MQ: no -- the embedding grids (Q6.1 / Q4.3) do not lie inside the Hamming attention's grid (Q5.2), the
+#   byte arithmetic of the batched kernels cannot carry them; cfg1: no -- EN_FIXED_POINT false, nothing is quantised
+@pytest.mark.parametrize("binary,mode_name,drop,cap,batched", [
+    ("MemN2N_ref", "quantized", 0.2, 0.75, True),
+    ("MemN2N_ref_mode3", "approximate", 0.1, 0.95, False),
+    ("MemN2N_ref_cfg1", "normal", 0.2, 0.75, False),   # BASELINE config 1: float dot attention, no fixed point, one hop
     # shift-based softmax + scale layer + RELU layers switched on together: their verbs inside the reference's
     # own loops; a functional run (finite errors), not a learning claim for this combination
-    ("MemN2N_ref_feat", "quantized", None, 1.0),
+    ("MemN2N_ref_feat", "quantized", None, 1.0, True),
 ])
-def test_unmodified_reference_program_trains_and_tests(gold, tmp_path, binary, mode_name, drop, cap):
+def test_unmodified_reference_program_trains_and_tests(gold, tmp_path, binary, mode_name, drop, cap, batched):
     """oracle/_ref/MemN2N_ref is the reference's whole host program -- MemN2N.c, sample.c, layer.c, common.c
     compiled where they lie with its own define.h -- linked against libqmann_hip.so in place of the CUDA
     object.  `./MemN2N 1 1 1 5` (run.sh's command line for task 1, one loop): 100 epochs of SGD, then the
@@ -108,12 +136,19 @@ def test_unmodified_reference_program_trains_and_tests(gold, tmp_path, binary, m
     d.mkdir(parents=True)
     (d / "qa1_single-supporting-fact_train_set").write_bytes(g["train_set"].tobytes())
     (d / "qa1_single-supporting-fact_test_set").write_bytes(g["test_set"].tobytes())
+    import os
     with open(tmp_path / "stdout.log", "w") as out:
         r = subprocess.run([str(exe), "1", "1", "1", "5"], cwd=tmp_path, stdout=out, stderr=subprocess.STDOUT,
-                           timeout=900)
+                           timeout=900, env=dict(os.environ, QMANN_DEFER_STATS="1"))
     text = (tmp_path / "stdout.log").read_text(errors="replace")
     assert r.returncode == 0, text[-3000:]
     assert f"ATTENTION MODE : {mode_name}" in text
+    stats = [l for l in text.splitlines() if l.startswith("[qmann defer]")]
+    assert len(stats) == 1, text[-2000:]
+    n_batched = int(stats[0].split("queries batched ")[1].split()[0])
+    # 100 validation stories after each of the 100 epochs + the 1 000 test stories
+    assert n_batched == (100 * 100 + 1000 if batched else 0), stats[0]
+    print(stats[0])
     itr = [l for l in text.splitlines() if l.startswith("< ITR")]
     assert len(itr) == 100
     err = [float(l.split("error:")[1].split(",")[0]) for l in itr]
@@ -125,3 +160,95 @@ def test_unmodified_reference_program_trains_and_tests(gold, tmp_path, binary, m
     res = (tmp_path / "result.csv").read_text().strip().split(",")
     err_test = float(res[10])
     assert 0.0 <= err_test <= cap, err_test                     # chance is 5 of 6 wrong
+
+
+def _bow(words, V, with_time):
+    out = np.zeros((words.shape[0], V), np.float32)
+    for r, row in enumerate(words):
+        ent = [int(w) for w in row if w != 0xFFFF]
+        t = ent.pop() if (with_time and ent) else None
+        for w in ent:
+            out[r, w] += 1.0
+        if t is not None:
+            out[r, t] = 1.0
+    return out
+
+
+@pytest.mark.parametrize("binary,att_mode,en_mq", [("MemN2N_ref", 2, True), ("MemN2N_ref_mode3nomq", 3, False)])
+def test_trained_weights_batched_forward_equals_the_reference_programs_own_test_error(gold, oracle, tmp_path, binary, att_mode, en_mq):
+    """End to end on TRAINED weights (peaky softmaxes, saturated codes -- what seeded random weights never show).
+    The reference's unmodified program trains on bAbI task 1 and tests; the library, in verify mode, computes the test
+    phase BOTH ways -- verb by verb (that count goes into the program's accumulators: its printed err(test),
+    MemN2N.c:2701-2703 / result.csv) and through the batched forward -- and writes the matrices it tested with
+    (QMANN_SAVE_WEIGHTS_DIR: the reference's own weight-file layout + the quantised parameter blob).  Then, in THIS process:
+      * the record files are read natively into word lists (qmann_dataset.h) and run through qmann_model_forward_words with
+        a model from the saved float files AND one from the saved blob: same predictions, and their match count is the
+        count the reference program printed;
+      * every story's prediction equals the CPU oracle's with those weights."""
+    import os
+    import torch
+    from conftest import load_pkg
+    load_pkg()
+    import qmann_amd.abi as abi
+    import qmann_amd.model as model
+    exe = ROOT / "oracle" / "_ref" / binary
+    if not exe.exists():
+        pytest.skip(f"oracle/_ref/{binary} not built (needs /root/reference at build time)")
+    g = gold("babi_qa1_en1k_sets.npz")
+    d = tmp_path / "dataset" / "en_10k_parsed"
+    d.mkdir(parents=True)
+    train_f, test_f = d / "qa1_single-supporting-fact_train_set", d / "qa1_single-supporting-fact_test_set"
+    train_f.write_bytes(g["train_set"].tobytes()); test_f.write_bytes(g["test_set"].tobytes())
+    wdir = tmp_path / "weights"; wdir.mkdir()
+    with open(tmp_path / "stdout.log", "w") as out:
+        r = subprocess.run([str(exe), "1", "1", "1", "5"], cwd=tmp_path, stdout=out, stderr=subprocess.STDOUT, timeout=900,
+                           env=dict(os.environ, QMANN_DEFER="verify", QMANN_DEFER_STATS="1", QMANN_SAVE_WEIGHTS_DIR=str(wdir)))
+    text = (tmp_path / "stdout.log").read_text(errors="replace")
+    assert r.returncode == 0, text[-3000:]
+    ver = [l for l in text.splitlines() if l.startswith("[qmann defer verify]")]
+    assert ver and not [l for l in ver if "MISMATCH" in l], "\n".join(ver[-5:])
+    tst = [l for l in ver if "1000 queries (cross_entropy mode 3)" in l]
+    assert len(tst) == 1, ver[-3:]
+    m_batched = int(tst[0].split("batched match ")[1].split()[0]); m_verbs = int(tst[0].split("op-by-op match ")[1].split()[0])
+    err_test = float((tmp_path / "result.csv").read_text().strip().split(",")[10])
+    assert m_verbs == m_batched and err_test == pytest.approx(1.0 - m_verbs / 1000.0, abs=1e-6)
+    print(tst[0]); print("err(test) printed by the reference program:", err_test)
+
+    # the same test set, read natively, through the batched forward in this process
+    ds = abi.load_dataset(train_f, test_f, 50)
+    V, D, H = ds["dim_input"], 60, 3
+    cfg = model.babi_cfg(V, attention_mode=att_mode, softmax_base=0, iwl=5, en_mq=en_mq)
+    wts = model.load_weights(wdir, cfg)
+    dev = torch.device("cuda:0")
+    n_sen = np.diff(ds["row_off"].astype(np.int64))
+    args = (torch.from_numpy(ds["story_words"].view(np.int16)).to(dev), torch.from_numpy(ds["question_words"].view(np.int16)).to(dev),
+            torch.from_numpy(ds["row_off"].astype(np.int32)).to(dev), int(n_sen.max()),
+            torch.from_numpy(ds["answer"].astype(np.int64).astype(np.int32)).to(dev))
+    hm = model.HostModel(cfg, wts)
+    pred, _, match = hm.forward_words(*args); torch.cuda.synchronize()
+    blob = np.fromfile(wdir / "qmann_params.bin", np.uint8)
+    hb = model.HostModel.from_params(cfg, blob.ctypes.data, blob.size)
+    pred_b, _, match_b = hb.forward_words(*args); torch.cuda.synchronize()
+    pred = pred.cpu().numpy()
+    np.testing.assert_array_equal(pred_b.cpu().numpy(), pred)
+    assert int(match.item()) == int(match_b.item()) == m_verbs, (int(match.item()), m_verbs)
+    hm.close(); hb.close()
+    # trained matrices are tied across the hops and sit on their grids; peaky attention is the point of this test
+    m = oracle.make_model(cfg, wts)
+    offs = ds["row_off"].astype(np.int64)
+    agree = near_tie = 0
+    p_max = []
+    for q in range(ds["n_query"]):
+        st = _bow(ds["story_words"][offs[q]:offs[q + 1]], V, True)
+        qu = _bow(ds["question_words"][q:q + 1], V, False)[0]
+        op, t = oracle.forward(m, st, qu, taps=("probs", "out_probs"))
+        p_max.append(float(np.max(t["probs"][H - 1])))
+        top2 = np.sort(t["out_probs"])[-2:]
+        if top2[1] - top2[0] <= 1e-6:
+            near_tie += 1
+            continue
+        assert int(pred[q]) == op, f"story {q}: batched {int(pred[q])}, oracle {op}"
+        agree += 1
+    assert agree >= ds["n_query"] - 5, (agree, near_tie)
+    print(f"oracle: {agree} of {ds['n_query']} predictions equal ({near_tie} near-ties skipped); last-hop max p: mean {np.mean(p_max):.3f}, "
+          f"{np.mean(np.array(p_max) > 0.9) * 100:.0f} % above 0.9")
