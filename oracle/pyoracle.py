@@ -103,6 +103,9 @@ class Oracle:
         L.qo_memn2n_forward.argtypes = [C.POINTER(QoModel), _f32p, u, _f32p, C.POINTER(QoTaps)]
         L.qo_memn2n_forward_mem.restype = u
         L.qo_memn2n_forward_mem.argtypes = [C.POINTER(QoModel), _f32p, _f32p, u, _f32p, C.POINTER(QoTaps)]
+        vp = C.c_void_p
+        L.qo_memn2n_forward_words_batch.restype = None
+        L.qo_memn2n_forward_words_batch.argtypes = [C.POINTER(QoModel), vp, u, vp, u, vp, u, u, vp, vp, vp, vp]
 
     # ---- scalar helpers (vectorised over numpy inputs for convenience) ----
     def quant(self, x, iwl, frac):
@@ -288,6 +291,24 @@ class Oracle:
         t, arrs = self._taps(m, n_sen, taps)
         pred = self.L.qo_memn2n_forward(C.byref(m), _fp(story), n_sen, _fp(question), C.byref(t))
         return int(pred), arrs
+
+    def forward_words_batch(self, m, story_words, question_words, row_off, n_threads=None):
+        """every story of a set through qo_memn2n_forward on C threads.  story_words uint16 [rows][W] (the last valid entry of a
+        row is its time index), question_words uint16 [n][Wq], row_off [n + 1].  Returns pred [n] uint32, u_final [n][D],
+        top2_gap [n] (two largest output probabilities), near_step [n] bool (a softmax weight on a truncation step)."""
+        import os
+        sw = np.ascontiguousarray(story_words, np.uint16); qw = np.ascontiguousarray(question_words, np.uint16)
+        ro = np.ascontiguousarray(row_off, np.uint32)
+        n = qw.shape[0]
+        if sw.shape[0] == 0:
+            sw = np.full((1, max(sw.shape[1], 1)), 0xFFFF, np.uint16)
+        pred = np.zeros(n, np.uint32); u = np.zeros((n, m.dim_emb), np.float32)
+        gap = np.zeros(n, np.float32); near = np.zeros(n, np.uint8)
+        nt = n_threads or min(64, max(1, len(os.sched_getaffinity(0))))
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+        self.L.qo_memn2n_forward_words_batch(C.byref(m), ptr(sw), sw.shape[1], ptr(qw), qw.shape[1], ptr(ro), n, nt, ptr(pred), ptr(u),
+                                             ptr(gap), ptr(near))
+        return pred, u, gap, near.astype(bool)
 
     def forward_mem(self, m, keys, vals, u0, taps=("scores", "probs", "o", "lu", "u", "logits", "out_probs")):
         keys = np.ascontiguousarray(keys, np.float32); vals = np.ascontiguousarray(vals, np.float32)

@@ -706,3 +706,99 @@ unsigned qo_memn2n_forward(const qo_model *m, const float *story, unsigned n_sen
     free(u); free(keys); free(vals);
     return pred;
 }
+
+/* ------------------------------------------------------------------------ */
+/* batch driver for the tests: many stories given as word lists, on threads  */
+/* ------------------------------------------------------------------------ */
+#include <pthread.h>
+
+/* uint16 word lists -> the float bag-of-words rows sample.c builds (MemN2N/sample.c:466-475, 544-548): word entries COUNT
+ * occurrences, the last valid entry of a STORY row is its time index and is SET to 1; 0xFFFF = unused slot; words outside
+ * the dictionary are ignored.  (Position encoding is not handled here: the tests that use EN_PE build their rows themselves.) */
+static void words_to_row(const uint16_t *w, unsigned width, unsigned V, int with_time, float *row)
+{
+    memset(row, 0, V * sizeof(float));
+    int last = -1;
+    for (unsigned k = 0; k < width; k++)
+        if (w[k] != 0xFFFFu) last = (int)k;
+    for (int k = 0; k <= last; k++) {
+        if (w[k] == 0xFFFFu || w[k] >= V) continue;
+        if (with_time && k == last) row[w[k]] = 1.0f;
+        else row[w[k]] += 1.0f;
+    }
+}
+
+typedef struct {
+    const qo_model *m;
+    const uint16_t *sw, *qw;
+    unsigned sw_width, qw_width;
+    const uint32_t *row_off;
+    unsigned n_query, n_threads, tid;
+    uint32_t *pred;
+    float *u_final, *top2_gap;
+    uint8_t *near_step;
+} qo_batch_job;
+
+static void *qo_batch_worker(void *p)
+{
+    const qo_batch_job *j = (const qo_batch_job *)p;
+    const qo_model *m = j->m;
+    const unsigned V = m->dim_input, D = m->dim_emb, H = m->n_hop;
+    unsigned max_sen = 1;
+    for (unsigned q = 0; q < j->n_query; q++)
+        if (j->row_off[q + 1] - j->row_off[q] > max_sen) max_sen = j->row_off[q + 1] - j->row_off[q];
+    float *story = (float *)malloc((size_t)max_sen * V * sizeof(float));
+    float *ques = (float *)malloc(V * sizeof(float));
+    float *probs = (float *)malloc((size_t)H * max_sen * sizeof(float));
+    float *u = (float *)malloc((size_t)H * D * sizeof(float));
+    float *outp = (float *)malloc(V * sizeof(float));
+    for (unsigned q = j->tid; q < j->n_query; q += j->n_threads) {
+        const unsigned r0 = j->row_off[q], ns = j->row_off[q + 1] - r0;
+        for (unsigned s = 0; s < ns; s++) words_to_row(j->sw + (size_t)(r0 + s) * j->sw_width, j->sw_width, V, 1, story + (size_t)s * V);
+        words_to_row(j->qw + (size_t)q * j->qw_width, j->qw_width, V, 0, ques);
+        qo_taps t;
+        memset(&t, 0, sizeof t);
+        t.probs = probs; t.u = u; t.out_probs = outp;
+        j->pred[q] = qo_memn2n_forward(m, story, ns, ques, &t);
+        if (j->u_final) memcpy(j->u_final + (size_t)q * D, u + (size_t)(H - 1) * D, D * sizeof(float));
+        if (j->top2_gap) {
+            float a = -1.0f, b = -1.0f;
+            for (unsigned i = 0; i < V; i++) {
+                if (outp[i] > a) { b = a; a = outp[i]; }
+                else if (outp[i] > b) b = outp[i];
+            }
+            j->top2_gap[q] = a - b;
+        }
+        if (j->near_step) {
+            /* does a softmax weight of some hop sit within 1e-5 (relative) of a truncation step of Q(act[h])?  There the
+             * 1e-5 float tolerance of the softmax may move Q(p) by one code, and only there may a hop output differ */
+            uint8_t near = 0;
+            for (unsigned h = 0; h < H; h++)
+                for (unsigned s = 0; s < ns; s++) {
+                    const double x = (double)probs[(size_t)h * ns + s] * (double)(1u << m->frac[h]);
+                    const double k = (double)(long long)(x + 0.5);
+                    const double tol = 1e-5 * (x > 1.0 ? x : 1.0);
+                    if (k > 0.0 && (x > k ? x - k : k - x) <= tol) near = 1;
+                }
+            j->near_step[q] = near;
+        }
+    }
+    free(story); free(ques); free(probs); free(u); free(outp);
+    return NULL;
+}
+
+void qo_memn2n_forward_words_batch(const qo_model *m, const uint16_t *story_words, unsigned sw_width, const uint16_t *question_words,
+                                   unsigned qw_width, const uint32_t *row_off, unsigned n_query, unsigned n_threads, uint32_t *pred,
+                                   float *u_final, float *top2_gap, uint8_t *near_step)
+{
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 64) n_threads = 64;
+    pthread_t th[64];
+    qo_batch_job jobs[64];
+    for (unsigned t = 0; t < n_threads; t++) {
+        qo_batch_job j = {m, story_words, question_words, sw_width, qw_width, row_off, n_query, n_threads, t, pred, u_final, top2_gap, near_step};
+        jobs[t] = j;
+        pthread_create(&th[t], NULL, qo_batch_worker, &jobs[t]);
+    }
+    for (unsigned t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
+}

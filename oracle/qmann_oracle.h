@@ -154,6 +154,14 @@ unsigned qo_memn2n_forward(const qo_model *m, const float *story, unsigned n_sen
 unsigned qo_memn2n_forward_mem(const qo_model *m, const float *keys, const float *vals,
                                unsigned n_sen, const float *u0, qo_taps *taps);
 
+/* Test driver: the forward above for MANY stories given as uint16 word lists (the product's wire format; rows are expanded
+ * to the bag-of-words floats of sample.c per story), on n_threads threads.  pred [n], u_final [n][D] = sv[n_hop-1],
+ * top2_gap [n] = difference of the two largest output probabilities, near_step [n] = 1 when some in-hop softmax weight lies
+ * within 1e-5 of a truncation step of its format (the only place a hop output may legitimately differ by a code). */
+void qo_memn2n_forward_words_batch(const qo_model *m, const uint16_t *story_words, unsigned sw_width, const uint16_t *question_words,
+                                   unsigned qw_width, const uint32_t *row_off, unsigned n_query, unsigned n_threads, uint32_t *pred,
+                                   float *u_final, float *top2_gap, uint8_t *near_step);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,7 +60,8 @@ void init_mode()
     if (getenv("QMANN_DEFER_STATS"))
         atexit([] {
             const qmann_defer_stats &s = g_stats;
-            fprintf(stderr, "[qmann defer] verbs queued %llu, replayed one by one %llu; queries batched %llu in %llu runs (%.3f ms), "
+            fflush(stdout);
+            fprintf(stderr, "\n[qmann defer] verbs queued %llu, replayed one by one %llu; queries batched %llu in %llu runs (%.3f ms), "
                             "op-by-op %.3f ms, models built %llu (%.3f ms); verify: %llu runs, %llu mismatches\n",
                     (unsigned long long)s.ops_queued, (unsigned long long)s.ops_replayed, (unsigned long long)s.queries_batched,
                     (unsigned long long)s.batches, s.ms_batched, s.ms_replayed, (unsigned long long)s.models_built, s.ms_model,
@@ -315,12 +316,14 @@ __global__ void k_onehot_labels(const float *__restrict__ y, uint32_t n, uint32_
     }
 }
 
-void replay(const std::vector<Op> &ops, size_t a, size_t b)
+// verb-by-verb execution of ops [a, b); timed (device-synchronised when statistics are on) only for whole runs of queries,
+// not for the single verbs of a training step
+void replay(const std::vector<Op> &ops, size_t a, size_t b, bool timed = true)
 {
-    const double t0 = now_ms();
+    const double t0 = timed ? now_ms() : 0.0;
     for (size_t i = a; i < b; i++) run_now(ops[i]);
     g_stats.ops_replayed += b - a;
-    g_stats.ms_replayed += now_ms() - t0;
+    if (timed) g_stats.ms_replayed += now_ms() - t0;
 }
 
 // queries [a, b) of `qs` share `s` and lie back to back in the host's pools: one batched forward.  false = nothing was done
@@ -385,7 +388,8 @@ void dispatch_run(const std::vector<Op> &ops, const Sig &s, const std::vector<Qu
                 g_stats.queries_batched += b - a; g_stats.batches++; g_stats.ms_batched += t1 - t0;
                 const bool same = mb == m1 - m0;
                 if (!same) g_stats.verify_mismatch++;
-                fprintf(stderr, "[qmann defer verify] %zu queries (cross_entropy mode %u): batched match %u cost %.6f | op-by-op match %u cost %.6f | %s\n",
+                fflush(stdout);               // (a host that logs to a file: keep the line whole)
+                fprintf(stderr, "\n[qmann defer verify] %zu queries (cross_entropy mode %u): batched match %u cost %.6f | op-by-op match %u cost %.6f | %s\n",
                         b - a, s.ce_mode, mb, cb, m1 - m0, c1 - c0, same ? "equal" : "MISMATCH");
             }
         } else {
@@ -431,7 +435,7 @@ void drain()
             i += n;
         } else {
             close_run();
-            replay(ops, i, i + 1);
+            replay(ops, i, i + 1, /*timed=*/false);
             i++;
         }
     }

@@ -46,6 +46,10 @@ def weights(seed, H, D, V, sigma, with_emb=True):
     return w
 
 
+ORACLE_SM = {0: 0, 1: 1, 2: 2}       # qmann softmax_base -> the oracle's variant (QO_SM_CUDA, _CPU_POW2, _CPU_EXP_PLAN)
+E2E_FLOAT_EXCUSED = 8              # test_model_host_object, mode 1: observed maximum + 1 (set from the first full-suite run)
+
+
 def near_step(p, frac, rel=1e-5):
     """True where the oracle's p sits within `rel` of a Q(.frac) truncation step."""
     x = p.astype(np.float64) * (1 << frac)
@@ -53,7 +57,7 @@ def near_step(p, frac, rel=1e-5):
     return (np.abs(x - k) <= rel * np.maximum(1.0, np.abs(x))) & (k > 0)
 
 
-def run_case(env, oracle, cfg, B, S_list, seed, sigma_u=20.0, sigma_k=30.0, sigma_h=1.0, extra=None):
+def run_case(env, oracle, cfg, B, S_list, seed, sigma_u=20.0, sigma_k=30.0, sigma_h=1.0, extra=None, max_excused=0):
     """Random memories (ragged slot counts) -> hops + answer on the GPU vs the oracle per query."""
     torch, model = env.torch, env.model
     cfg = dict(cfg, **(extra or {}))
@@ -110,7 +114,8 @@ def run_case(env, oracle, cfg, B, S_list, seed, sigma_u=20.0, sigma_k=30.0, sigm
         top2 = np.sort(t["out_probs"])[-2:]
         if top2[1] - top2[0] > 1e-6:
             assert int(g_pred[q]) == opred, f"pred q{q}"
-    assert skipped <= max(1, B // 8), f"{skipped} of {B} queries hit the p-on-a-step exclusion"
+    # observed: 0 in every case of this file (the excuse exists for the float tolerance of the softmax)
+    assert skipped <= max_excused, f"{skipped} of {B} queries hit the p-on-a-step exclusion (bound {max_excused})"
     return skipped
 
 
@@ -212,7 +217,7 @@ def test_babi_end_to_end_from_bag_of_words(env, oracle, gold):
                     top2 = np.sort(t["out_probs"])[-2:]
                     if top2[1] - top2[0] > 1e-6:
                         assert int(g_pred[q]) == opred
-            assert n_ok >= n_take * 3 // 4
+            assert n_ok == n_take, f"{n_take - n_ok} of {n_take} stories needed the p-on-a-step excuse (observed: 0)"
             # bookkeeping: match count equals the number of correct predictions on the GPU side
             assert int(out["match"].cpu()) == int((g_pred == ans).sum())
             want_cost = -float(g_probs[np.arange(n_take), ans].astype(np.float64).sum())
@@ -287,7 +292,7 @@ def run_hamming_case(env, oracle, mode, D, S_list, B, seed, iwl=5, num_bit=8, si
                 assert near_step(t["probs"][h], frac).any(), f"o/u differ q{q} h{h}"
                 ok = False
         excused += not ok
-    assert excused <= max(1, B // 8)
+    assert excused == 0, f"{excused} of {B} queries needed the p-on-a-step excuse (observed: 0)"
 
 
 @pytest.mark.parametrize("D", [60, 128, 256])
@@ -404,6 +409,19 @@ def test_answer_mfma_i8_one_pass(env, D, V, B, sig, base):
     torch.cuda.synchronize()
     np.testing.assert_array_equal(pred_1.cpu().numpy(), pred_f.cpu().numpy())
     np.testing.assert_array_equal(pred_n.cpu().numpy(), pred_f.cpu().numpy())
+    # the oracle's own answer layer (dense_fwd float, softmax of this base, arg-max with ties to the highest index:
+    # lib/layer_cuda.cu:1918-1939) on a spread of the queries -- every seventh has all logits equal (exact ties)
+    p1 = pred_1.cpu().numpy()
+    sm = {0: 0, 1: 1, 2: 2}[base]
+    n_match = 0.0
+    for q in list(range(0, B, max(1, B // 40)))[:48]:
+        lo = oracle.dense_fwd(w_float, u[q], False, (8, 7), (8, 7))
+        po = oracle.softmax_fwd(lo, variant=ORACLE_SM[sm])
+        top2 = np.sort(po)[-2:]
+        if top2[1] - top2[0] > 1e-6 or top2[1] == top2[0]:       # clear winner, or an exact tie (the rule decides)
+            assert int(p1[q]) == oracle.argmax_hi(po), f"query {q}"
+            n_match += 1
+    assert n_match >= 10
     assert int(match_1.cpu()) == int(match_f.cpu())
     # (both costs are float sums over the batch in different orders: ~1 ulp of the running total per atomic add)
     assert float(cost_1.cpu()) == pytest.approx(float(cost_f.cpu()), rel=1e-4, abs=1e-6)
@@ -417,6 +435,11 @@ def test_answer_mfma_i8_one_pass(env, D, V, B, sig, base):
                                         (128, [10000, 4097], 3)])
 def test_hops_float_attention(env, oracle, D, S_list, B):
     run_float_case(env, oracle, D, S_list, B)
+
+
+# mode 1: queries whose float read-out o sits within 1e-3 code units of a step of Qa (then Qa(o) may differ by a code):
+# the observed maximum over the cases of this file + 1
+FLOAT_EXCUSED = 1
 
 
 def run_float_case(env, oracle, D, S_list, B, extra=None, seed=None, max_excused=None):
@@ -465,7 +488,8 @@ def run_float_case(env, oracle, D, S_list, B, extra=None, seed=None, max_excused
                 assert np.all(np.abs(x[bad] - np.rint(x[bad])) < 1e-3), f"u differs away from a step q{q} h{h}"
                 excused += 1
                 break
-    assert excused <= (max(1, B // 4) if max_excused is None else max_excused)
+    print(f"float attention: {excused} of {B} queries have a hop state on a step of Qa(o)")
+    assert excused <= (FLOAT_EXCUSED if max_excused is None else max_excused), f"{excused} of {B}"
 
 
 # ---------------------------------------------------------------------------------------------
@@ -588,6 +612,19 @@ def test_hops_softmax_variants(env, oracle, path, variant):
         run_hamming_case(env, oracle, 11, 128, [1, 9, 50, 64], B=8, seed=907, num_bit=4, extra=extra)
     else:
         run_float_case(env, oracle, 60, [1, 2, 10, 50, 64, 300], 6, extra=extra)
+
+
+@pytest.mark.parametrize("base", [1, 2])
+def test_cpu_softmax_bases_on_long_memories(env, oracle, base):
+    """The 2^x and exp_plan bases come from the reference's CPU softmax, whose total is a FLOAT added slot by slot
+    (lib/layer.c:1161, :1236).  The kernels for up to 64 slots reproduce that sum as it is; the streaming kernels (65 slots
+    and more) add the terms of a score histogram in double -- an order-free sum of thousands of float terms cannot be the
+    serial float one.  The probabilities then agree within the 1e-5 tolerance, and a hop output may differ from the oracle's
+    (which sums serially in float) ONLY where a softmax weight lies within 1e-5 of a truncation step of Q(p); how often that
+    happens is bounded here: observed 0 of 40 queries per base + 1."""
+    cfg = cfg_synth(60, 40, 5, base=base)
+    n = run_case(env, oracle, cfg, B=40, S_list=[65, 200, 1000, 5000, 10000], seed=4200 + base, max_excused=1)
+    print(f"base {base}: {n} of 40 long-memory queries excused")
 
 
 # ---------------------------------------------------------------------------------------------
@@ -787,7 +824,10 @@ def test_host_model_forward_equals_oracle(env, oracle, gold, name, mode, num_bit
         if top2[1] - top2[0] > 1e-6 and mode != 1:
             assert int(p1[q]) == opred, q
         n_match += int(p1[q] == ans[q])
-    assert excused <= (B // 4 if mode == 1 else max(1, B // 8)), excused
+    print(f"mode {mode}: {excused} of {B} stories excused")
+    # mode 1 (float attention): a 1e-5 difference of o on a step of Qa(o) cascades through the hops -- observed maximum + 1;
+    # the fixed-point and Hamming modes: observed 0
+    assert excused <= (E2E_FLOAT_EXCUSED if mode == 1 else 0), excused
     assert int(m1.item()) == sum(int(p1[q] == ans[q]) for q in range(B))      # the device-side match counter
     hm.close()
 
@@ -917,7 +957,7 @@ def test_joint_20_tasks_forward_equals_oracle(env, oracle, gold, mode, num_bit):
         if top2[1] - top2[0] > 1e-6:
             assert int(pred[i]) == opred, i
         checked += 1
-    assert excused <= 12 and checked >= 88
+    assert excused == 0 and checked == 100, (excused, checked)
     hm.close()
 
 

@@ -148,7 +148,32 @@ def oracle_sample(oracle, cfg, wts, sw, qw, n_sen, pred, u, pick):
         assert near, f"story {i}: final state differs from the oracle's"
         excused += 1
     print(f"oracle sample: {excused} of {len(pick)} stories excused (p on a truncation step)")
-    assert excused <= max(2, len(pick) // 8), f"{excused} of {len(pick)} stories hit the p-on-a-step exclusion"
+    assert excused == 0, f"{excused} of {len(pick)} stories hit the p-on-a-step exclusion (observed: 0)"
+
+
+# stories per attention mode that needed the "p on a truncation step" excuse when these tests were written (observed + 1)
+QA1_EXCUSED = {2: 0, 3: 0, 10: 0, 11: 0}
+JOINT_EXCUSED = {2: 0, 3: 0, 10: 0, 11: 0}
+
+
+def oracle_full(oracle, cfg, wts, sw, qw, n_sen, pred, u, max_excused):
+    """EVERY story of a set against the oracle (qo_memn2n_forward on C threads, oracle/qmann_oracle.c).  The final hop state
+    must be equal bit for bit; a story may differ only where a softmax weight of the oracle lies within 1e-5 of a truncation
+    step of Q(p) (both results are then inside the float tolerance), and at most `max_excused` stories may use that excuse --
+    the observed count + 1 (0 observed: the bound is 0)."""
+    m = oracle.make_model(cfg, wts)
+    row_off = np.concatenate([[0], np.cumsum(n_sen)]).astype(np.uint32)
+    opred, ou, gap, near = oracle.forward_words_batch(m, sw, qw, row_off)
+    differ = (ou != u).any(1)
+    bad = np.flatnonzero(differ & ~near)
+    assert bad.size == 0, f"{bad.size} stories differ from the oracle with no softmax weight on a truncation step, first {bad[:5]}"
+    excused = int(differ.sum())
+    clear = ~differ & (gap > 1e-6)
+    wrong = np.flatnonzero(clear & (opred.astype(np.int64) != pred.astype(np.int64)))
+    assert wrong.size == 0, f"predictions differ for stories {wrong[:5]}"
+    print(f"oracle, all {len(n_sen)} stories: {excused} excused (p on a truncation step; {int(near.sum())} stories have such a p), "
+          f"{int(clear.sum())} predictions compared")
+    assert excused <= max_excused, f"{excused} stories needed the p-on-a-step excuse (bound {max_excused})"
 
 
 @pytest.mark.parametrize("mode,nb", [(2, 8), (3, 8), (10, 8), (11, 8)])
@@ -162,7 +187,7 @@ def test_full_qa1_test_set(env, oracle, mode, nb):
     cfg["num_bit"] = nb
     wts = weights(11, 3, 60, V)
     pred, u = run_both(env, cfg, wts, sw, qw, n_sen, ans)
-    oracle_sample(oracle, cfg, wts, sw, qw, n_sen, pred, u, list(range(0, 1000, 5)))
+    oracle_full(oracle, cfg, wts, sw, qw, n_sen, pred, u, max_excused=QA1_EXCUSED[mode])
 
 
 @pytest.mark.parametrize("mode,nb", [(11, 8), (10, 8), (3, 8), (2, 8)])
@@ -177,7 +202,7 @@ def test_full_joint_test_set(env, oracle, mode, nb):
     cfg["num_bit"] = nb
     wts = weights(12, 3, 60, V)
     pred, u = run_both(env, cfg, wts, sw, qw, n_sen, ans)
-    oracle_sample(oracle, cfg, wts, sw, qw, n_sen, pred, u, list(range(7, 20000, 100)))
+    oracle_full(oracle, cfg, wts, sw, qw, n_sen, pred, u, max_excused=JOINT_EXCUSED[mode])
 
 
 def random_stories(rng, B, V, dd, W, S_list, dup_every=3):
