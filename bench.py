@@ -84,6 +84,11 @@ for _n, _m, _nb in (("babi_joint20_v1", 11, 8), ("babi_joint20_v0", 10, 8), ("ba
 # the same with the embedding matrices tied across the hops as the reference trains them (TYPE_WEIGHT_TYING 2,
 # MemN2N/define.h:287; MemN2N.c:1770-1773): the host model then embeds the stories once for all hops
 WORKLOADS["babi_joint20_v1_tied"] = dict(S=64, D=60, V=238, B=262000, mode=11, nb=8, ans="f32", joint=True, tied=True)
+# BASELINE.json configs[1] on TRAINED weights: the matrices the reference's unmodified host program trained on bAbI task 1
+# through this library (tools/make_trained_fixture.py -> tests/golden/trained_qa1/), the 1 000 real test stories read from the
+# record files (replicated), labels from the files: reports queries/s AND the test error, beside the err(test) the reference
+# program itself printed for these weights
+WORKLOADS["babi_task1_trained"] = dict(S=10, D=60, V=0, B=262000, mode=2, nb=8, ans="f32", trained=True)
 KERNEL_OF_MODE = {1: "k_hops_float", 2: "k_hops_fixed", 3: "k_hops_ham", 10: "k_hops_ham", 11: "k_hops_ham"}
 
 
@@ -462,6 +467,86 @@ def run_joint(args, name, wl, cfg, wts, hm, dev, rank, world, model):
     return res
 
 
+def run_trained(args, name, wl, dev, rank, world, model, abi, replicate_model):
+    """configs[1] with trained weights and labels: the whole forward from word indices, test error from the labels."""
+    import tempfile
+    tdir = ROOT / "tests" / "golden" / "trained_qa1"
+    rec = json.loads((tdir / "reference_run.json").read_text())
+    g = np.load(ROOT / "tests" / "golden" / "babi_qa1_en1k_sets.npz")
+    with tempfile.TemporaryDirectory() as td:
+        tr, te = Path(td) / "train_set", Path(td) / "test_set"
+        tr.write_bytes(g["train_set"].tobytes()); te.write_bytes(g["test_set"].tobytes())
+        ds = abi.load_dataset(tr, te, 50)                       # include/qmann_dataset.h: record files -> word lists
+    V, D, H = ds["dim_input"], 60, 3
+    cfg = model.babi_cfg(V, attention_mode=2, softmax_base=0, iwl=int(rec["argv"][3]), n_hop=H, D=D, en_mq=True)
+    wts, hm = None, None
+    if rank == 0:
+        wts = model.load_weights(tdir, cfg)
+        hm = model.HostModel(cfg, wts, device=str(dev))
+    hm, bcast_ms, bcast_how = replicate_model(hm, cfg, dev, rank, world, COMM, model)
+    nq = ds["n_query"]
+    B = args.queries or wl["B"]
+    rep = max(1, B // nq)
+    B = rep * nq
+    n_sen = np.diff(ds["row_off"].astype(np.int64))
+    sw = torch.from_numpy(np.tile(ds["story_words"], (rep, 1)).view(np.int16)).to(dev)
+    qw = torch.from_numpy(np.tile(ds["question_words"], (rep, 1)).view(np.int16)).to(dev)
+    ans = torch.from_numpy(np.tile(ds["answer"].astype(np.int64).astype(np.int32), rep)).to(dev)
+    row_off = torch.from_numpy(np.concatenate([[0], np.cumsum(np.tile(n_sen, rep))]).astype(np.int32)).to(dev)
+    max_slots = int(n_sen.max())
+    torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        out = hm.forward_words(sw, qw, row_off, max_slots, ans)
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = hm.forward_words(sw, qw, row_off, max_slots, ans)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    match = int(out[2].item())                                   # the last step's match counter (zeroed per call)
+    err = 1.0 - match / B
+    pred1 = out[0][:nq].cpu().numpy()
+    bytes_in = (int(row_off[-1]) + B) * ds["story_words"].shape[1] * 2
+    res = {
+        "metric": "queries/sec", "value": world * B * args.steps / elapsed, "unit": "queries/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int8",
+        "data": "bAbI qa1 (en, 1k) test stories read from the record files (1 000, replicated), labels from the files; weights TRAINED by the "
+                "reference's unmodified host program through this library (tests/golden/trained_qa1)",
+        "config": {"workload": name, "slots": f"2..{max_slots} (mean {n_sen.mean():.1f})", "dim_emb": D, "dim_input": V, "hops": H,
+                   "queries_per_gpu": B, "format": "Q5.2 + EN_MQ weight formats", "attention_mode": 2,
+                   "stages": "one qmann_model_forward_words call: story embedding (int8 MFMA) + question embedding + hops + answer layer",
+                   "parallelism": f"replicas x{world}, query-sharded"},
+        "roofline": {"bound": "hbm", "kernel": "whole forward (issue / latency bound at these sizes)",
+                     "achieved": bytes_in * args.steps / elapsed / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": bytes_in * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, "traffic": None},
+        "accuracy": {"test_error_from_labels": err, "matches": match, "queries": B,
+                     "reference_program_err_test": rec["err_test_result_csv"],
+                     "equals_reference_program": bool(abs(err - rec["err_test_result_csv"]) < 1e-6),
+                     "reference_run": {k: rec[k] for k in ("binary", "argv", "verify_line", "train_error_first_epoch", "train_error_last_epoch", "epochs")},
+                     "chance_error": 5.0 / 6.0},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        offs = ds["row_off"].astype(np.int64)
+        pick = list(range(0, nq, 5))
+        pool = [(words_to_bow(ds["story_words"][offs[i]:offs[i + 1]], V, ds["dim_dict"], True),
+                 words_to_bow(ds["question_words"][i:i + 1], V, ds["dim_dict"], False)[0]) for i in pick]
+        res["cpu_baseline"] = cpu_baseline(cfg, wts, pool, f"{len(pick)} of the 1 000 test stories, whole forward, trained weights",
+                                           gpu_preds=[int(pred1[i]) for i in pick])
+    return with_bcast(res, None if bcast_ms is None else {"ms": bcast_ms, "how": bcast_how, "bytes": hm.params()[1]})
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -639,6 +724,8 @@ def run_workload(args, name, dev, rank, world):
         import torch.distributed as dist
 
     wl = WORKLOADS[name]
+    if wl.get("trained"):
+        return run_trained(args, name, wl, dev, rank, world, model, abi, replicate_model)
     S, D, V, mode, nb = wl["S"], wl["D"], wl["V"], wl["mode"], wl["nb"]
     B = args.queries or wl["B"]
     H = 3

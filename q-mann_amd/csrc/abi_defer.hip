@@ -29,6 +29,7 @@ bool g_draining = false;
 qmann_defer_stats g_stats{};
 bool g_timing = false;                              // QMANN_DEFER_STATS / verify: bracket the phases with device syncs
 const char *g_save_dir = nullptr;                   // QMANN_SAVE_WEIGHTS_DIR
+std::string g_verify_log;                           // verify mode: one line per run, printed when the process ends
 
 bool feq(QFmt a, QFmt b) { return a.iwl == b.iwl && a.frac == b.frac; }
 
@@ -47,6 +48,24 @@ struct Query {
     size_t first, n_ops;
 };
 
+void exit_report()
+{
+    static bool registered = false;
+    if (registered) return;
+    registered = true;
+    atexit([] {
+        const qmann_defer_stats &s = g_stats;
+        fflush(stdout);
+        fprintf(stderr, "\n%s", g_verify_log.c_str());
+        if (!getenv("QMANN_DEFER_STATS")) return;
+        fprintf(stderr, "[qmann defer] verbs queued %llu, replayed one by one %llu; queries batched %llu in %llu runs (%.3f ms), "
+                        "op-by-op %.3f ms, models built %llu (%.3f ms); verify: %llu runs, %llu mismatches\n",
+                (unsigned long long)s.ops_queued, (unsigned long long)s.ops_replayed, (unsigned long long)s.queries_batched,
+                (unsigned long long)s.batches, s.ms_batched, s.ms_replayed, (unsigned long long)s.models_built, s.ms_model,
+                (unsigned long long)s.verify_runs, (unsigned long long)s.verify_mismatch);
+    });
+}
+
 void init_mode()
 {
     if (g_mode >= 0) return;
@@ -57,16 +76,7 @@ void init_mode()
     if (getenv("QMANN_NO_DEFER")) g_mode = kOff;
     g_save_dir = getenv("QMANN_SAVE_WEIGHTS_DIR");
     g_timing = getenv("QMANN_DEFER_STATS") != nullptr || g_mode == kVerify;
-    if (getenv("QMANN_DEFER_STATS"))
-        atexit([] {
-            const qmann_defer_stats &s = g_stats;
-            fflush(stdout);
-            fprintf(stderr, "\n[qmann defer] verbs queued %llu, replayed one by one %llu; queries batched %llu in %llu runs (%.3f ms), "
-                            "op-by-op %.3f ms, models built %llu (%.3f ms); verify: %llu runs, %llu mismatches\n",
-                    (unsigned long long)s.ops_queued, (unsigned long long)s.ops_replayed, (unsigned long long)s.queries_batched,
-                    (unsigned long long)s.batches, s.ms_batched, s.ms_replayed, (unsigned long long)s.models_built, s.ms_model,
-                    (unsigned long long)s.verify_runs, (unsigned long long)s.verify_mismatch);
-        });
+    if (getenv("QMANN_DEFER_STATS") || g_mode == kVerify) exit_report();
 }
 
 double now_ms()
@@ -388,9 +398,12 @@ void dispatch_run(const std::vector<Op> &ops, const Sig &s, const std::vector<Qu
                 g_stats.queries_batched += b - a; g_stats.batches++; g_stats.ms_batched += t1 - t0;
                 const bool same = mb == m1 - m0;
                 if (!same) g_stats.verify_mismatch++;
-                fflush(stdout);               // (a host that logs to a file: keep the line whole)
-                fprintf(stderr, "\n[qmann defer verify] %zu queries (cross_entropy mode %u): batched match %u cost %.6f | op-by-op match %u cost %.6f | %s\n",
-                        b - a, s.ce_mode, mb, cb, m1 - m0, c1 - c0, same ? "equal" : "MISMATCH");
+                // (kept for the end of the process: a line on stderr in the middle of the run would cut the host's own
+                // half-printed stdout lines in two when both go to one file)
+                char line[320];
+                snprintf(line, sizeof line, "[qmann defer verify] %zu queries (cross_entropy mode %u): batched match %u cost %.6f | op-by-op match %u cost %.6f | %s\n",
+                         b - a, s.ce_mode, mb, cb, m1 - m0, c1 - c0, same ? "equal" : "MISMATCH");
+                g_verify_log += line;
             }
         } else {
             const double t0 = now_ms();
@@ -473,7 +486,7 @@ void qmann_abi_set_defer(int mode)
     qmdefer::init_mode();
     qmdefer::drain();
     qmdefer::g_mode = mode == 0 ? qmdefer::kOff : mode == 2 ? qmdefer::kVerify : qmdefer::kOn;
-    if (mode == 2) qmdefer::g_timing = true;
+    if (mode == 2) { qmdefer::g_timing = true; qmdefer::exit_report(); }
 }
 
 void qmann_abi_flush(void) { qmdefer::sync_point(false); }

@@ -47,7 +47,7 @@ def weights(seed, H, D, V, sigma, with_emb=True):
 
 
 ORACLE_SM = {0: 0, 1: 1, 2: 2}       # qmann softmax_base -> the oracle's variant (QO_SM_CUDA, _CPU_POW2, _CPU_EXP_PLAN)
-E2E_FLOAT_EXCUSED = 8              # test_model_host_object, mode 1: observed maximum + 1 (set from the first full-suite run)
+E2E_FLOAT_EXCUSED = 2              # the whole forward in mode 1 against the oracle: observed maximum (1 of 64 stories) + 1
 
 
 def near_step(p, frac, rel=1e-5):
@@ -381,7 +381,7 @@ def test_answer_mfma_i8_bit_identical_to_float_path(env, oracle, D, V, B):
 @pytest.mark.parametrize("base", [0, 1, 2])
 @pytest.mark.parametrize("D,V,B,sig", [(60, 30, 5, 40), (128, 256, 37, 40), (256, 256, 64, 3), (128, 1000, 33, 40), (256, 4096, 300, 12),
                                        (60, 4097, 2000, 1), (256, 65, 8192, 40)])
-def test_answer_mfma_i8_one_pass(env, D, V, B, sig, base):
+def test_answer_mfma_i8_one_pass(env, oracle, D, V, B, sig, base):
     """Without a probabilities output the int8 answer layer runs in one pass (no logits round trip, running-maximum
     normaliser, dictionary slices merged by a second kernel): predictions -- ties to the highest index included -- and the
     match count equal the float path exactly, the cost within the softmax tolerance.  Small sigma: many exact logit ties.
@@ -421,7 +421,7 @@ def test_answer_mfma_i8_one_pass(env, D, V, B, sig, base):
         if top2[1] - top2[0] > 1e-6 or top2[1] == top2[0]:       # clear winner, or an exact tie (the rule decides)
             assert int(p1[q]) == oracle.argmax_hi(po), f"query {q}"
             n_match += 1
-    assert n_match >= 10
+    assert n_match >= min(10, B)
     assert int(match_1.cpu()) == int(match_f.cpu())
     # (both costs are float sums over the batch in different orders: ~1 ulp of the running total per atomic add)
     assert float(cost_1.cpu()) == pytest.approx(float(cost_f.cpu()), rel=1e-4, abs=1e-6)

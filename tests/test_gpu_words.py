@@ -456,3 +456,43 @@ def test_record_file_to_predictions(env, tmp_path):
     cfg = env.model.babi_cfg(V, attention_mode=2, D=60)
     ans = np.where(ds["answer"] == 0xFFFFFFFF, 0xFFFF, ds["answer"]).astype(np.int64)
     run_both(env, cfg, weights(5, 3, 60, V, 1.5), ds["story_words"], ds["question_words"], n_sen, ans)
+
+
+@pytest.mark.parametrize("via", ["weights", "bow"])
+def test_trained_weights_fixture_full_test_set(env, oracle, tmp_path, via):
+    """tests/golden/trained_qa1: the matrices the reference's unmodified host program trained on bAbI task 1 through this
+    library (tools/make_trained_fixture.py; reference_run.json holds the err(test) it printed).  Trained weights are tied
+    across the hops, sit on their grids and give peaky, partly saturated softmaxes -- what seeded random weights never do.
+    All 1 000 test stories, read natively from the record files: the match count from the labels is the reference program's
+    own, and every story equals the oracle (final hop state bit for bit, predictions)."""
+    import json
+    torch, model = env.torch, env.model
+    load_pkg()
+    import qmann_amd.abi as abi
+    tdir = GOLD / "trained_qa1"
+    rec = json.loads((tdir / "reference_run.json").read_text())
+    g = np.load(GOLD / "babi_qa1_en1k_sets.npz")
+    (tmp_path / "train").write_bytes(g["train_set"].tobytes()); (tmp_path / "test").write_bytes(g["test_set"].tobytes())
+    ds = abi.load_dataset(tmp_path / "train", tmp_path / "test", 50)
+    V = ds["dim_input"]
+    cfg = model.babi_cfg(V, attention_mode=2, softmax_base=0, iwl=int(rec["argv"][3]), en_mq=True)
+    wts = model.load_weights(tdir, cfg)
+    assert all(np.array_equal(wts["w_a"][h], wts["w_a"][0]) for h in range(3))          # TYPE_WEIGHT_TYING 2 (MemN2N.c:1770-1773)
+    n_sen = np.diff(ds["row_off"].astype(np.int64))
+    sw, qw = ds["story_words"], ds["question_words"]
+    ans = ds["answer"].astype(np.int64)
+    hm = model.HostModel(cfg, wts)
+    d_ro = torch.from_numpy(ds["row_off"].astype(np.int32)).to(env.dev); d_ans = torch.from_numpy(ans.astype(np.int32)).to(env.dev)
+    if via == "weights":
+        pred, _, match = hm.forward_words(torch.from_numpy(sw.view(np.int16)).to(env.dev), torch.from_numpy(qw.view(np.int16)).to(env.dev),
+                                          d_ro, int(n_sen.max()), d_ans)
+    else:                                                                                 # the reference's own input format
+        pred, _, match = hm.forward_bow(torch.from_numpy(words_to_bow(sw, V, True)).to(env.dev),
+                                        torch.from_numpy(words_to_bow(qw, V, False)).to(env.dev), d_ro, int(n_sen.max()), d_ans)
+    torch.cuda.synchronize()
+    u = hm.last_u(ds["n_query"]).cpu().numpy(); pred = pred.cpu().numpy()
+    hm.close()
+    n_match = int(match.item())
+    assert n_match == int((pred == ans).sum())
+    assert 1.0 - n_match / ds["n_query"] == pytest.approx(rec["err_test_result_csv"], abs=1e-6), (n_match, rec["err_test_result_csv"])
+    oracle_full(oracle, cfg, wts, sw, qw, n_sen, pred, u, max_excused=0)
