@@ -22,6 +22,7 @@ __host__ __device__ inline uint32_t v0_table_bytes(uint32_t nbins) { return 2 * 
 // ---- APPX: 4 key bytes against 4 query bytes -------------------------------------------------
 struct AppxConst {
     uint32_t um[4];   // |u| bytes
+    uint32_t u127[4]; // |u| + 127 per byte (<= 254): what a sign-differing byte is replaced by in the same-sign sum
     uint32_t nb[4];   // 128 - |u| per byte
     uint32_t us[4];   // 0x80 where u < 0
     uint32_t m7[4];   // 0x7F in real columns, 0 in padding
@@ -29,8 +30,9 @@ struct AppxConst {
     int bias;         // 127 . (16 - padding columns of this lane): the same-sign terms' constant part
 };
 
-// 13 VALU operations per 4 columns in the compiled loop (the boolean pairs fuse into v_bitop3_b32; round 1: 15 + 2 per row).  Padding columns are forced to "same sign, both magnitudes 0"
-// by the masks (a term of exactly 127), which `bias` leaves out.
+// 12 VALU operations per 4 columns in the compiled loop (the boolean pairs fuse into v_bitop3_b32; round 1: 15 + 2 per row,
+// round 2: 13).  Padding columns are forced to "same sign, both magnitudes 0" by the masks (a term of exactly 127), which
+// `bias` leaves out.
 __device__ __forceinline__ int appx_lane_sum(const i32x4 x, const AppxConst &c)
 {
     int dot = 0;
@@ -41,10 +43,10 @@ __device__ __forceinline__ int appx_lane_sum(const i32x4 x, const AppxConst &c)
         const uint32_t km = w & c.m7[d];
         const uint32_t sd = (w ^ c.us[d]) & c.m8[d];                        // signs differ
         const uint32_t dmask = __builtin_amdgcn_perm(0u, 0u, sd);           // 0xFF in those bytes
-        // same sign: 127 - |ka - kb|; `bias` holds a 127 for every real column, the opposite-sign ones give theirs back here
-        dot = __builtin_amdgcn_sdot4((int)dmask, 0x7F7F7F7F, dot, false);
-        // (where the signs differ the key byte is replaced by the query's: a difference of 0)
-        sad = __builtin_amdgcn_sad_u8((km & ~dmask) | (c.um[d] & dmask), c.um[d], sad);
+        // same sign: 127 - |ka - kb|; `bias` holds a 127 for every real column.  Where the signs differ the key byte is
+        // replaced by |u| + 127: a difference of exactly 127, which gives that column's 127 back inside the same v_sad_u8
+        // (round 2 spent a v_dot4 on counting those columns)
+        sad = __builtin_amdgcn_sad_u8((km & ~dmask) | (c.u127[d] & dmask), c.um[d], sad);
         // opposite sign: +-(127 - ((ka + kb) & 127)); per byte ka + kb <= 254, no carry across bytes
         const uint32_t s4 = km + c.um[d];                                   // bit 7 of a byte = carry out of 7 bits
         const uint32_t val = ~s4 & (dmask & 0x7F7F7F7Fu);
@@ -163,6 +165,7 @@ __device__ __forceinline__ void make_appx_const(AppxConst &c, const uint8_t *ub,
     for (int d = 0; d < 4; d++) {
         const uint32_t b4 = *(const uint32_t *)(ub + c0 + 4 * d);
         c.um[d] = b4 & 0x7F7F7F7Fu;
+        c.u127[d] = (b4 & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;                         // per byte <= 254: no carry
         c.nb[d] = (~b4 & 0x7F7F7F7Fu) + 0x01010101u;                          // (127 - |u|) + 1 per byte
         c.us[d] = b4 & 0x80808080u;
         uint32_t vm = 0;
