@@ -27,7 +27,7 @@
 //   4. linear map H.u (int8 [D][Dp], L2-resident) and u' = Q(Q(Hu) + Q(o)).
 //
 // All integer work is exact; the only floating-point step is the softmax table.
-#include "hops_lean.h"
+#include "hops_mid.h"
 
 namespace {
 
@@ -296,6 +296,11 @@ int qmann_hops_i8(const qmann_net *net, const int8_t *keys, const int8_t *vals, 
         if (net->dim_emb_pad == 64) k_hops_small<4, 4, kModeFixed, 8><<<n_query, kWave, 0, st>>>(a, 64);
         else if (net->dim_emb_pad == 128) k_hops_small<8, 8, kModeFixed, 8><<<n_query, kWave, 0, st>>>(a, 128);
         else k_hops_small<16, 16, kModeFixed, 8><<<n_query, kWave, 0, st>>>(a, 256);
+        QM_LAUNCH_CHECK();
+        return qm_scope.rc();
+    }
+    if (mid_supported(a, max_slots)) {                      // hops_mid.h: 65 .. 1 024 slots at bAbI width
+        launch_mid(a, max_slots, n_query, st);
         QM_LAUNCH_CHECK();
         return qm_scope.rc();
     }

@@ -179,6 +179,61 @@ __device__ __forceinline__ void lean_stage_tables(const HopArgs &a, const LeanAr
     }
 }
 
+// The end of a hop, shared by the one-wavefront kernels (this file and hops_mid.h): the read-out code `acc` of column `lane`
+// is clamped and published, the linear map H.u runs on the pre-split rows in LDS, and u' = Qa(Qa(Hu) + Qa(o)) replaces `u`.
+//   kb_code   Q_bin(u) of column `lane` (the linear map's operand)
+//   csc / csh the scan constants still in registers; `reuse`: they are already those of (word length of w[h], frac_bin)
+template <bool W7>
+__device__ __forceinline__ void lean_finish_hop(const HopArgs &a, uint32_t h, uint32_t lane, uint8_t *lw, const uint8_t *lmap, float &u,
+                                                int acc, int kb_code, ScanConst &csc, uint32_t &csh, bool reuse)
+{
+    constexpr uint32_t LPR = 4;
+    const uint32_t sub = lane >> 2, chunk = lane & 3u, D = a.D;
+    const QFmt fa = a.act[h], fb = a.bin, fw = a.w[h];
+    const int maxa = (1 << (fa.iwl + fa.frac)) - 1;
+    const uint32_t wl_w = fw.iwl + fw.frac;
+    acc = acc > maxa ? maxa : (acc < -maxa ? -maxa : acc);
+    *(int16_t *)(lw + kLwOc + lane * 2) = (int16_t)acc;
+
+    // ---- linear map + hop update ---------------------------------------------------------------------
+    if (a.en_lin_map) {
+        if (!reuse) {
+            wave_sync();                                          // every lane is done with the previous image
+            publish_const<W7>(lw, lane, kb_code, wl_w, (int)fb.frac);
+        }
+        wave_sync();
+        if (!reuse) csh = fetch_scan_const(csc, lw, chunk, wl_w);
+        const int maxw = (1 << wl_w) - 1;
+        const uint32_t n_it = (D + 15u) / 16u;
+        int keep = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            if ((uint32_t)t < n_it) {                             // wavefront-uniform
+                const uint8_t *hr = lmap + h * kLmHopBytes + (t * 16 + sub) * 192u + chunk * 16u;
+                const int s = row_lanes_sum<LPR>(lane_sum_split<W7>(*(const i32x4 *)hr, *(const i32x4 *)(hr + 64), *(const i32x4 *)(hr + 128), csc, csh));
+                if (chunk == (uint32_t)t) keep = s;
+            }
+        }
+        // lane (sub, chunk) now holds the sum of row o = 16 . chunk + sub
+        const uint32_t o_i = chunk * 16u + sub;
+        const int kw = keep > maxw ? maxw : (keep < -maxw ? -maxw : keep);       // Qw of the row sum
+        const uint32_t mag = (uint32_t)(kw < 0 ? -kw : kw);
+        const uint32_t ma = fa.frac >= fw.frac ? mag << (fa.frac - fw.frac) : mag >> (fw.frac - fa.frac);
+        const int lam = ma > (uint32_t)maxa ? maxa : (int)ma;                  // Qa of that value
+        int un = (kw < 0 ? -lam : lam) + (int)*(const int16_t *)(lw + kLwOc + o_i * 2);
+        un = un > maxa ? maxa : (un < -maxa ? -maxa : un);
+        wave_sync();                                              // (kLwUn shares its bytes with the constant images)
+        *(float *)(lw + kLwUn + o_i * 4) = qm_scale_down((float)un, fa.frac);
+        wave_sync();
+        u = (lane < D) ? *(const float *)(lw + kLwUn + lane * 4) : 0.0f;
+    } else {
+        int un = ((lane < D) ? qm_code(u, fa.iwl, fa.frac) : 0) + acc;
+        un = un > maxa ? maxa : (un < -maxa ? -maxa : un);
+        u = qm_scale_down((float)un, fa.frac);
+    }
+    wave_sync();                                                  // the next hop rewrites the images
+}
+
 // One hop of one query on one wavefront.  u: the hop state, lane c owns column c (updated in place).
 //   key_of(j)         this lane's 16-byte piece (chunk = lane & 3) of key row 16 j + (lane >> 2), j = 0..3
 //   before_readout()  called once the read-out weights are known, before the value tile `vt` is read
@@ -279,47 +334,7 @@ __device__ __forceinline__ void lean_hop(const HopArgs &a, const LeanArgs &la, u
             acc += (bb[i] & 0x80u) ? -(int)t : (int)t;
         }
     }
-    acc = acc > maxa ? maxa : (acc < -maxa ? -maxa : acc);
-    *(int16_t *)(lw + kLwOc + lane * 2) = (int16_t)acc;
-
-    // ---- linear map + hop update ---------------------------------------------------------------------
-    if (a.en_lin_map) {
-        const bool reuse = MODE == kModeFixed && wl_w == wl_m && !relu;
-        if (!reuse) {
-            wave_sync();                                          // every lane is done with the previous image
-            publish_const<W7>(lw, lane, kb_code, wl_w, (int)fb.frac);
-        }
-        wave_sync();
-        if (!reuse) csh = fetch_scan_const(csc, lw, chunk, wl_w);
-        const int maxw = (1 << wl_w) - 1;
-        const uint32_t n_it = (D + 15u) / 16u;
-        int keep = 0;
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            if ((uint32_t)t < n_it) {                             // wavefront-uniform
-                const uint8_t *hr = lmap + h * kLmHopBytes + (t * 16 + sub) * 192u + chunk * 16u;
-                const int s = row_lanes_sum<LPR>(lane_sum_split<W7>(*(const i32x4 *)hr, *(const i32x4 *)(hr + 64), *(const i32x4 *)(hr + 128), csc, csh));
-                if (chunk == (uint32_t)t) keep = s;
-            }
-        }
-        // lane (sub, chunk) now holds the sum of row o = 16 . chunk + sub
-        const uint32_t o_i = chunk * 16u + sub;
-        const int kw = keep > maxw ? maxw : (keep < -maxw ? -maxw : keep);       // Qw of the row sum
-        const uint32_t mag = (uint32_t)(kw < 0 ? -kw : kw);
-        const uint32_t ma = fa.frac >= fw.frac ? mag << (fa.frac - fw.frac) : mag >> (fw.frac - fa.frac);
-        const int lam = ma > (uint32_t)maxa ? maxa : (int)ma;                  // Qa of that value
-        int un = (kw < 0 ? -lam : lam) + (int)*(const int16_t *)(lw + kLwOc + o_i * 2);
-        un = un > maxa ? maxa : (un < -maxa ? -maxa : un);
-        wave_sync();                                              // (kLwUn shares its bytes with the constant images)
-        *(float *)(lw + kLwUn + o_i * 4) = qm_scale_down((float)un, fa.frac);
-        wave_sync();
-        u = (lane < D) ? *(const float *)(lw + kLwUn + lane * 4) : 0.0f;
-    } else {
-        int un = ((lane < D) ? qm_code(u, fa.iwl, fa.frac) : 0) + acc;
-        un = un > maxa ? maxa : (un < -maxa ? -maxa : un);
-        u = qm_scale_down((float)un, fa.frac);
-    }
-    wave_sync();                                                  // the next hop rewrites the images
+    lean_finish_hop<W7>(a, h, lane, lw, lmap, u, acc, kb_code, csc, csh, MODE == kModeFixed && wl_w == wl_m && !relu);
 }
 
 template <int MODE, int NB, bool W7>

@@ -1,0 +1,236 @@
+// hops_mid.h -- memories of 65 .. 1 024 slots at bAbI width (64-byte rows), fixed-point attention: between the sizes the
+// reference reaches (MAX_SEN_LEN <= 64: hops_lean.h) and the long memories the streaming kernel (batch_hops.hip) is built for.
+//
+// At these sizes the streaming kernel's per-hop fixed costs are as large as its scan: a 256-bin score histogram with its
+// per-bin exponentials, divisions and atomics (sized for 10 000 slots), the lane constants rebuilt from 16 codes per lane, the
+// linear-map rows fetched from L2 every hop.  This kernel is hops_lean.h stretched over more rows instead:
+//   * persistent workgroups of 8 wavefronts, one wavefront per query at a time; exp table per hop and the pre-split linear maps
+//     in LDS for the kernel's lifetime (lean_stage_tables), operand constants published once per column (publish_const);
+//   * the scan streams the key plane in groups of 64 rows (4 x 16-byte loads per lane), two groups in flight, the next hop's
+//     (or the next query's) first two groups requested before the softmax / read-out / linear map of the current hop;
+//   * scores are 8-bit codes in a per-wavefront LDS array (1 KB); the softmax is one table look-up per slot -- exp(x - max)
+//     takes at most 255 values on the score grid -- and a double total (lib/layer_cuda.cu:2024-2042);
+//   * a slot can carry a non-zero read-out weight Q(p) only if e >= total . 2^-frac (up to float rounding): only those few
+//     slots get the exact quotient (float)((double)e / total) of the reference, and only their value rows are read (the others
+//     contribute exact zeros, :562);
+//   * the hop's tail (linear map on the LDS images, u' = Qa(Qa(Hu) + Qa(o))) is hops_lean.h's.
+// Same arithmetic, stage by stage, as k_hops_fixed; tests/test_gpu_mid.py holds the two against each other bit for bit and
+// this kernel against the oracle.  Taken by qmann_hops_i8 for 64 < max_slots <= 1 024 when mid_supported() holds.
+#pragma once
+#include "hops_lean.h"
+
+namespace {
+
+constexpr uint32_t kMidMaxSlots = 1024;
+
+template <bool W7>
+__global__ void __launch_bounds__(kLeanBlock, 4)          // 4 wavefronts per SIMD: two workgroups per CU
+k_hops_mid(const HopArgs a, const LeanArgs la)
+{
+    constexpr uint32_t Dp = 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1);
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid / kWave));   // (uniform: query bookkeeping stays in SGPRs)
+    const uint32_t sub = lane >> 2, chunk = lane & 3u;
+    const uint32_t D = a.D, H = a.n_hop;
+    float *etab = (float *)smem;                                        // [H][256]
+    uint8_t *lmap = smem + H * 1024u;                                   // [H][64][3][64] (lean_stage_tables)
+    uint8_t *wbase = lmap + (la.lm_in_lds ? H * kLmHopBytes : 0u);
+    const uint32_t wslice = kLwBytes + la.rows_pad;                     // rows_pad: score bytes per wavefront (multiple of 64)
+    uint8_t *lw = wbase + wave * wslice;                                // small arrays
+    int8_t *sc = (int8_t *)(lw + kLwBytes);                             // score codes, slot r
+    lean_stage_tables(a, la, etab, lmap, tid, kLeanBlock);
+    __syncthreads();
+
+    const uint32_t q_stride = gridDim.x * kLeanWaves, n_query = a.rows_total;   // (rows_total carries the query count, see launcher)
+    uint32_t q = blockIdx.x * kLeanWaves + wave;
+    if (q >= n_query) return;
+    const uint32_t R_end = a.row_off[n_query];                          // rows of a plane that belong to this batch
+    auto slots_of = [&](uint32_t qq, uint32_t &r0_, uint32_t &S_) {
+        r0_ = a.row_off[qq];
+        const uint32_t S_in = a.row_off[qq + 1] - r0_;
+        S_ = S_in < a.max_slots ? S_in : a.max_slots;                   // a story longer than the caller's bound is cut to it
+    };
+    uint32_t r0, S;
+    slots_of(q, r0, S);
+
+    // Group g of a query = its rows 64 g .. 64 g + 63: four 16-byte loads per lane (rows gs + 16 j + sub, piece `chunk`), one
+    // lane offset and immediate row offsets.  A group that would run past the END OF THE PLANE is moved back to end there
+    // (gs < 64 g; the rows it repeats are skipped when the scores are stored); rows past the query's own end belong to the
+    // next query -- valid memory, their sums are dropped.  A query with fewer than 64 rows left in the plane (the batch's
+    // last ones: "irregular") takes a plain loop with per-row clamping instead, without prefetch.
+    // The steady-state loop holds no branch around a load: the compiler then counts its outstanding loads exactly
+    // (s_waitcnt vmcnt(4) before a group's sums, the other group still in flight).
+    const uint32_t lane_off = sub * Dp + chunk * 16u;
+    i32x4 xa[4], xb[4];
+    auto key_plane = [&](uint32_t h, uint32_t r0_) { return (const uint8_t *)a.keys + (size_t)h * a.key_hop_stride + (size_t)r0_ * Dp; };
+    auto issue = [&](i32x4 (&x)[4], const uint8_t *plane, uint32_t lim, uint32_t g) {      // regular queries only
+        const uint32_t gs = g * 64u < lim ? g * 64u : lim;
+        const uint8_t *p = plane + (size_t)gs * Dp + lane_off;
+#pragma unroll
+        for (int j = 0; j < 4; j++) x[j] = *(const i32x4 *)(p + j * 16 * Dp);
+    };
+    auto is_regular = [&](uint32_t r0_, uint32_t S_) { return S_ > 0u && R_end - r0_ >= 64u; };
+    bool regular = is_regular(r0, S);
+    if (regular) { issue(xa, key_plane(0, r0), R_end - r0 - 64u, 0); issue(xb, key_plane(0, r0), R_end - r0 - 64u, 1); }
+    float u_next = (lane < D) ? a.u0[(size_t)q * D + lane] : 0.0f;
+
+    for (; q < n_query; q += q_stride) {
+        const uint32_t qn = q + q_stride;
+        uint32_t r0n = 0, Sn = 0;
+        if (qn < n_query) slots_of(qn, r0n, Sn);
+        const bool regular_n = qn < n_query && is_regular(r0n, Sn);
+        float u = u_next;
+        const uint32_t n_g = (S + 63u) / 64u;
+        const uint32_t lim = R_end - r0 - 64u;                        // (meaningful for regular queries)
+        for (uint32_t h = 0; h < H; h++) {
+            const QFmt fa = a.act[h], fm = a.att[h], fb = a.bin, fw = a.w[h];
+            const int maxa = (1 << (fa.iwl + fa.frac)) - 1;
+            const uint32_t wl_m = fm.iwl + fm.frac, wl_w = fw.iwl + fw.frac;
+            const int maxm = (1 << wl_m) - 1;
+            const bool relu = hop_relu(a, h);
+            // ---- column c: operand codes, published for the scan --------------------------------------------------
+            const int kb_code = (lane < D) ? qm_code_or_sign(u, fb.iwl, fb.frac) : 0;
+            int ka = kb_code;
+            if (relu && ka < 0) ka = (fb.iwl + fb.frac == 0) ? 1 : 0;               // see make_scan_const
+            publish_const<W7>(lw, lane, ka, wl_m, (int)fb.frac);
+            wave_sync();
+            ScanConst csc;
+            uint32_t csh = fetch_scan_const(csc, lw, chunk, wl_m);
+
+            // ---- scan: scores of all rows, 64 rows per step ---------------------------------------------------------
+            const uint8_t *kp = key_plane(h, r0);
+            int mx = -128;
+            auto consume = [&](const i32x4 (&x)[4], uint32_t g, uint32_t gs) {
+                int s[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) s[j] = row_lanes_sum<4>(lane_sum_w<W7>(x[j], csc, csh));
+                // every lane of a row group holds its row's sum: lane (sub, chunk) keeps row gs + 16 chunk + sub
+                int v = s[0];
+                v = chunk == 1u ? s[1] : v; v = chunk == 2u ? s[2] : v; v = chunk == 3u ? s[3] : v;
+                const int code = v > maxm ? maxm : (v < -maxm ? -maxm : v);     // Qm of the row sum (lib/layer_cuda.cu:135)
+                const uint32_t r = gs + chunk * 16u + sub;
+                if (r >= g * 64u && r < S) { sc[r] = (int8_t)code; mx = code > mx ? code : mx; }
+            };
+            auto gstart = [&](uint32_t g) { return g * 64u < lim ? g * 64u : lim; };
+            if (regular) {
+                __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): groups 0 and 1, requested a hop ago, have landed
+                uint32_t g = 0;
+                for (; g + 2 < n_g; g += 2) {                         // steady state: two groups in flight, no branch inside
+                    consume(xa, g, gstart(g));
+                    issue(xa, kp, lim, g + 2);
+                    consume(xb, g + 1, gstart(g + 1));
+                    issue(xb, kp, lim, g + 3);
+                }
+                consume(xa, g, gstart(g));
+                consume(xb, g + 1, gstart(g + 1));                    // (a group past the story's end stores nothing)
+                // in flight during the rest of the hop: the next hop's first two groups, or the next query's
+                if (h + 1 < H) { issue(xa, key_plane(h + 1, r0), lim, 0); issue(xb, key_plane(h + 1, r0), lim, 1); }
+            } else if (S > 0) {
+                for (uint32_t g = 0; g < n_g; g++) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        uint32_t r = g * 64u + (uint32_t)j * 16u + sub;
+                        r = r < S ? r : S - 1u;
+                        xa[j] = *(const i32x4 *)(kp + (size_t)r * Dp + chunk * 16u);
+                    }
+                    consume(xa, g, g * 64u);
+                }
+            }
+            if (h + 1 == H && regular_n) {
+                issue(xa, key_plane(0, r0n), R_end - r0n - 64u, 0); issue(xb, key_plane(0, r0n), R_end - r0n - 64u, 1);
+            }
+            if (h + 1 == H && qn < n_query) u_next = (lane < D) ? a.u0[(size_t)qn * D + lane] : 0.0f;
+            wave_sync();                                              // the score bytes are visible to every lane
+
+            // ---- softmax over slots: table look-ups and a double total ------------------------------------------------
+            int acc = 0;
+            if (S > 0) {
+                const int mxc = wave_max_i32(mx);
+                const float *et = etab + h * 256u;
+                double part = 0.0;
+                for (uint32_t g = 0; g < n_g; g++) {
+                    const uint32_t s = g * 64u + lane;
+                    if (s < S) part += (double)et[(uint32_t)(mxc - (int)sc[s])];
+                }
+                const double total = wave_sum_f64(part);
+                // Q(p) != 0 needs p >= 2^-frac; p = (float)(e / total) rounds by at most 2^-24 relative, so a slot with
+                // e < total . 2^-frac . (1 - 2^-20) cannot reach it.  Only the others get the exact quotient.
+                const float thr = (float)(total * (double)qm_scale_down(1.0f, fa.frac) * (1.0 - 9.5367431640625e-07));
+                const SmCfg smc = sm_cfg(a, h);
+                const uint8_t *vb = (const uint8_t *)a.vals + (size_t)h * a.hop_stride + (size_t)r0 * Dp + lane;
+                for (uint32_t g = 0; g < n_g; g++) {
+                    const uint32_t s = g * 64u + lane;
+                    const float e = (s < S) ? et[(uint32_t)(mxc - (int)sc[s])] : 0.0f;
+                    const bool cand = (s < S) && e >= thr;
+                    if (__ballot(cand) == 0) continue;                // wavefront-uniform
+                    int kq = 0;
+                    if (cand) {
+                        const float p = sm_quot(e, total, smc);
+                        kq = (int)__builtin_ldexpf(p, (int)fa.frac);   // Q(p) for 0 <= p <= 1: trunc(p . 2^frac), saturated
+                        kq = kq > maxa ? maxa : kq;
+                    }
+                    // read-out over the rows of this group whose weight code is non-zero (lane c owns column c), four rows per
+                    // round with their value bytes requested together
+                    for (uint64_t m = __ballot(kq != 0); m;) {
+                        int rr[4], kk[4];
+                        uint32_t bb[4];
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            rr[i] = m ? __builtin_ctzll(m) : -1;      // (wavefront-uniform)
+                            m &= m - 1;                               // (0 stays 0)
+                            kk[i] = rr[i] >= 0 ? __builtin_amdgcn_readlane(kq, rr[i] >= 0 ? rr[i] : 0) : 0;
+                            bb[i] = rr[i] >= 0 ? vb[(size_t)(g * 64u + (uint32_t)rr[i]) * Dp] : 0u;
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            uint32_t t = ((uint32_t)kk[i] * (bb[i] & 0x7Fu)) >> fa.frac;   // |Q(p) . v| / 2^frac toward zero
+                            t = t > (uint32_t)maxa ? (uint32_t)maxa : t;
+                            acc += (bb[i] & 0x80u) ? -(int)t : (int)t;
+                        }
+                    }
+                }
+            }
+            lean_finish_hop<W7>(a, h, lane, lw, lmap, u, acc, kb_code, csc, csh, wl_w == wl_m && !relu);
+        }
+        if (lane < D) a.u_out[(size_t)q * D + lane] = relu_if(u, a.en_non_lin != 0);
+        r0 = r0n; S = Sn; regular = regular_n;
+    }
+}
+
+// what this kernel covers: fixed-point attention with the e^x softmax from a table (no shift-based form, no scale layer),
+// 64-byte rows, 65 .. 1 024 slots, no taps; everything else keeps the streaming kernel
+inline bool mid_supported(const HopArgs &a, uint32_t max_slots)
+{
+    return a.Dp == 64 && max_slots > (uint32_t)kWave && max_slots <= kMidMaxSlots && a.softmax_base == QMANN_SOFTMAX_EXP &&
+           !a.softmax_shift && !a.en_att_scale && !a.tap_codes && !a.tap_scores && !a.tap_probs && !a.tap_o && !a.tap_u &&
+           getenv("QMANN_NO_MID") == nullptr;
+}
+
+template <bool W7>
+inline void launch_mid_w(HopArgs a, uint32_t max_slots, uint32_t n_query, hipStream_t st)
+{
+    LeanArgs la{};
+    la.rows_pad = (max_slots + 63u) & ~63u;
+    la.exp_table = 1u;
+    la.lm_in_lds = a.en_lin_map ? 1u : 0u;
+    a.rows_total = n_query;                                               // (no taps: the field carries the query count)
+    const size_t lds = a.n_hop * 1024u + (la.lm_in_lds ? a.n_hop * kLmHopBytes : 0u) + (size_t)kLeanWaves * (kLwBytes + la.rows_pad);
+    if (lds > kLdsDefaultLimit)
+        QM_HIP(hipFuncSetAttribute((const void *)k_hops_mid<W7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const uint32_t need = (n_query + kLeanWaves - 1) / kLeanWaves;
+    const uint32_t per_cu = (uint32_t)(160u * 1024u / (lds + 256u));
+    const uint32_t resident = 256u * (per_cu > 8u ? 8u : (per_cu ? per_cu : 1u));
+    k_hops_mid<W7><<<need < resident ? need : resident, kLeanBlock, lds, st>>>(a, la);
+}
+
+inline void launch_mid(const HopArgs &a, uint32_t max_slots, uint32_t n_query, hipStream_t st)
+{
+    bool w7 = true;
+    for (uint32_t h = 0; h < a.n_hop; h++)
+        w7 = w7 && a.att[h].iwl + a.att[h].frac == 7 && (!a.en_lin_map || a.w[h].iwl + a.w[h].frac == 7);
+    if (w7) launch_mid_w<true>(a, max_slots, n_query, st);
+    else launch_mid_w<false>(a, max_slots, n_query, st);
+}
+
+}  // namespace

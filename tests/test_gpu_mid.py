@@ -1,0 +1,187 @@
+"""The hop kernel for memories of 65 .. 1 024 slots at bAbI width (csrc/hops_mid.h: persistent workgroups, one wavefront per
+query, exp table, exact quotient only for the slots that can survive Q(p)) against
+  * the streaming kernel (csrc/batch_hops.hip, the taps path; itself checked against the oracle in test_gpu_batch.py): the hop
+    outputs must be identical bit for bit, for every format combination and option the kernel accepts;
+  * the CPU oracle directly, per query.
+A request with taps always takes the streaming kernel, one without takes the mid kernel when it applies (QMANN_NO_MID=1 off)."""
+import numpy as np
+import pytest
+
+from conftest import load_pkg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    assert torch.cuda.is_available()
+    load_pkg()
+    import qmann_amd.model as model
+
+    class Env:
+        pass
+    e = Env()
+    e.torch, e.model, e.dev = torch, model, torch.device("cuda:0")
+    return e
+
+
+def cfg_of(D=60, H=3, iwl=5, **kw):
+    frac = 7 - iwl
+    fmt = [(iwl, frac)] * H
+    c = dict(n_hop=H, dim_emb=D, dim_input=40, attention_mode=2, softmax_variant=0, f_fixed=True, en_lin_map=True,
+             fmt=fmt, fmt_w=list(fmt), fmt_att=list(fmt), fmt_bin=(iwl, frac), num_bit=8)
+    c.update(kw)
+    return c
+
+
+def make_batch(env, cfg, B, S_list, seed, sigma_k=30.0, sigma_u=20.0, sigma_h=1.0, shuffle=True):
+    model = env.model
+    H, D, V = cfg["n_hop"], cfg["dim_emb"], cfg["dim_input"]
+    rng = np.random.default_rng(seed)
+    wts = {"w_h": [rng.normal(0, sigma_h, (D, D)).astype(np.float32) for _ in range(H)],
+           "w_ans": rng.normal(0, 0.1, (V, D)).astype(np.float32)}
+    n_slots = np.array([S_list[i % len(S_list)] for i in range(B)], np.int64)
+    if shuffle:
+        rng.shuffle(n_slots)
+    row_off = np.concatenate([[0], np.cumsum(n_slots)]).astype(np.int64)
+    R = max(int(row_off[-1]), 1)
+    keys = np.zeros((H, R, 64), np.int8); vals = np.zeros((H, R, 64), np.int8)
+    keys[:, :, :D] = np.clip(np.rint(rng.normal(0, sigma_k, (H, R, D))), -127, 127)
+    vals[:, :, :D] = np.clip(np.rint(rng.normal(0, sigma_k, (H, R, D))), -127, 127)
+    keys[:, 1::5, ::4] = 0
+    for h in range(H):
+        mk = (1 << sum(cfg["fmt_att"][h])) - 1; mv = (1 << sum(cfg["fmt"][h])) - 1
+        keys[h] = np.clip(keys[h], -mk, mk); vals[h] = np.clip(vals[h], -mv, mv)
+    w0 = cfg["fmt_w"][0]
+    m0 = (1 << sum(w0)) - 1
+    u0 = (np.clip(np.rint(rng.normal(0, sigma_u, (B, D))), -m0, m0) / (1 << w0[1])).astype(np.float32)
+    return wts, keys, vals, u0, n_slots, row_off
+
+
+def both_paths(env, cfg, B, S_list, seed, max_slots=None, oracle=None, n_oracle=0, **kw):
+    torch, model = env.torch, env.model
+    wts, keys, vals, u0, n_slots, row_off = make_batch(env, cfg, B, S_list, seed, **kw)
+    net = model.QNet(cfg, wts, device="cuda:0")
+    assert net.Dp == 64
+    sk = model.to_signmag(keys)
+    sk[:, ::11, 3] = np.int8(-128)                      # "minus zero" bytes (0x80) are legal memory codes
+    dk = torch.from_numpy(sk).to(env.dev); dv = torch.from_numpy(model.to_signmag(vals)).to(env.dev)
+    dro = torch.from_numpy(row_off.astype(np.int32)).to(env.dev); du0 = torch.from_numpy(u0).to(env.dev)
+    ms = int(max_slots if max_slots is not None else n_slots.max())
+    assert 64 < ms <= 1024
+    u_gen, _ = net.hops(dk, dv, dro, ms, du0, taps=True)        # taps: the streaming kernel
+    u_mid = net.hops(dk, dv, dro, ms, du0)                      # no taps: hops_mid.h
+    torch.cuda.synchronize()
+    a, b = u_mid.cpu().numpy(), u_gen.cpu().numpy()
+    bad = np.flatnonzero((a != b).any(1))
+    assert bad.size == 0, f"{bad.size} of {B} queries differ, first {bad[:5]}, slots {n_slots[bad[:5]]}"
+    assert np.abs(b).sum() > 0
+    if oracle is not None:
+        H, D = cfg["n_hop"], cfg["dim_emb"]
+        kd = model.from_signmag(sk)
+        m = oracle.make_model(cfg, wts)
+        pick = [q for q in range(B) if n_slots[q] > 0][:n_oracle]
+        for q in pick:
+            r0, r1 = int(row_off[q]), int(row_off[q]) + min(int(n_slots[q]), ms)
+            kf = np.stack([kd[h, r0:r1, :D] / np.float32(1 << cfg["fmt_att"][h][1]) for h in range(H)]).astype(np.float32)
+            vf = np.stack([vals[h, r0:r1, :D] / np.float32(1 << cfg["fmt"][h][1]) for h in range(H)]).astype(np.float32)
+            _, t = oracle.forward_mem(m, kf, vf, u0[q])
+            want = t["u"][H - 1]
+            if cfg.get("en_non_lin"):                    # u_out is what the answer layer reads: RELU(sv[H-1]) (MemN2N.c:2535-2537)
+                want = np.maximum(want, 0.0)
+            np.testing.assert_array_equal(a[q], want, err_msg=f"query {q} ({n_slots[q]} slots) against the oracle")
+    return net
+
+
+SLOTS = [0, 1, 2, 17, 63, 64, 65, 66, 127, 128, 129, 200, 511, 777, 1000, 1023, 1024]
+
+
+@pytest.mark.parametrize("D", [60, 64, 17])
+def test_mid_equals_streaming_kernel_and_oracle(env, oracle, D):
+    both_paths(env, cfg_of(D=D), B=len(SLOTS) * 6, S_list=SLOTS, seed=500 + D, oracle=oracle, n_oracle=40)
+
+
+@pytest.mark.parametrize("max_slots", [65, 200, 1024])
+def test_mid_uniform_lengths(env, oracle, max_slots):
+    """every story at the bound (the bench's shape), and the batch's last story ending exactly at the end of the plane"""
+    both_paths(env, cfg_of(), B=300, S_list=[max_slots], seed=600 + max_slots, oracle=oracle, n_oracle=6)
+
+
+def test_mid_short_tail_of_the_plane(env, oracle):
+    """the last queries own fewer than 64 rows in total: the per-row clamped loads (no read past the plane's end); and a
+    batch that is one short story only"""
+    both_paths(env, cfg_of(), B=40, S_list=[300] * 37 + [5, 3, 1], seed=700, shuffle=False, oracle=oracle, n_oracle=40, max_slots=300)
+    both_paths(env, cfg_of(), B=1, S_list=[7], seed=701, max_slots=100, oracle=oracle, n_oracle=1)
+    both_paths(env, cfg_of(), B=3, S_list=[70, 0, 2], seed=702, shuffle=False, max_slots=70, oracle=oracle, n_oracle=3)
+
+
+def test_mid_persistent_grid_many_queries(env):
+    """more queries than resident wavefronts: every wavefront walks several queries of different lengths"""
+    both_paths(env, cfg_of(), B=20000, S_list=[65, 70, 100, 3, 130], seed=800)
+
+
+def test_mid_story_longer_than_the_bound_is_cut(env, oracle):
+    both_paths(env, cfg_of(), B=200, S_list=[10, 100, 150, 400, 90], seed=900, max_slots=100, oracle=oracle, n_oracle=30)
+
+
+@pytest.mark.parametrize("iwl", [2, 3, 6])
+def test_mid_other_word_splits(env, oracle, iwl):
+    both_paths(env, cfg_of(iwl=iwl), B=60, S_list=[1, 65, 200, 900], seed=1000 + iwl, oracle=oracle, n_oracle=12)
+
+
+VARIANTS = {
+    "relu": dict(en_non_lin=True), "no_lin_map": dict(en_lin_map=False), "binary": dict(fmt_bin=(0, 0)),
+    "binary_relu": dict(fmt_bin=(0, 0), en_non_lin=True), "en_mq": dict(fmt_w=[(6, 1), (5, 2), (4, 3)]),
+    "one_hop": dict(n_hop=1), "five_hops": dict(n_hop=5),
+    "short_words": dict(fmt=[(3, 2)] * 3, fmt_att=[(2, 4)] * 3, fmt_w=[(2, 3), (4, 1), (1, 2)], fmt_bin=(3, 1)),
+    "fine_activations": dict(fmt=[(0, 7)] * 3),          # Q(p) with 7 fraction bits: up to 128 surviving rows
+}
+
+
+@pytest.mark.parametrize("variant", sorted(VARIANTS))
+def test_mid_options(env, oracle, variant):
+    extra = dict(VARIANTS[variant])
+    H = extra.pop("n_hop", 3)
+    cfg = cfg_of(H=H)
+    for k in ("fmt", "fmt_att", "fmt_w"):
+        if k in extra and len(extra[k]) != H:
+            extra[k] = (extra[k] * H)[:H]
+    cfg.update(extra)
+    both_paths(env, cfg, B=90, S_list=[1, 64, 65, 130, 333, 1024], seed=1100 + len(variant), oracle=oracle, n_oracle=12,
+               sigma_k=12.0 if variant in ("short_words", "fine_activations") else 30.0)
+
+
+def test_mid_linear_map_clamp_corrections(env):
+    """large linear-map codes against large operands: many per-product clamps"""
+    both_paths(env, cfg_of(), B=100, S_list=[70, 200], seed=1200, sigma_u=80.0, sigma_h=12.0)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_mid_random_formats(env, seed):
+    rng = np.random.default_rng(7000 + seed)
+
+    def fmt(lo=2, hi=7):
+        wl = int(rng.integers(lo, hi + 1)); iwl = int(rng.integers(0, wl + 1))
+        return (iwl, wl - iwl)
+    H = int(rng.integers(1, 5))
+    cfg = dict(n_hop=H, dim_emb=int(rng.choice([20, 60, 64])), dim_input=40, attention_mode=2, softmax_variant=0, f_fixed=True,
+               en_lin_map=bool(rng.integers(0, 4)), fmt=[fmt() for _ in range(H)], fmt_w=[fmt() for _ in range(H)],
+               fmt_att=[fmt() for _ in range(H)], fmt_bin=fmt(1, 7), en_non_lin=bool(rng.integers(0, 2)))
+    both_paths(env, cfg, B=50, S_list=[1, 65, 100, 400, 1024], seed=7100 + seed, sigma_k=25.0)
+
+
+def test_other_softmax_forms_keep_the_streaming_kernel(env):
+    """the 2^x / exp_plan bases, the shift-based form and the scale layer are not this kernel's: the request must still be
+    served (by the streaming kernel), with and without taps alike"""
+    torch, model = env.torch, env.model
+    for extra in (dict(softmax_variant=1), dict(softmax_variant=2), dict(att_scale=[-0.5, 0.25, -0.125]),
+                  dict(softmax_variant=1, softmax_shift_based=True)):
+        cfg = cfg_of(); cfg.update(extra)
+        wts, keys, vals, u0, n_slots, row_off = make_batch(env, cfg, 30, [70, 200], 1300)
+        net = model.QNet(cfg, wts, device="cuda:0")
+        dk = torch.from_numpy(model.to_signmag(keys)).to(env.dev); dv = torch.from_numpy(model.to_signmag(vals)).to(env.dev)
+        dro = torch.from_numpy(row_off.astype(np.int32)).to(env.dev); du0 = torch.from_numpy(u0).to(env.dev)
+        a = net.hops(dk, dv, dro, 200, du0); b = net.hops(dk, dv, dro, 200, du0, taps=True)[0]
+        torch.cuda.synchronize()
+        assert torch.equal(a, b)
