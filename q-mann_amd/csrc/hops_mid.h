@@ -64,11 +64,14 @@ k_hops_mid(const HopArgs a, const LeanArgs la)
     const uint32_t lane_off = sub * Dp + chunk * 16u;
     i32x4 xa[4], xb[4];
     auto key_plane = [&](uint32_t h, uint32_t r0_) { return (const uint8_t *)a.keys + (size_t)h * a.key_hop_stride + (size_t)r0_ * Dp; };
+    // np: the passes of 16 rows this group really has (4 for a full group; the story's last group may have fewer, and the
+    // arithmetic of the passes it lacks is skipped -- their loads still run, branch-free, into the next story's rows).
+    auto passes_of = [&](uint32_t g, uint32_t S_) { const uint32_t left = S_ > g * 64u ? S_ - g * 64u : 0u; return left >= 64u ? 4u : (left + 15u) / 16u; };
     auto issue = [&](i32x4 (&x)[4], const uint8_t *plane, uint32_t lim, uint32_t g) {      // regular queries only
         const uint32_t gs = g * 64u < lim ? g * 64u : lim;
         const uint8_t *p = plane + (size_t)gs * Dp + lane_off;
 #pragma unroll
-        for (int j = 0; j < 4; j++) x[j] = *(const i32x4 *)(p + j * 16 * Dp);
+        for (int j = 0; j < 4; j++) x[j] = __builtin_nontemporal_load((const i32x4 *)(p + j * 16 * Dp));
     };
     auto is_regular = [&](uint32_t r0_, uint32_t S_) { return S_ > 0u && R_end - r0_ >= 64u; };
     bool regular = is_regular(r0, S);
@@ -101,10 +104,11 @@ k_hops_mid(const HopArgs a, const LeanArgs la)
             // ---- scan: scores of all rows, 64 rows per step ---------------------------------------------------------
             const uint8_t *kp = key_plane(h, r0);
             int mx = -128;
-            auto consume = [&](const i32x4 (&x)[4], uint32_t g, uint32_t gs) {
-                int s[4];
+            auto consume = [&](const i32x4 (&x)[4], uint32_t g, uint32_t gs, uint32_t np) {
+                int s[4] = {0, 0, 0, 0};
 #pragma unroll
-                for (int j = 0; j < 4; j++) s[j] = row_lanes_sum<4>(lane_sum_w<W7>(x[j], csc, csh));
+                for (uint32_t j = 0; j < 4; j++)
+                    if (j < np) s[j] = row_lanes_sum<4>(lane_sum_w<W7>(x[j], csc, csh));      // wavefront-uniform
                 // every lane of a row group holds its row's sum: lane (sub, chunk) keeps row gs + 16 chunk + sub
                 int v = s[0];
                 v = chunk == 1u ? s[1] : v; v = chunk == 2u ? s[2] : v; v = chunk == 3u ? s[3] : v;
@@ -116,14 +120,14 @@ k_hops_mid(const HopArgs a, const LeanArgs la)
             if (regular) {
                 __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): groups 0 and 1, requested a hop ago, have landed
                 uint32_t g = 0;
-                for (; g + 2 < n_g; g += 2) {                         // steady state: two groups in flight, no branch inside
-                    consume(xa, g, gstart(g));
+                for (; g + 2 < n_g; g += 2) {                         // steady state: two groups in flight, no branch around a load
+                    consume(xa, g, gstart(g), 4);
                     issue(xa, kp, lim, g + 2);
-                    consume(xb, g + 1, gstart(g + 1));
+                    consume(xb, g + 1, gstart(g + 1), 4);
                     issue(xb, kp, lim, g + 3);
                 }
-                consume(xa, g, gstart(g));
-                consume(xb, g + 1, gstart(g + 1));                    // (a group past the story's end stores nothing)
+                consume(xa, g, gstart(g), passes_of(g, S));
+                consume(xb, g + 1, gstart(g + 1), passes_of(g + 1, S));       // (a group past the story's end: no pass, nothing stored)
                 // in flight during the rest of the hop: the next hop's first two groups, or the next query's
                 if (h + 1 < H) { issue(xa, key_plane(h + 1, r0), lim, 0); issue(xb, key_plane(h + 1, r0), lim, 1); }
             } else if (S > 0) {
@@ -134,7 +138,7 @@ k_hops_mid(const HopArgs a, const LeanArgs la)
                         r = r < S ? r : S - 1u;
                         xa[j] = *(const i32x4 *)(kp + (size_t)r * Dp + chunk * 16u);
                     }
-                    consume(xa, g, g * 64u);
+                    consume(xa, g, g * 64u, 4);
                 }
             }
             if (h + 1 == H && regular_n) {
