@@ -22,9 +22,14 @@
 namespace {
 
 constexpr uint32_t kMidMaxSlots = 1024;
+#ifndef QM_MID_WAVES
+#define QM_MID_WAVES 8                                    // (10 -- five wavefronts per SIMD at 96 registers -- measured 35 % slower)
+#endif
+constexpr int kMidWaves = QM_MID_WAVES;                 // wavefronts per workgroup; two workgroups per CU
+constexpr int kMidBlock = kMidWaves * kWave;
 
 template <bool W7>
-__global__ void __launch_bounds__(kLeanBlock, 4)          // 4 wavefronts per SIMD: two workgroups per CU
+__global__ void __launch_bounds__(kMidBlock, (2 * kMidWaves + 3) / 4)      // two workgroups per CU
 k_hops_mid(const HopArgs a, const LeanArgs la)
 {
     constexpr uint32_t Dp = 64;
@@ -39,11 +44,11 @@ k_hops_mid(const HopArgs a, const LeanArgs la)
     const uint32_t wslice = kLwBytes + la.rows_pad;                     // rows_pad: score bytes per wavefront (multiple of 64)
     uint8_t *lw = wbase + wave * wslice;                                // small arrays
     int8_t *sc = (int8_t *)(lw + kLwBytes);                             // score codes, slot r
-    lean_stage_tables(a, la, etab, lmap, tid, kLeanBlock);
+    lean_stage_tables(a, la, etab, lmap, tid, kMidBlock);
     __syncthreads();
 
-    const uint32_t q_stride = gridDim.x * kLeanWaves, n_query = a.rows_total;   // (rows_total carries the query count, see launcher)
-    uint32_t q = blockIdx.x * kLeanWaves + wave;
+    const uint32_t q_stride = gridDim.x * kMidWaves, n_query = a.rows_total;   // (rows_total carries the query count, see launcher)
+    uint32_t q = blockIdx.x * kMidWaves + wave;
     if (q >= n_query) return;
     const uint32_t R_end = a.row_off[n_query];                          // rows of a plane that belong to this batch
     auto slots_of = [&](uint32_t qq, uint32_t &r0_, uint32_t &S_) {
@@ -219,13 +224,13 @@ inline void launch_mid_w(HopArgs a, uint32_t max_slots, uint32_t n_query, hipStr
     la.exp_table = 1u;
     la.lm_in_lds = a.en_lin_map ? 1u : 0u;
     a.rows_total = n_query;                                               // (no taps: the field carries the query count)
-    const size_t lds = a.n_hop * 1024u + (la.lm_in_lds ? a.n_hop * kLmHopBytes : 0u) + (size_t)kLeanWaves * (kLwBytes + la.rows_pad);
+    const size_t lds = a.n_hop * 1024u + (la.lm_in_lds ? a.n_hop * kLmHopBytes : 0u) + (size_t)kMidWaves * (kLwBytes + la.rows_pad);
     if (lds > kLdsDefaultLimit)
         QM_HIP(hipFuncSetAttribute((const void *)k_hops_mid<W7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const uint32_t need = (n_query + kLeanWaves - 1) / kLeanWaves;
+    const uint32_t need = (n_query + kMidWaves - 1) / kMidWaves;
     const uint32_t per_cu = (uint32_t)(160u * 1024u / (lds + 256u));
-    const uint32_t resident = 256u * (per_cu > 8u ? 8u : (per_cu ? per_cu : 1u));
-    k_hops_mid<W7><<<need < resident ? need : resident, kLeanBlock, lds, st>>>(a, la);
+    const uint32_t resident = 256u * (per_cu > 2u ? 2u : (per_cu ? per_cu : 1u));
+    k_hops_mid<W7><<<need < resident ? need : resident, kMidBlock, lds, st>>>(a, la);
 }
 
 inline void launch_mid(const HopArgs &a, uint32_t max_slots, uint32_t n_query, hipStream_t st)
