@@ -59,7 +59,7 @@ def make_batch(env, cfg, B, S_list, seed, sigma_k=30.0, sigma_u=20.0, sigma_h=1.
     return wts, keys, vals, u0, n_slots, row_off
 
 
-def both_paths(env, cfg, B, S_list, seed, max_slots=None, oracle=None, n_oracle=0, **kw):
+def both_paths(env, cfg, B, S_list, seed, max_slots=None, oracle=None, n_oracle=0, nonzero=True, max_excused=0, **kw):
     torch, model = env.torch, env.model
     wts, keys, vals, u0, n_slots, row_off = make_batch(env, cfg, B, S_list, seed, **kw)
     net = model.QNet(cfg, wts, device="cuda:0")
@@ -68,7 +68,7 @@ def both_paths(env, cfg, B, S_list, seed, max_slots=None, oracle=None, n_oracle=
     sk[:, ::11, 3] = np.int8(-128)                      # "minus zero" bytes (0x80) are legal memory codes
     dk = torch.from_numpy(sk).to(env.dev); dv = torch.from_numpy(model.to_signmag(vals)).to(env.dev)
     dro = torch.from_numpy(row_off.astype(np.int32)).to(env.dev); du0 = torch.from_numpy(u0).to(env.dev)
-    ms = int(max_slots if max_slots is not None else n_slots.max())
+    ms = int(max_slots if max_slots is not None else max(int(n_slots.max()), 65))
     assert 64 < ms <= 1024
     u_gen, _ = net.hops(dk, dv, dro, ms, du0, taps=True)        # taps: the streaming kernel
     u_mid = net.hops(dk, dv, dro, ms, du0)                      # no taps: hops_mid.h
@@ -76,12 +76,13 @@ def both_paths(env, cfg, B, S_list, seed, max_slots=None, oracle=None, n_oracle=
     a, b = u_mid.cpu().numpy(), u_gen.cpu().numpy()
     bad = np.flatnonzero((a != b).any(1))
     assert bad.size == 0, f"{bad.size} of {B} queries differ, first {bad[:5]}, slots {n_slots[bad[:5]]}"
-    assert np.abs(b).sum() > 0
+    assert not nonzero or np.abs(b).sum() > 0
     if oracle is not None:
         H, D = cfg["n_hop"], cfg["dim_emb"]
         kd = model.from_signmag(sk)
         m = oracle.make_model(cfg, wts)
         pick = [q for q in range(B) if n_slots[q] > 0][:n_oracle]
+        excused = 0
         for q in pick:
             r0, r1 = int(row_off[q]), int(row_off[q]) + min(int(n_slots[q]), ms)
             kf = np.stack([kd[h, r0:r1, :D] / np.float32(1 << cfg["fmt_att"][h][1]) for h in range(H)]).astype(np.float32)
@@ -90,7 +91,17 @@ def both_paths(env, cfg, B, S_list, seed, max_slots=None, oracle=None, n_oracle=
             want = t["u"][H - 1]
             if cfg.get("en_non_lin"):                    # u_out is what the answer layer reads: RELU(sv[H-1]) (MemN2N.c:2535-2537)
                 want = np.maximum(want, 0.0)
-            np.testing.assert_array_equal(a[q], want, err_msg=f"query {q} ({n_slots[q]} slots) against the oracle")
+            if not np.array_equal(a[q], want):
+                # only where a softmax weight of the oracle lies within 1e-5 of a truncation step of Q(p) (never seen in the
+                # cases of this file: max_excused = 0; tools/soak.py allows it and reports)
+                near = False
+                for h in range(H):
+                    x = t["probs"][h].astype(np.float64) * (1 << cfg["fmt"][h][1])
+                    k = np.rint(x)
+                    near |= bool(((np.abs(x - k) <= 1e-5 * np.maximum(1.0, np.abs(x))) & (k > 0)).any())
+                assert near, f"query {q} ({n_slots[q]} slots) differs from the oracle with no softmax weight on a truncation step"
+                excused += 1
+        assert excused <= max_excused, f"{excused} queries needed the p-on-a-step excuse"
     return net
 
 

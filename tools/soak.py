@@ -13,6 +13,7 @@ import test_gpu_lean as TL                                   # noqa: E402
 import test_gpu_words as TW                                  # noqa: E402
 import test_gpu_batch as TB                                  # noqa: E402
 import test_gpu_ops as TO                                    # noqa: E402
+import test_gpu_mid as TM                                    # noqa: E402
 
 
 def main():
@@ -43,7 +44,7 @@ def main():
     print("soak seed base", seed, flush=True)
     while time.time() - t0 < budget:
         rng = np.random.default_rng(seed + n)
-        kind = n % 9
+        kind = n % 10
         if kind == 0:                                        # lean kernel vs general kernel, random formats (fixed-point attention)
             def fmt(lo=2, hi=7):
                 wl = int(rng.integers(lo, hi + 1)); iwl = int(rng.integers(0, wl + 1))
@@ -94,7 +95,7 @@ def main():
                 S_list = [int(rng.integers(700, 6000))]            # a long memory now and then (the four-wavefront streaming form)
             try:
                 TB.run_case(env, oracle, cfg, B=int(rng.integers(1, 10)), S_list=S_list, seed=seed + n, sigma_u=float(rng.uniform(3, 60)),
-                            sigma_k=float(rng.uniform(3, 50)), sigma_h=float(rng.uniform(0.3, 8)))
+                            sigma_k=float(rng.uniform(3, 50)), sigma_h=float(rng.uniform(0.3, 8)), max_excused=1)
             except AssertionError:
                 print("FAILED oracle case", n, "seed base", seed, "cfg", cfg, "S_list", S_list, flush=True)
                 raise
@@ -152,6 +153,22 @@ def main():
                 TB.run_float_case(env, oracle, D, S_list, Bf, seed=seed + n, max_excused=Bf)
             except AssertionError:
                 print("FAILED float case", n, "seed base", seed, D, S_list, Bf, flush=True)
+                raise
+        if kind == 9:                                        # the 65..1 024-slot kernel (hops_mid.h) against the streaming kernel and the oracle
+            def fmt(lo=2, hi=7):
+                wl = int(rng.integers(lo, hi + 1)); iwl = int(rng.integers(0, wl + 1))
+                return (iwl, wl - iwl)
+            H = int(rng.integers(1, 5))
+            cfg = dict(n_hop=H, dim_emb=int(rng.choice([17, 20, 60, 64])), dim_input=40, attention_mode=2, softmax_variant=0, f_fixed=True,
+                       en_lin_map=bool(rng.integers(0, 4)), fmt=[fmt() for _ in range(H)], fmt_w=[fmt() for _ in range(H)],
+                       fmt_att=[fmt() for _ in range(H)], fmt_bin=fmt(1, 7), en_non_lin=bool(rng.integers(0, 2)))
+            S = [int(x) for x in rng.integers(0, 1025, 5)] + [int(rng.integers(65, 1025))]
+            args = dict(B=int(rng.integers(1, 60)), S_list=S, seed=seed + n, sigma_k=float(rng.uniform(3, 60)),
+                        sigma_u=float(rng.uniform(3, 80)), sigma_h=float(rng.uniform(0.3, 12)))
+            try:
+                TM.both_paths(env, cfg, oracle=oracle, n_oracle=3, nonzero=False, max_excused=3, **args)
+            except AssertionError:
+                print("FAILED mid case", n, "seed base", seed, "cfg", cfg, "args", args, flush=True)
                 raise
         n += 1
         if n % 100 == 0:
