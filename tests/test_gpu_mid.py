@@ -75,13 +75,18 @@ def both_paths(env, cfg, B, S_list, seed, max_slots=None, oracle=None, n_oracle=
     torch.cuda.synchronize()
     a, b = u_mid.cpu().numpy(), u_gen.cpu().numpy()
     bad = np.flatnonzero((a != b).any(1))
-    assert bad.size == 0, f"{bad.size} of {B} queries differ, first {bad[:5]}, slots {n_slots[bad[:5]]}"
+    # The two kernels add the softmax total in different orders (per slot / per score bin), both in double: the totals can
+    # differ in the last bit, and where a weight sits exactly on a truncation step of Q(p) -- two tied top scores give p = 1/2 --
+    # that bit decides the code.  Such a query is excused ONLY with the oracle's word that some p lies on a step (below);
+    # without an oracle any difference fails.  None occurs in the cases of this file (max_excused = 0); tools/soak.py found
+    # one in ~240 random-format cases (formats with one or two fraction bits).
+    assert bad.size == 0 or oracle is not None, f"{bad.size} of {B} queries differ, first {bad[:5]}, slots {n_slots[bad[:5]]}"
     assert not nonzero or np.abs(b).sum() > 0
     if oracle is not None:
         H, D = cfg["n_hop"], cfg["dim_emb"]
         kd = model.from_signmag(sk)
         m = oracle.make_model(cfg, wts)
-        pick = [q for q in range(B) if n_slots[q] > 0][:n_oracle]
+        pick = sorted(set([q for q in range(B) if n_slots[q] > 0][:n_oracle]) | set(int(q) for q in bad))
         excused = 0
         for q in pick:
             r0, r1 = int(row_off[q]), int(row_off[q]) + min(int(n_slots[q]), ms)
