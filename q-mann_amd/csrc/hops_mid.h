@@ -122,26 +122,20 @@ k_hops_mid(const HopArgs a, const LeanArgs la)
                 if (r >= g * 64u && r < S) { sc[r] = (int8_t)code; mx = code > mx ? code : mx; }
             };
             auto gstart = [&](uint32_t g) { return g * 64u < lim ? g * 64u : lim; };
+            // passes with live rows in group g: a group moved back from the plane's end (gstart(g) < 64 g) holds its live rows in
+            // its LAST passes, not its first -- all four are taken then (the row test in consume() drops the repeated rows)
+            auto passes_at = [&](uint32_t g) { return gstart(g) == g * 64u ? passes_of(g, S) : (g * 64u < S ? 4u : 0u); };
             if (regular) {
-                // Four groups in flight: groups 0 and 1 were requested a hop ago (xa, xb), 2 and 3 are requested now, and every
-                // group consumed is replaced by the one four ahead.  A group index past the story's last group is clamped to it
-                // (a line already in flight; its arithmetic is skipped), so no branch surrounds a load.
-                const uint32_t g_last = n_g - 1u;
-                auto issue_c = [&](i32x4 (&x)[4], uint32_t g) { issue(x, kp, lim, g < g_last ? g : g_last); };
-                auto passes_c = [&](uint32_t g) { return g <= g_last ? passes_of(g, S) : 0u; };
-                i32x4 xc[4], xd[4];
-                issue_c(xc, 2); issue_c(xd, 3);
+                __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): groups 0 and 1, requested a hop ago, have landed
                 uint32_t g = 0;
-                for (; g + 4 < n_g; g += 4) {
-                    consume(xa, g, gstart(g), 4); issue_c(xa, g + 4);
-                    consume(xb, g + 1, gstart(g + 1), 4); issue_c(xb, g + 5);
-                    consume(xc, g + 2, gstart(g + 2), 4); issue_c(xc, g + 6);
-                    consume(xd, g + 3, gstart(g + 3), 4); issue_c(xd, g + 7);
+                for (; g + 2 < n_g; g += 2) {                         // steady state: two groups in flight, no branch around a load
+                    consume(xa, g, gstart(g), 4);
+                    issue(xa, kp, lim, g + 2);
+                    consume(xb, g + 1, gstart(g + 1), 4);
+                    issue(xb, kp, lim, g + 3);
                 }
-                consume(xa, g, gstart(g), passes_c(g));
-                consume(xb, g + 1, gstart(g + 1), passes_c(g + 1));
-                consume(xc, g + 2, gstart(g + 2), passes_c(g + 2));
-                consume(xd, g + 3, gstart(g + 3), passes_c(g + 3));
+                consume(xa, g, gstart(g), passes_at(g));
+                consume(xb, g + 1, gstart(g + 1), passes_at(g + 1));       // (a group past the story's end: no pass, nothing stored)
                 // in flight during the rest of the hop: the next hop's first two groups, or the next query's
                 if (h + 1 < H) { issue(xa, key_plane(h + 1, r0), lim, 0); issue(xb, key_plane(h + 1, r0), lim, 1); }
             } else if (S > 0) {

@@ -201,3 +201,39 @@ def test_other_softmax_forms_keep_the_streaming_kernel(env):
         a = net.hops(dk, dv, dro, 200, du0); b = net.hops(dk, dv, dro, 200, du0, taps=True)[0]
         torch.cuda.synchronize()
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("tail", [1, 8, 17, 40, 63])
+def test_mid_last_story_of_the_plane_whose_decisive_rows_lie_in_its_last_group(env, oracle, tail):
+    """tools/soak.py case 12740589 + 2439.  The LAST story of a batch has nothing behind it in the plane, so its last group of
+    64 rows is moved back to end at the plane's end: the rows that are new in that group sit in its LAST passes.  An earlier
+    version skipped all but the first passes of a short last group and so never scored those rows.  Here the row that decides
+    the softmax of hop 0 is the story's very last one (a key aligned with the query, every other score far below it); the
+    story has 64 + tail rows."""
+    torch, model = env.torch, env.model
+    cfg = cfg_of()
+    S_last = 64 + tail
+    wts, keys, vals, u0, n_slots, row_off = make_batch(env, cfg, 3, [130, 70, S_last], 1400 + tail, shuffle=False, sigma_k=1.5, sigma_u=8.0)
+    D, H = cfg["dim_emb"], cfg["n_hop"]
+    r_last = int(row_off[-1]) - 1
+    uc = np.rint(u0[2] * 4.0)                                             # Q5.2 codes of the query
+    keys[0, r_last, :D] = np.clip(np.sign(uc) * 90, -127, 127)           # hop 0: this row's score saturates at the top code
+    vals[:, :, :D] = np.clip(np.rint(np.random.default_rng(tail).normal(0, 30, vals[:, :, :D].shape)), -127, 127)
+    vals[0, r_last, :D] = np.clip(np.arange(D) % 7 * 17 - 50, -127, 127)  # and its value row is distinctive
+    net = model.QNet(cfg, wts, device="cuda:0")
+    sk, sv = model.to_signmag(keys), model.to_signmag(vals)
+    dk, dv = torch.from_numpy(sk).to(env.dev), torch.from_numpy(sv).to(env.dev)
+    dro = torch.from_numpy(row_off.astype(np.int32)).to(env.dev); du0 = torch.from_numpy(u0).to(env.dev)
+    ms = 130
+    u_mid = net.hops(dk, dv, dro, ms, du0).cpu().numpy()
+    u_gen = net.hops(dk, dv, dro, ms, du0, taps=True)[0].cpu().numpy()
+    m = oracle.make_model(cfg, wts)
+    for q in range(3):
+        r0, r1 = int(row_off[q]), int(row_off[q + 1])
+        kf = np.stack([keys[h, r0:r1, :D] / np.float32(1 << cfg["fmt_att"][h][1]) for h in range(H)]).astype(np.float32)
+        vf = np.stack([vals[h, r0:r1, :D] / np.float32(1 << cfg["fmt"][h][1]) for h in range(H)]).astype(np.float32)
+        _, t = oracle.forward_mem(m, kf, vf, u0[q])
+        if q == 2:
+            assert t["probs"][0][-1] > 0.9                                # the last row does decide hop 0
+        np.testing.assert_array_equal(u_mid[q], t["u"][H - 1], err_msg=f"query {q}")
+        np.testing.assert_array_equal(u_gen[q], t["u"][H - 1], err_msg=f"query {q} (streaming kernel)")
