@@ -376,7 +376,7 @@ k_hops_lean(const HopArgs a, const LeanArgs la)
         for (int j = 0; j < 4; j++) {
             const uint32_t r = j * 16 + sub;
             kq[j] = i32x4{0, 0, 0, 0};
-            if (r < S_) kq[j] = *(const i32x4 *)(kb + (size_t)r * Dp);
+            if (r < S_) kq[j] = __builtin_nontemporal_load((const i32x4 *)(kb + (size_t)r * Dp));   // (streamed once: keep it out of the caches' way)
         }
     };
     load_keys_of(0, r0, S);
@@ -399,7 +399,7 @@ k_hops_lean(const HopArgs a, const LeanArgs la)
                 if (j * 16 < (int)S) {                                    // wavefront-uniform
                     if (r < S)
                         __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(vb + (size_t)r * Dp),
-                                                         (void __attribute__((address_space(3))) *)(vt + j * 1024), 16, 0, 0);
+                                                         (void __attribute__((address_space(3))) *)(vt + j * 1024), 16, 0, 0);   // (the nt policy on this DMA measured no different)
                 }
             }
             lean_hop<MODE, NB, W7>(a, la, h, S, lane, vt, lw, lmap, etab, u, [&](int j) { return kq[j]; }, [&]() {
