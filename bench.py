@@ -637,8 +637,18 @@ def main(argv=None):
         if world > 1 and not rehearse:
             # the library's own communicator (ncclCommInitRank inside libqmann_hip.so); torch.distributed carried the id
             from qmann_amd.parallel import Comm
-            COMM = Comm(rank, world, local_rank)
-            comm_info = COMM.info()
+            try:
+                COMM = Comm(rank, world, local_rank)
+                comm_info = COMM.info()
+            except Exception as e:                                   # (the line then says so; the blob goes through the process group)
+                COMM, comm_info = None, {"error": f"C-level RCCL rendezvous failed: {e}"}
+            # every rank must take the same road: one rank without a communicator sends all of them to the process group
+            import torch.distributed as dist
+            ok = torch.tensor([1 if COMM is not None else 0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and COMM is not None:
+                COMM.close()
+                COMM, comm_info = None, {"error": "another rank could not join the C-level communicator"}
         out = run_workload(args, args.workload, dev, rank, world)
         # BASELINE.json quotes its metric at |mem| = 50 (the bAbI cap) and sets its target at |mem| = 10 000:
         # the default line is the 10 000-slot configuration and carries the 50-slot figure beside it

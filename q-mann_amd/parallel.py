@@ -151,17 +151,26 @@ def replicate_model(hm, cfg, dev, rank: int, world: int, comm: "Comm | None", mo
         finally:
             abi.lib.qmann_params_free(blob)
         return hm, ms, f"qmann_comm_broadcast_params: ncclBroadcast of the quantised blob ({n.value} bytes)"
-    # rehearsal: same blob, carried by the process group
-    size = torch.zeros(1, dtype=torch.int64)
+    # no library communicator (the one-GPU rehearsal over gloo, or the C-level rendezvous failed): the same blob, carried by
+    # the process group -- on device tensors when the group's backend is RCCL, on host tensors otherwise
+    on_gpu = dist.get_backend() == "nccl"
+    pg_dev = dev if on_gpu else torch.device("cpu")
+    size = torch.zeros(1, dtype=torch.int64, device=pg_dev)
     raw = hm.params_bytes() if rank == 0 else b""
     if rank == 0:
         size[0] = len(raw)
     dist.broadcast(size, src=0)
-    buf = torch.frombuffer(bytearray(raw), dtype=torch.uint8) if rank == 0 else torch.zeros(int(size[0]), dtype=torch.uint8)
+    n = int(size.item())
+    buf = (torch.frombuffer(bytearray(raw), dtype=torch.uint8) if rank == 0 else torch.zeros(n, dtype=torch.uint8)).to(pg_dev)
+    if on_gpu:
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     dist.broadcast(buf, src=0)
+    if on_gpu:
+        torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 1e3
     if rank != 0:
-        host = buf.numpy()
+        host = buf.cpu().numpy()
         hm = model_mod.HostModel.from_params(cfg, host.ctypes.data, host.size, device=str(dev))
-    return hm, ms, f"process-group broadcast of the quantised blob ({int(size[0])} bytes; rehearsal, not RCCL)"
+    return hm, ms, (f"process-group broadcast of the quantised blob ({n} bytes, backend {dist.get_backend()}; "
+                    "not the library's own communicator)")

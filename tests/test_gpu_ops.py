@@ -344,3 +344,109 @@ def test_forward_verbs_random_shapes_and_formats(env, oracle, seed):
     dMa, dua, dsa = env.up(Ma), env.up(ua), env.empty(r)
     env.lib.cuda_dot_mat_vec_fwd_appx(env.ptr(dMa), env.ptr(dua), env.ptr(dsa), None, None, r, c, True, ia, 7 - ia, 3, 8, False, False)
     np.testing.assert_array_equal(dsa.cpu().numpy(), oracle.dot_mat_vec_fwd_appx(Ma, ua, False, True, ia, 7 - ia, 8), err_msg="appx")
+
+
+# ---------------------------------------------------------------------------------------------
+# the deferred queue behind the forward verbs (include/qmann_abi.h "Deferred execution"), driven verb by verb
+# ---------------------------------------------------------------------------------------------
+def _host_loop(env, cfg, wts, story, ques, ans_onehot, n_sen, nq, defer, stray=None):
+    """MemN2N.c's test loop (:2378-2702) in ctypes: per query the 31 verbs in the reference's order on FIXED layer buffers
+    (as the host's structs hold them), accumulators fetched once at the end.  `stray`: a query index after which an
+    unrelated verb (a vector sum on scratch) is issued -- the pattern breaks there and must fall back to the verbs."""
+    lib, up, ptr, empty, torch = env.lib, env.up, env.ptr, env.empty, env.torch
+    V, D, H = cfg["dim_input"], cfg["dim_emb"], cfg["n_hop"]
+    lib.qmann_abi_set_defer(defer)
+    dwq, dwans = up(wts["w_q"]), up(wts["w_ans"])
+    dwa = [up(w) for w in wts["w_a"]]; dwc = [up(w) for w in wts["w_c"]]; dwh = [up(w) for w in wts["w_h"]]
+    offs = np.concatenate([[0], np.cumsum(n_sen[:nq])]).astype(np.int64)
+    dm, dq, da = up(story[:offs[nq]]), up(ques[:nq]), up(ans_onehot[:nq])
+    S = int(n_sen[:nq].max())
+    u0 = empty(D); Mk = [empty(S, D) for _ in range(H)]; Mc = [empty(S, D) for _ in range(H)]
+    s = [empty(S) for _ in range(H)]; p = [empty(S) for _ in range(H)]; o = [empty(D) for _ in range(H)]
+    lu = [empty(D) for _ in range(H)]; sv = [empty(D) for _ in range(H)]
+    a, ph, mxs, grad = empty(V), empty(V), empty(1), empty(V)
+    cost = torch.zeros(3, device=env.dev); cnt = torch.zeros(3, dtype=torch.int32, device=env.dev)
+    pred = torch.zeros(1, dtype=torch.int32, device=env.dev)
+    junk = [empty(D) for _ in range(3)]
+    fptr = lambda t, i: C.c_void_p(t.data_ptr() + 4 * i)
+    for i in range(nq):
+        ns = int(n_sen[i])
+        X = C.c_void_p(dm.data_ptr() + 4 * V * int(offs[i])); q = C.c_void_p(dq.data_ptr() + 4 * V * i)
+        y = C.c_void_p(da.data_ptr() + 4 * V * i)
+        fw0 = cfg["fmt_w"][0]
+        lib.cuda_dense_fwd(ptr(dwq), None, q, ptr(u0), None, V, D, b"NULL", True, *fw0, *fw0, 3, False)
+        u = u0
+        for h in range(H):
+            fw, fa, fm, fb = cfg["fmt_w"][h], cfg["fmt"][h], cfg["fmt_att"][h], cfg["fmt_bin"]
+            lib.cuda_dense_mat_fwd(ptr(dwa[h]), None, X, ptr(Mk[h]), None, V, D, ns, True, *fw, 3, False)
+            lib.cuda_dense_mat_fwd(ptr(dwc[h]), None, X, ptr(Mc[h]), None, V, D, ns, True, *fw, 3, False)
+            lib.cuda_dot_mat_vec_fwd(ptr(Mk[h]), ptr(u), ptr(s[h]), None, ns, D, False, True, *fm, *fb, 3, False)
+            lib.cuda_softmax_fwd(ptr(p[h]), ptr(s[h]), None, None, ptr(mxs), ns, False, False)
+            lib.cuda_dot_mat_vec_fwd(ptr(Mc[h]), ptr(p[h]), ptr(o[h]), None, ns, D, True, True, *fa, *fa, 3, False)
+            lib.cuda_dense_fwd(ptr(dwh[h]), None, ptr(u), ptr(lu[h]), None, D, D, b"NULL", True, *fb, *fw, 3, False)
+            lib.cuda_sum_vec_fwd(ptr(lu[h]), ptr(o[h]), ptr(sv[h]), D, True, *fa, 3, False)
+            u = sv[h]
+        lib.cuda_dense_fwd(ptr(dwans), None, ptr(u), ptr(a), None, D, V, b"NULL", False, 8, 7, 8, 7, 3, False)
+        lib.cuda_softmax_fwd(ptr(ph), ptr(a), None, None, ptr(mxs), V, False, False)
+        lib.cuda_cross_entropy_run(fptr(cost, 0), fptr(cost, 1), fptr(cost, 2), fptr(cnt, 0), fptr(cnt, 1), fptr(cnt, 2), ptr(pred),
+                                   None, ptr(ph), y, None, None, ptr(grad), None, V, 3)
+        if stray is not None and i == stray:
+            lib.cuda_sum_vec_fwd(ptr(junk[0]), ptr(junk[1]), ptr(junk[2]), D, False, 0, 0, 3, False)
+    hc = (C.c_float * 3)(); hm = (C.c_uint * 3)()
+    lib.cuda_cross_entropy_cost_load(fptr(cost, 0), fptr(cost, 1), fptr(cost, 2), hc, C.byref(hc, 4), C.byref(hc, 8))
+    lib.cuda_cross_entropy_m_cnt_load(fptr(cnt, 0), fptr(cnt, 1), fptr(cnt, 2), hm, C.byref(hm, 4), C.byref(hm, 8))
+    st = env.abi.defer_stats()
+    lib.qmann_abi_set_defer(0)
+    return dict(match=int(hm[2]), cost=float(hc[2]), last_u=sv[H - 1].cpu().numpy().copy(), last_p=ph.cpu().numpy().copy(),
+                last_pred=int(pred.item()), last_scores=s[0].cpu().numpy()[:int(n_sen[nq - 1])].copy(), stats=st)
+
+
+def test_deferred_queue_equals_the_verbs(env, gold):
+    """the same host loop with the queue off, on and in verify mode: match count equal, cost within the float tolerance, and
+    after the loop every layer buffer holds the LAST query's values as the serial loop leaves them.  With a stray verb in the
+    middle the run splits in two batched pieces and the stray verb executes in order between them."""
+    import importlib.util
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("gen_golden", ROOT / "oracle" / "gen_golden.py")
+    gg = importlib.util.module_from_spec(spec); spec.loader.exec_module(gg)
+    b = gold("babi_qa1_test64.npz")
+    V, D, H, nq = int(b["dim_input"]), 60, 3, 40
+    cfg = gg.babi_cfg(V, 2, 0)
+    wts = gg.seeded_weights(4321, H, D, V, 1.0)
+    args = (env, cfg, wts, b["story"].astype(np.float32), b["question"].astype(np.float32), b["answer"].astype(np.float32),
+            b["n_sen"].astype(np.int64), nq)
+    s0 = env.abi.defer_stats()
+    off = _host_loop(*args, defer=0)
+    assert off["stats"]["queries_batched"] == s0["queries_batched"]
+    on = _host_loop(*args, defer=1)
+    assert on["stats"]["queries_batched"] - off["stats"]["queries_batched"] == nq and on["stats"]["batches"] - off["stats"]["batches"] == 1
+    ver = _host_loop(*args, defer=2)
+    assert ver["stats"]["verify_mismatch"] == off["stats"]["verify_mismatch"]
+    split = _host_loop(*args, defer=1, stray=17)
+    assert split["stats"]["batches"] - ver["stats"]["batches"] == 2
+    for r in (on, ver, split):
+        assert r["match"] == off["match"] and r["last_pred"] == off["last_pred"]
+        assert r["cost"] == pytest.approx(off["cost"], rel=1e-5)
+        np.testing.assert_array_equal(r["last_u"], off["last_u"])
+        np.testing.assert_array_equal(r["last_scores"], off["last_scores"])
+        np.testing.assert_array_equal(r["last_p"], off["last_p"])
+
+
+def test_deferred_verbs_become_visible_at_a_flush(env):
+    """queue on: a forward verb's result is not there until a synchronising verb or qmann_abi_flush() -- the contract of
+    include/qmann_abi.h; a lone verb (no pattern) is simply executed at the flush"""
+    lib, up, ptr, empty = env.lib, env.up, env.ptr, env.empty
+    a, b, out = up(np.arange(8, dtype=np.float32)), up(np.ones(8, np.float32)), env.torch.zeros(8, device=env.dev)
+    lib.qmann_abi_set_defer(1)
+    lib.cuda_sum_vec_fwd(ptr(a), ptr(b), ptr(out), 8, False, 0, 0, 3, False)
+    env.torch.cuda.synchronize()
+    assert float(out.sum()) == 0.0                       # recorded, not launched
+    lib.qmann_abi_flush()
+    env.torch.cuda.synchronize()
+    np.testing.assert_array_equal(out.cpu().numpy(), np.arange(8) + 1.0)
+    out.zero_()
+    lib.cuda_sum_vec_fwd(ptr(a), ptr(b), ptr(out), 8, False, 0, 0, 3, False)
+    host = np.zeros(8, np.float32)
+    lib.cuda_copy_dev2host(host.ctypes.data_as(C.c_void_p), ptr(out), 8)        # a synchronising verb drains the queue first
+    np.testing.assert_array_equal(host, np.arange(8) + 1.0)
+    lib.qmann_abi_set_defer(0)
