@@ -153,12 +153,15 @@ void bind_sections(qmann_model *m, const BlobHeader &h)
     for (uint32_t i = m->H; i < QMANN_MAX_HOP; i++) m->net.lin_map[i] = nullptr;
 }
 
-// packed planes pay off when they are smaller than the bytes (num_bit < 8) and the memory is long enough for
-// bandwidth to matter; otherwise the same scores come straight from the int8 keys.  A plane row must fill a 16-byte load
+// Packed planes pay off when they are smaller than the bytes (num_bit < 8), the memory is long enough for bandwidth to
+// matter, AND a plane is read more than once: packing reads every key byte once more and writes the planes, so with a plane
+// per hop (each read by its own hop only) the packed path moves 2 + num_bit/4 bytes per key byte where the byte form moves 2
+// (embedding store + one scan).  Only tied hops -- one plane scanned by every hop -- win: 2 + (1 + H) num_bit/8 against 1 + H.
+// Otherwise the same scores come straight from the int8 keys (the V0 / V1 byte forms).  A plane row must fill a 16-byte load
 // (qmann_hops_packed refuses Dp = 64 with a single plane: 8 bytes per row): that case takes the byte form too.
 bool use_planes(const qmann_model *m, uint32_t max_slots)
 {
-    return packed_mode(m->net) && m->net.num_bit < 8 && max_slots > 64 && (m->Dp / 64) * m->net.num_bit * 8 >= 16;
+    return packed_mode(m->net) && m->net.num_bit < 8 && max_slots > 64 && (m->Dp / 64) * m->net.num_bit * 8 >= 16 && m->tied && m->H > 1;
 }
 
 int ensure(qmann_model *m, size_t rows, uint32_t n_query, bool planes)
