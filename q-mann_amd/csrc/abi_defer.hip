@@ -133,8 +133,6 @@ size_t match_query(const std::vector<Op> &ops, size_t i, Sig &s, Query &qr)
             mode = QMANN_ATT_APPX;
             if (o->k != 1u + o->fa.iwl + o->fa.frac) return 0;               // lib/layer.c:230
             s.f_att[h] = o->fa; s.num_bit = o->k;
-            // the byte arithmetic of the batched kernels is exact only when the keys' grid lies inside the attention grid
-            if (s.f_w[h].iwl > o->fa.iwl || s.f_w[h].frac > o->fa.frac) return 0;
         } else if (o->fixed) {
             mode = QMANN_ATT_FIXED;
             s.f_att[h] = o->fa;
@@ -197,6 +195,11 @@ size_t match_query(const std::vector<Op> &ops, size_t i, Sig &s, Query &qr)
     if (s.att_mode != QMANN_ATT_FIXED && !s.has_lin) s.f_bin = s.f_att[0];   // (nothing reads it then)
     if (s.att_mode == QMANN_ATT_FLOAT)                                        // mode 1 memories carry the embedding grid
         for (uint32_t k = 0; k < h; k++) s.f_att[k] = s.f_w[k];
+    // the byte arithmetic of the batched mode-3 kernels carries the reference's operand words only for these grid combinations
+    // (EN_MQ's among them: qfmt.h::ham_hop_kind); anything else stays with the verbs, which work on the words themselves
+    if (s.att_mode == QMANN_ATT_APPX)
+        for (uint32_t k = 0; k < h; k++)
+            if (ham_hop_kind(k == 0 ? s.f_w[0] : s.f_act[k - 1], s.f_w[k], s.f_att[k]) == kHamNone) return 0;
     // ds_ans (float), output softmax, cross entropy of the valid / test phase
     o = at(j);
     if (!o || o->kind != kDense || o->fixed || o->act != 0 || o->in != u_att || o->c != s.D || o->r != s.V) return 0;

@@ -73,8 +73,7 @@ k_hops_ham(const HopArgs a, const uint32_t key_row_bytes, const uint32_t lds_slo
         const float uv = u_f[tid];
         ku[tid] = (short)((tid < D) ? qm_code_or_sign(uv, fb.iwl, fb.frac) : 0);
         const float ua = relu_if(uv, hop_relu(a, h));                    // what the attention reads
-        const int kc = (tid < D) ? qm_code(ua, fm.iwl, fm.frac) : 0;
-        const uint32_t ubyte = (uint32_t)(kc < 0 ? -kc : kc) | ((tid < D && !(ua >= 0.0f)) ? 0x80u : 0u);
+        const uint32_t ubyte = ham_ubyte(ua, fm, tid < D);
         ub[tid] = (uint8_t)ubyte;
         if (mode_is_planes(MODE)) {
 #pragma unroll
@@ -95,15 +94,20 @@ k_hops_ham(const HopArgs a, const uint32_t key_row_bytes, const uint32_t lds_slo
                 sc[r] = (score_t)v;
                 if (mode_is_v0(MODE)) atomicAdd(&v0_hist[v], 1u);
             };
-            if (MODE == kModeAppx) {
+            if (mode_is_appx(MODE)) {
                 scale = 1.0f / 1024.0f;                         // 2^-(n-1) . 2^ATTENTION_CONST_SCALE, n = 8
                 const int lim = 1 << (fm.iwl + 10);             // final Q(iwl, 31-iwl) clamps at +-2^iwl
                 AppxConst c;
                 make_appx_const(c, ub, (lane % LPRK) * 16, D);
-                auto row_sum = [&](const i32x4 x) { return appx_lane_sum(x, c); };
                 auto retire_c = [&](uint32_t r, int v) { sc[r] = (score_t)appx_clamp(v, lim); };
-                if (S >= (kWave / LPRK) * 4) scan_rows<LPRK, 4, true, kWaves>(kb, S, row_sum, retire_c, lane, wave);
-                else scan_rows_short<LPRK>(kb, S, row_sum, retire_c, lane, wave, kWaves);
+                auto run = [&](auto row_sum) {
+                    if (S >= (kWave / LPRK) * 4) scan_rows<LPRK, 4, true, kWaves>(kb, S, row_sum, retire_c, lane, wave);
+                    else scan_rows_short<LPRK>(kb, S, row_sum, retire_c, lane, wave, kWaves);
+                };
+                const uint32_t kind = MODE == kModeAppxMq ? ham_kind_of(a, h) : (uint32_t)kHamSame;     // (workgroup-uniform)
+                if (kind == kHamFine) run([&](const i32x4 x) { return appx_lane_sum_k<kHamFine>(x, c); });
+                else if (kind == kHamCoarse) run([&](const i32x4 x) { return appx_lane_sum_k<kHamCoarse>(x, c); });
+                else run([&](const i32x4 x) { return appx_lane_sum(x, c); });
             } else if (mode_is_planes(MODE)) {
                 if (MODE == kModeV1) scale = qm_scale_down(1.0f, NB);
                 PlaneConst c;
@@ -235,11 +239,6 @@ k_pack_planes(const uint8_t *__restrict__ sm, uint64_t *__restrict__ planes, siz
 
 inline bool fmt8(qmann_fmt f) { return f.iwl + f.frac >= 1 && f.iwl + f.frac <= 7; }
 
-// u (in format `src`) must be exactly representable on the attention grid Q(iwl.7-iwl) without
-// saturation -- otherwise its 8-bit code is not the reference's 32-bit word and the byte form
-// of the Hamming arithmetic would not be exact
-inline bool grid_within(qmann_fmt src, qmann_fmt att) { return src.iwl <= att.iwl && src.frac <= att.frac; }
-
 int fill_args(HopArgs &a, const qmann_net *net, const void *keys, const int8_t *vals, size_t key_hop_stride,
               size_t val_hop_stride, const uint32_t *row_off, const float *u0, float *u_out, const qmann_taps *taps)
 {
@@ -253,11 +252,18 @@ int fill_args(HopArgs &a, const qmann_net *net, const void *keys, const int8_t *
         if (!fmt8(net->act[h]) || !fmt8(net->w[h]) || !fmt8(net->att[h])) return QMANN_ERANGE;
         if (net->att[h].iwl + net->att[h].frac != 7 || net->att[h].iwl < 1) return QMANN_EUNSUPPORTED;
         if (net->en_lin_map && !net->lin_map[h]) return QMANN_EINVAL;
-        // u entering hop h comes from emb_q (format w[0]) or from sv[h-1] (format act[h-1])
-        const qmann_fmt src = h == 0 ? net->w[0] : net->act[h - 1];
-        if (!grid_within(src, net->att[h])) return QMANN_EUNSUPPORTED;
     }
     a = HopArgs{};
+    // Mode 3 does word arithmetic on its operands before it compares bits: a byte per operand carries that only for the grid
+    // combinations of qfmt.h::ham_hop_kind.  u entering hop h comes from emb_q (format w[0]) or from sv[h-1] (format act[h-1]);
+    // the keys of hop h lie on w[h].  (Modes 10 / 11 compare the words' top bits as they are: any grid.)
+    if (net->attention_mode == QMANN_ATT_APPX)
+        for (uint32_t h = 0; h < net->n_hop; h++) {
+            const qmann_fmt src = h == 0 ? net->w[0] : net->act[h - 1];
+            const int kind = ham_hop_kind(QFmt{src.iwl, src.frac}, QFmt{net->w[h].iwl, net->w[h].frac}, QFmt{net->att[h].iwl, net->att[h].frac});
+            if (kind == kHamNone) return QMANN_EUNSUPPORTED;
+            a.ham_kinds |= (uint32_t)kind << (2u * h);
+        }
     a.keys = (const int8_t *)keys; a.vals = vals; a.row_off = row_off;
     a.hop_stride = val_hop_stride; a.key_hop_stride = key_hop_stride;
     a.u0 = u0; a.u_out = u_out;
@@ -328,21 +334,21 @@ int qmann_hops_appx_impl(const qmann_net *net, const int8_t *keys, const int8_t 
     if (n_query == 0) return QMANN_OK;
     if (n_query >= (1u << 24)) return QMANN_ERANGE;      // one workgroup per query: a launch holds < 2^32 threads
     hipStream_t st = (hipStream_t)stream;
-    if (lean_supported(a, max_slots, 64)) {                 // hops_lean.h
-        launch_lean<kModeAppx, 8>(a, max_slots, n_query, st);
-        QM_LAUNCH_CHECK();
-        return qm_scope.rc();
-    }
-    if (max_slots <= (uint32_t)kWave) {                     // hops_small.h
-        if (net->dim_emb_pad == 64) k_hops_small<4, 4, kModeAppx, 8><<<n_query, kWave, 0, st>>>(a, 64);
-        else if (net->dim_emb_pad == 128) k_hops_small<8, 8, kModeAppx, 8><<<n_query, kWave, 0, st>>>(a, 128);
-        else k_hops_small<16, 16, kModeAppx, 8><<<n_query, kWave, 0, st>>>(a, 256);
-        QM_LAUNCH_CHECK();
-        return qm_scope.rc();
-    }
-    if (net->dim_emb_pad == 64) launch<4, 64, kModeAppx, 8>(a, 64, lds, max_slots, n_query, st);
-    else if (net->dim_emb_pad == 128) launch<8, 128, kModeAppx, 8>(a, 128, lds, max_slots, n_query, st);
-    else launch<16, 256, kModeAppx, 8>(a, 256, lds, max_slots, n_query, st);
+    const bool mq = a.ham_kinds != 0;                       // some hop's operands leave the attention grid (EN_MQ): the kernels
+                                                            // that carry all three lane sums (ham_common.h)
+#define QM_APPX(M)                                                                                                    \
+    do {                                                                                                              \
+        if (lean_supported(a, max_slots, 64)) launch_lean<M, 8>(a, max_slots, n_query, st);       /* hops_lean.h */   \
+        else if (max_slots <= (uint32_t)kWave) {                                                  /* hops_small.h */  \
+            if (net->dim_emb_pad == 64) k_hops_small<4, 4, M, 8><<<n_query, kWave, 0, st>>>(a, 64);                   \
+            else if (net->dim_emb_pad == 128) k_hops_small<8, 8, M, 8><<<n_query, kWave, 0, st>>>(a, 128);            \
+            else k_hops_small<16, 16, M, 8><<<n_query, kWave, 0, st>>>(a, 256);                                       \
+        } else if (net->dim_emb_pad == 64) launch<4, 64, M, 8>(a, 64, lds, max_slots, n_query, st);                   \
+        else if (net->dim_emb_pad == 128) launch<8, 128, M, 8>(a, 128, lds, max_slots, n_query, st);                  \
+        else launch<16, 256, M, 8>(a, 256, lds, max_slots, n_query, st);                                              \
+    } while (0)
+    if (mq) QM_APPX(kModeAppxMq); else QM_APPX(kModeAppx);
+#undef QM_APPX
     QM_LAUNCH_CHECK();
     return qm_scope.rc();
 }

@@ -577,10 +577,12 @@ k_answer_i8_combine(const AnsPart *__restrict__ part, const float *__restrict__ 
 constexpr int kMaxNnz = 64;
 
 // sign-magnitude byte of Q(f)(x): the top byte of the reference's FLOAT2FIXED word
-__device__ __forceinline__ int8_t sm_byte(float x, QFmt f)
+// (`mz`: see ew_to_bytes -- exactly -2^iwl is "minus zero" for the keys of a Hamming-family attention on a wider weight grid)
+__device__ __forceinline__ int8_t sm_byte(float x, QFmt f, bool mz = false)
 {
     const int k = qm_code(x, f.iwl, f.frac);
-    return (int8_t)((uint32_t)(k < 0 ? -k : k) | ((x >= 0.0f) ? 0u : 0x80u));
+    const uint32_t mag = (mz && x == -(float)(1u << f.iwl)) ? 0u : (uint32_t)(k < 0 ? -k : k);
+    return (int8_t)(mag | ((x >= 0.0f) ? 0u : 0x80u));
 }
 
 struct EmbedArgs {
@@ -591,7 +593,8 @@ struct EmbedArgs {
     int8_t *vals;
     size_t hop_stride;
     uint32_t n_hop, D, Dp, V, rows;
-    QFmt act[QMANN_MAX_HOP], w[QMANN_MAX_HOP], att[QMANN_MAX_HOP];
+    QFmt act[QMANN_MAX_HOP], w[QMANN_MAX_HOP], att[QMANN_MAX_HOP];   // att: the format of the KEY BYTES (fill_key_formats)
+    uint32_t key_mz;              // bit h: hop h's keys follow the minus-zero rule
     const uint32_t *row_list;     // optional: only these rows (device array; its length is read from *n_list)
     const uint32_t *n_list;
 };
@@ -642,7 +645,7 @@ k_embed_story(const EmbedArgs a)
                 }
                 const float ea = qm_quant(sa, fw.iwl, fw.frac);
                 const float ec = qm_quant(sc, fw.iwl, fw.frac);
-                kcode = sm_byte(ea, a.att[h]);
+                kcode = sm_byte(ea, a.att[h], (a.key_mz >> h) & 1u);
                 vcode = sm_byte(ec, a.act[h]);
             }
             a.keys[(size_t)h * a.hop_stride + s * a.Dp + j] = kcode;
@@ -763,7 +766,8 @@ struct EmbedIdxArgs {
     int8_t *vals;
     size_t hop_stride;
     uint32_t n_hop, D, Dp, V, rows, max_words, time_last;
-    QFmt act[QMANN_MAX_HOP], w[QMANN_MAX_HOP], att[QMANN_MAX_HOP];
+    QFmt act[QMANN_MAX_HOP], w[QMANN_MAX_HOP], att[QMANN_MAX_HOP];   // att: the format of the KEY BYTES (fill_key_formats)
+    uint32_t key_mz;              // bit h: hop h's keys follow the minus-zero rule
 };
 
 // integer count c >= 0 as a code of the format in units of 2^-frac: Qw(c), saturating at the format maximum
@@ -823,13 +827,20 @@ __device__ __forceinline__ uint32_t ew_pack_row(uint32_t w, uint32_t V, bool tim
 
 // Qw of the sum, then the memory byte: magnitude moved to the target grid (toward zero), clamped, sign bit from the
 // VALUE (a negative sum that truncates to zero is "minus zero")
-__device__ __forceinline__ uint32_t ew_to_bytes(s16x2 x, int maxw, QFmt fw, QFmt dst)
+// `mz`: the key bytes of a Hamming-family attention whose weight grid is wider than the attention grid -- a value of exactly
+// -2^iwl_att is "minus zero" in the reference's operand word (ham_common.h::ham_ubyte): magnitude 0, sign kept
+__device__ __forceinline__ uint32_t ew_to_bytes(s16x2 x, int maxw, QFmt fw, QFmt dst, bool mz = false)
 {
     const short mw = (short)maxw;
     x = __builtin_elementwise_min(__builtin_elementwise_max(x, s16x2{(short)-mw, (short)-mw}), s16x2{mw, mw});
     u16x2 mag = __builtin_bit_cast(u16x2, __builtin_elementwise_max(x, (s16x2)(-x)));
     mag = dst.frac >= fw.frac ? (u16x2)(mag << (unsigned short)(dst.frac - fw.frac)) : (u16x2)(mag >> (unsigned short)(fw.frac - dst.frac));
     const unsigned short md = (unsigned short)((1u << (dst.iwl + dst.frac)) - 1u);
+    if (mz) {
+        const unsigned short edge = (unsigned short)(md + 1u);
+        const u16x2 hit = __builtin_bit_cast(u16x2, (s16x2)(mag == u16x2{edge, edge})) & __builtin_bit_cast(u16x2, (s16x2)(x < s16x2{0, 0}));
+        mag = mag & ~hit;
+    }
     mag = __builtin_elementwise_min(mag, u16x2{md, md});
     const u16x2 sgn = __builtin_bit_cast(u16x2, (s16x2)(x >> 8)) & (unsigned short)0x0080;
     return __builtin_bit_cast(uint32_t, (u16x2)(mag | sgn));
@@ -930,7 +941,8 @@ k_embed_story_idx(const EmbedIdxArgs a)
                 for (int e = 0; e < 8; e++) { ae += xa_e[e]; ao += xa_o[e]; ce += xc_e[e]; co += xc_o[e]; }
             }
             if (row_ok) {
-                *(uint32_t *)(a.keys + (size_t)h * a.hop_stride + s * a.Dp + 4 * c4) = (ew_to_bytes(ae, maxw, fw, a.att[h]) | (ew_to_bytes(ao, maxw, fw, a.att[h]) << 8)) & colmask;
+                const bool kmz = (a.key_mz >> h) & 1u;
+                *(uint32_t *)(a.keys + (size_t)h * a.hop_stride + s * a.Dp + 4 * c4) = (ew_to_bytes(ae, maxw, fw, a.att[h], kmz) | (ew_to_bytes(ao, maxw, fw, a.att[h], kmz) << 8)) & colmask;
                 *(uint32_t *)(a.vals + (size_t)h * a.hop_stride + s * a.Dp + 4 * c4) = (ew_to_bytes(ce, maxw, fw, a.act[h]) | (ew_to_bytes(co, maxw, fw, a.act[h]) << 8)) & colmask;
             }
         }
@@ -991,6 +1003,7 @@ k_embed_story_mfma(const EmbedIdxArgs a)
     __syncthreads();
 
     const QFmt fw = a.w[h], f_att = a.att[h], f_act = a.act[h];
+    const bool kmz = (a.key_mz >> h) & 1u;
     const int maxw = (1 << (fw.iwl + fw.frac)) - 1;
     const uint32_t r4 = lane >> 2, qd = lane & 3u;                       // word phase: row r4 of the tile, slots 4 qd .. 4 qd + 3
     const uint32_t nrow = lane & 15u, kq = lane >> 4;                    // matrix phase: story row nrow, K bytes 16 kq .. / columns 4 kq ..
@@ -1110,7 +1123,7 @@ k_embed_story_mfma(const EmbedIdxArgs a)
                 const i32x4 v = acc[t][cb];                              // v[r]: story row nrow, column 16 cb + 4 kq + r
                 const s16x2 x01 = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm((uint32_t)v[1], (uint32_t)v[0], 0x05040100u));
                 const s16x2 x23 = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm((uint32_t)v[3], (uint32_t)v[2], 0x05040100u));
-                const uint32_t b01 = ew_to_bytes(x01, maxw, fw, dstf), b23 = ew_to_bytes(x23, maxw, fw, dstf);
+                const uint32_t b01 = ew_to_bytes(x01, maxw, fw, dstf, t == 0 && kmz), b23 = ew_to_bytes(x23, maxw, fw, dstf, t == 0 && kmz);
                 *(uint32_t *)(stage + nrow * SP + cb * 16u + kq * 4u) = __builtin_amdgcn_perm(b23, b01, 0x06040200u);
             }
             // a row whose repeated word leaves the format: its sums term by term, Qw(Qw(count) . kw) over the row's distinct
@@ -1129,7 +1142,7 @@ k_embed_story_mfma(const EmbedIdxArgs a)
                     }
                 }
                 __builtin_amdgcn_wave_barrier();                         // (every lane's dword of this row is written)
-                stage[r * SP + lane] = (uint8_t)ew_to_bytes(s16x2{(short)sum, (short)0}, maxw, fw, dstf);
+                stage[r * SP + lane] = (uint8_t)ew_to_bytes(s16x2{(short)sum, (short)0}, maxw, fw, dstf, t == 0 && kmz);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -1237,6 +1250,22 @@ __global__ void k_dequantize_transpose(const int8_t *__restrict__ src, float *__
 }
 
 inline bool fmt8(qmann_fmt f) { return f.iwl + f.frac >= 1 && f.iwl + f.frac <= 7; }
+
+// formats of a hop's memory bytes from the net: values on act[h]; keys on att[h] -- except mode 3 with a finer weight grid,
+// whose keys keep the weight grid (qfmt.h::ham_key_format) -- and the hops whose keys follow the minus-zero rule
+template <typename Args>
+static void fill_key_formats(Args &a, const qmann_net *net)
+{
+    a.key_mz = 0;
+    for (uint32_t h = 0; h < net->n_hop; h++) {
+        const qmann_fmt src = h == 0 ? net->w[0] : net->act[h - 1];
+        a.act[h] = QFmt{net->act[h].iwl, net->act[h].frac};
+        a.w[h] = QFmt{net->w[h].iwl, net->w[h].frac};
+        bool mz = false;
+        a.att[h] = ham_key_format(net->attention_mode, QFmt{src.iwl, src.frac}, a.w[h], QFmt{net->att[h].iwl, net->att[h].frac}, &mz);
+        if (mz) a.key_mz |= 1u << h;
+    }
+}
 
 }  // namespace
 
@@ -1369,10 +1398,8 @@ static int embed_story_impl(const qmann_net *net, const float *story, uint32_t r
         if (!w_a[h] || !w_c[h]) return QMANN_EINVAL;
         if (!fmt8(net->act[h]) || !fmt8(net->w[h]) || !fmt8(net->att[h])) return QMANN_ERANGE;
         a.w_a[h] = w_a[h]; a.w_c[h] = w_c[h];
-        a.act[h] = QFmt{net->act[h].iwl, net->act[h].frac};
-        a.w[h] = QFmt{net->w[h].iwl, net->w[h].frac};
-        a.att[h] = QFmt{net->att[h].iwl, net->att[h].frac};
     }
+    fill_key_formats(a, net);
     if (rows_total == 0) return QMANN_OK;
     // a listed launch does not know the list's length on the host: a fixed grid walks it (and leaves at once if it is empty)
     const uint32_t grid = row_list ? (rows_total < 4096u ? rows_total : 4096u) : (rows_total < (1u << 22) ? rows_total : (1u << 22));
@@ -1481,10 +1508,8 @@ int qmann_embed_story_idx(const qmann_net *net, const uint16_t *words, uint32_t 
         if (!t_a[h] || !t_c[h]) return QMANN_EINVAL;
         if (!fmt8(net->act[h]) || !fmt8(net->w[h]) || !fmt8(net->att[h])) return QMANN_ERANGE;
         a.t_a[h] = t_a[h]; a.t_c[h] = t_c[h];
-        a.act[h] = QFmt{net->act[h].iwl, net->act[h].frac};
-        a.w[h] = QFmt{net->w[h].iwl, net->w[h].frac};
-        a.att[h] = QFmt{net->att[h].iwl, net->att[h].frac};
     }
+    fill_key_formats(a, net);
     if (rows_total == 0) return QMANN_OK;
     if ((net->dim_emb_pad & 3u) || (hop_stride & 3u) || ((uintptr_t)keys & 3u) || ((uintptr_t)vals & 3u)) return QMANN_EINVAL;
     if (net->dim_emb_pad % 64 != 0) return QMANN_EUNSUPPORTED;          // 16 lanes x 4 columns per round

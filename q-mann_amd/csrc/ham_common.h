@@ -9,7 +9,10 @@ namespace {
 // kModeV0 / kModeV1 read packed bit planes; kModeV0Bytes / kModeV1Bytes compute the same scores straight from
 // the sign-magnitude int8 memories (no packing pass; the choice for short memories and for num_bit = 8, where
 // planes are no smaller than bytes).  3 = kModeFixed (hops_small.h).
-enum { kModeAppx = 0, kModeV0 = 1, kModeV1 = 2, kModeV0Bytes = 4, kModeV1Bytes = 5 };
+// kModeAppxMq: APPX whose hops differ in operand grids (mixed quantisation, see "APPX under EN_MQ" below); kModeAppx is the
+// same kernel with every hop of kind kHamSame compiled in.
+enum { kModeAppx = 0, kModeV0 = 1, kModeV1 = 2, kModeV0Bytes = 4, kModeV1Bytes = 5, kModeAppxMq = 6 };
+constexpr bool mode_is_appx(int m) { return m == kModeAppx || m == kModeAppxMq; }
 constexpr bool mode_is_v0(int m) { return m == kModeV0 || m == kModeV0Bytes; }
 constexpr bool mode_is_planes(int m) { return m == kModeV0 || m == kModeV1; }
 
@@ -30,33 +33,72 @@ struct AppxConst {
     int bias;         // 127 . (16 - padding columns of this lane): the same-sign terms' constant part
 };
 
-// 12 VALU operations per 4 columns in the compiled loop (the boolean pairs fuse into v_bitop3_b32; round 1: 15 + 2 per row,
-// round 2: 13).  Padding columns are forced to "same sign, both magnitudes 0" by the masks (a term of exactly 127), which
-// `bias` leaves out.
-__device__ __forceinline__ int appx_lane_sum(const i32x4 x, const AppxConst &c)
+// APPX under EN_MQ (mixed quantisation, MemN2N/MemN2N.c:748-754: weight formats Q(iwl+1.frac-1), Q(iwl.frac), Q(iwl-1.frac+1)
+// for hops 0, 1, 2 while the attention format stays Q(iwl.frac)).  The reference re-encodes both operands of a column as
+// Q(iwl_att, 31 - iwl_att) sign-magnitude WORDS (lib/layer_cuda.cu:355-420) and only bits 30..24 of the adjusted words are
+// compared, but the adjustment (common magnitude removed / moved onto the larger operand) runs on all 31 bits.  What a byte per
+// operand can carry exactly, by the hop's KIND (qfmt.h::ham_hop_kind):
+//   kHamSame    both operand grids lie inside the attention grid: the word is byte << 24 (the case of the rounds before).
+//   kHamCoarse  both grids are at least one fractional bit coarser, wider range: on-grid codes are even, so the odd code 127 is
+//               free and stands for the SATURATED word 0x7FFFFFFF (Q_att clamps to 127 by itself).  Its low 24 ones never
+//               matter -- same sign: 0x7FFFFFFF - (b << 24) has top bits 127 - b; opposite: + (b << 24) carries nothing up --
+//               except when BOTH operands are saturated with opposite signs: 0x7FFFFFFF + 0x7FFFFFFF = 0xFFFFFFFE, top bits
+//               carry + 127 where 127 + 127 gives carry + 126.  `km & um & 1` is that case (every other code is even).
+//   kHamFine    the key grid is one fractional bit finer and at least one integer bit narrower; u lies inside the attention
+//               grid.  The key byte is the key's OWN code k8 (units 2^-(frac+1), <= 127), u's word is (2 u7) << 23:
+//                 opposite sign  top bits of k8 + 2 u7 are (k8 >> 1) + u7, carry and comparison likewise: the byte
+//                                arithmetic on kh = k8 >> 1;
+//                 same sign      |k8 - 2 u7| >> 1 = |kh - u7| - [k8 odd and kh < u7].
+// A value of exactly -2^iwl_att (reachable on a wider grid only) is "minus zero" in the reference's word: byte 0x80
+// (ham_ubyte below; the embedding kernels' key bytes follow the same rule).
+__device__ __forceinline__ uint32_t ham_kind_of(const HopArgs &a, uint32_t h) { return (a.ham_kinds >> (2u * h)) & 3u; }
+
+// operations per 4 columns in the compiled loop: kHamSame 12 (the boolean pairs fuse into v_bitop3_b32; round 1: 15 + 2 per
+// row, round 2: 13), kHamCoarse 13, kHamFine 17.  Padding columns are forced to "same sign, both magnitudes 0" by the masks
+// (a term of exactly 127), which `bias` leaves out.
+template <int KIND>
+__device__ __forceinline__ int appx_lane_sum_k(const i32x4 x, const AppxConst &c)
 {
     int dot = 0;
-    uint32_t sad = 0;
+    uint32_t sad = 0, fix = 0;
 #pragma unroll
     for (int d = 0; d < 4; d++) {
         const uint32_t w = (uint32_t)x[d];
-        const uint32_t km = w & c.m7[d];
+        const uint32_t km = KIND == kHamFine ? ((w >> 1) & ((c.m7[d] >> 1) & 0x3F3F3F3Fu)) : (w & c.m7[d]);
         const uint32_t sd = (w ^ c.us[d]) & c.m8[d];                        // signs differ
         const uint32_t dmask = __builtin_amdgcn_perm(0u, 0u, sd);           // 0xFF in those bytes
         // same sign: 127 - |ka - kb|; `bias` holds a 127 for every real column.  Where the signs differ the key byte is
         // replaced by |u| + 127: a difference of exactly 127, which gives that column's 127 back inside the same v_sad_u8
         // (round 2 spent a v_dot4 on counting those columns)
         sad = __builtin_amdgcn_sad_u8((km & ~dmask) | (c.u127[d] & dmask), c.um[d], sad);
-        // opposite sign: +-(127 - ((ka + kb) & 127)); per byte ka + kb <= 254, no carry across bytes
-        const uint32_t s4 = km + c.um[d];                                   // bit 7 of a byte = carry out of 7 bits
+        // opposite sign: +-(127 - ((ka + kb) & 127)); per byte ka + kb <= 254 (+ 1 for two saturated operands), no carry across bytes
+        const uint32_t s4 = KIND == kHamCoarse ? km + c.um[d] + (km & c.um[d] & 0x01010101u) : km + c.um[d];   // bit 7 of a byte = carry out of 7 bits
         const uint32_t val = ~s4 & (dmask & 0x7F7F7F7Fu);
         const uint32_t ge = km + c.nb[d];                                   // bit 7: |k| + 128 - |u| >= 128, i.e. |k| >= |u| (<= 255: no carry)
         const uint32_t lneg = (w & ge) | (c.us[d] & ~ge);                   // bit 7: sign of the larger operand
         const uint32_t neg = ((s4 & lneg) | ~s4) & 0x80808080u;             // negative unless carry and larger > 0
         const uint32_t sg = __builtin_amdgcn_perm(0x01010101u, 0x01010101u, neg);
         dot = __builtin_amdgcn_sdot4((int)val, (int)sg, dot, false);
+        if (KIND == kHamFine) {
+            // same sign, odd key code, kh < u7: the halved difference is one less than |kh - u7| (128 per such column)
+            const uint32_t odd7 = (w << 7) & c.m8[d];                       // bit 7 of a byte = bit 0 of that key byte
+            fix = __builtin_amdgcn_sad_u8(odd7 & ~ge & ~sd, 0u, fix);
+        }
     }
-    return dot + c.bias - (int)sad;
+    return dot + c.bias - (int)sad + (int)(fix >> 7);
+}
+__device__ __forceinline__ int appx_lane_sum(const i32x4 x, const AppxConst &c) { return appx_lane_sum_k<kHamSame>(x, c); }
+
+// sign-magnitude byte of the attention operand u of a Hamming-family mode: magnitude Q_att (clamped at 127, truncated toward
+// zero), sign from the VALUE; exactly -2^iwl is the reference's "minus zero" (its operand word is Q(iwl, 31 - iwl):
+// lib/layer_cuda.h:233-253 -- the value is not below the macro's float limit, converts to INT32_MIN, whose sign-magnitude
+// word has magnitude 0).  Only reachable when u's own grid is wider than the attention grid.
+__device__ __forceinline__ uint32_t ham_ubyte(float ua, QFmt fm, bool real)
+{
+    if (!real) return 0u;
+    const int kc = qm_code(ua, fm.iwl, fm.frac);
+    const uint32_t mag = ua == -(float)(1u << fm.iwl) ? 0u : (uint32_t)(kc < 0 ? -kc : kc);
+    return mag | (!(ua >= 0.0f) ? 0x80u : 0u);
 }
 
 // Final quantisation of a mode-3 score, Q(iwl, 31-iwl) (lib/layer_cuda.cu:2515): saturation at +-2^iwl -- except that a sum of

@@ -30,6 +30,7 @@ struct HopArgs {
     uint32_t softmax_shift, en_att_scale;     // in-hop softmax variants (qmann_net)
     uint32_t en_non_lin;                      // EN_NON_LINEARITY: see hop_relu() below
     float att_scale[QMANN_MAX_HOP];
+    uint32_t ham_kinds;      // mode 3 under mixed quantisation: 2 bits per hop, kHamSame / kHamCoarse / kHamFine (ham_common.h)
 };
 }  // namespace qmann
 using qmann::HopArgs;

@@ -258,8 +258,7 @@ __device__ __forceinline__ void lean_hop(const HopArgs &a, const LeanArgs &la, u
         publish_const<W7>(lw, lane, ka, wl_m, (int)fb.frac);
     } else {
         const float ua = relu_if(u, relu);
-        const int kc = (lane < D) ? qm_code(ua, fm.iwl, fm.frac) : 0;
-        lw[kLwUb + lane] = (uint8_t)((uint32_t)(kc < 0 ? -kc : kc) | ((lane < D && !(ua >= 0.0f)) ? 0x80u : 0u));
+        lw[kLwUb + lane] = (uint8_t)ham_ubyte(ua, fm, lane < D);
     }
     wave_sync();
 
@@ -280,11 +279,15 @@ __device__ __forceinline__ void lean_hop(const HopArgs &a, const LeanArgs &la, u
         unit = qm_scale_down(1.0f, fm.frac);
         csh = fetch_scan_const(csc, lw, chunk, wl_m);
         scan([&](const i32x4 x) { return lane_sum_w<W7>(x, csc, csh); }, (1 << wl_m) - 1);
-    } else if (MODE == kModeAppx) {
+    } else if (mode_is_appx(MODE)) {
         unit = 1.0f / 1024.0f;
         AppxConst c;
         make_appx_const(c, lw + kLwUb, chunk * 16, D);
-        scan([&](const i32x4 x) { return appx_lane_sum(x, c); }, 1 << (fm.iwl + 10), true);
+        const int lim = 1 << (fm.iwl + 10);
+        const uint32_t kind = MODE == kModeAppxMq ? ham_kind_of(a, h) : (uint32_t)kHamSame;             // (wavefront-uniform)
+        if (kind == kHamFine) scan([&](const i32x4 x) { return appx_lane_sum_k<kHamFine>(x, c); }, lim, true);
+        else if (kind == kHamCoarse) scan([&](const i32x4 x) { return appx_lane_sum_k<kHamCoarse>(x, c); }, lim, true);
+        else scan([&](const i32x4 x) { return appx_lane_sum(x, c); }, lim, true);
     } else {
         if (MODE == kModeV1Bytes) unit = qm_scale_down(1.0f, NB);
         HamByteConst c;

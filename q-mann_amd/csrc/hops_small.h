@@ -80,8 +80,7 @@ k_hops_small(const HopArgs a, const uint32_t key_row_bytes)
             ku[c] = (short)((c < D) ? qm_code_or_sign(uv, fb.iwl, fb.frac) : 0);
             if (MODE != kModeFixed) {
                 const float ua = relu_if(uv, hop_relu(a, h));            // what the attention reads
-                const int kc = (c < D) ? qm_code(ua, fm.iwl, fm.frac) : 0;
-                const uint32_t ubyte = (uint32_t)(kc < 0 ? -kc : kc) | ((c < D && !(ua >= 0.0f)) ? 0x80u : 0u);
+                const uint32_t ubyte = ham_ubyte(ua, fm, c < D);
                 ub[c] = (uint8_t)ubyte;
                 if (mode_is_planes(MODE)) {
 #pragma unroll
@@ -124,11 +123,15 @@ k_hops_small(const HopArgs a, const uint32_t key_row_bytes)
                 unit = qm_scale_down(1.0f, fm.frac);
                 csh = make_scan_const(csc, ku, chunkk * 16, fm.iwl + fm.frac, (int)fb.frac, hop_relu(a, h), fb.iwl + fb.frac == 0);
                 scan([&](const i32x4 x) { return lane_row_sum(x, csc, csh); }, (1 << (fm.iwl + fm.frac)) - 1);   // Qm, lib/layer_cuda.cu:135
-            } else if (MODE == kModeAppx) {
+            } else if (mode_is_appx(MODE)) {
                 unit = 1.0f / 1024.0f;                          // 2^-(n-1) . 2^ATTENTION_CONST_SCALE, n = 8
                 AppxConst c;
                 make_appx_const(c, ub, chunkk * 16, D);
-                scan([&](const i32x4 x) { return appx_lane_sum(x, c); }, 1 << (fm.iwl + 10), true);  // Q(iwl, 31-iwl) clamps at +-2^iwl
+                const int lim = 1 << (fm.iwl + 10);             // Q(iwl, 31-iwl) clamps at +-2^iwl
+                const uint32_t kind = MODE == kModeAppxMq ? ham_kind_of(a, h) : (uint32_t)kHamSame;     // (wavefront-uniform)
+                if (kind == kHamFine) scan([&](const i32x4 x) { return appx_lane_sum_k<kHamFine>(x, c); }, lim, true);
+                else if (kind == kHamCoarse) scan([&](const i32x4 x) { return appx_lane_sum_k<kHamCoarse>(x, c); }, lim, true);
+                else scan([&](const i32x4 x) { return appx_lane_sum(x, c); }, lim, true);
             } else if (mode_is_planes(MODE)) {
                 if (MODE == kModeV1) unit = qm_scale_down(1.0f, NB);
                 PlaneConst c;

@@ -88,3 +88,32 @@ QM_HD int32_t qm_mul_code(int32_t ka, int32_t kb, uint32_t frac_b, int32_t max_a
     int32_t t = (p + ((p >> 31) & ((1 << frac_b) - 1))) >> frac_b;
     return t > max_a ? max_a : (t < -max_a ? -max_a : t);
 }
+
+// ---- operands of the Hamming-family attentions under mixed quantisation (host side; the arithmetic: ham_common.h) ---------
+// The reference hands these attentions the embedding outputs on the WEIGHT grid of their hop (EN_MQ: Q(iwl+1.frac-1),
+// Q(iwl.frac), Q(iwl-1.frac+1) for hops 0, 1, 2; MemN2N/MemN2N.c:748-754) and re-encodes them as Q(iwl_att, 31 - iwl_att)
+// words (lib/layer_cuda.cu:355-420, :2515; lib/common.c:223-312 on the same alignment).  Modes 10 / 11 compare the top bits of
+// those words as they are: one byte per operand carries them for ANY grid (Q_att truncation, clamp, sign of the value, minus
+// zero at -2^iwl_att).  Mode 3 first does arithmetic on the whole words: what a byte can carry is classified per hop.
+enum { kHamSame = 0, kHamCoarse = 1, kHamFine = 2, kHamNone = 3 };
+
+// src: the grid of u entering the hop (w[0] for hop 0, act[h-1] after); wk: the grid of the hop's keys (w[h]); att: the
+// attention format (word length 8)
+static inline int ham_hop_kind(QFmt src, QFmt wk, QFmt att)
+{
+    const bool u_in = src.iwl <= att.iwl && src.frac <= att.frac, k_in = wk.iwl <= att.iwl && wk.frac <= att.frac;
+    if (u_in && k_in) return kHamSame;
+    if (src.frac + 1 <= att.frac && wk.frac + 1 <= att.frac) return kHamCoarse;      // odd codes free: 127 marks the saturated word
+    if (u_in && wk.frac == att.frac + 1 && wk.iwl + 1 <= att.iwl) return kHamFine;
+    return kHamNone;
+}
+
+// the format of a hop's KEY BYTES (what the embedding kernels quantise to) and whether the minus-zero rule applies to them
+// (a key of exactly -2^iwl_att: only on a wider grid).  mode: QMANN_ATT_* (3 = APPX, 10 / 11 = Hamming V0 / V1)
+static inline QFmt ham_key_format(uint32_t mode, QFmt src, QFmt wk, QFmt att, bool *minus_zero)
+{
+    const bool ham = mode == 3u || mode == 10u || mode == 11u;
+    *minus_zero = ham && wk.iwl > att.iwl;
+    if (mode == 3u && ham_hop_kind(src, wk, att) == kHamFine) return wk;
+    return att;
+}

@@ -227,14 +227,45 @@ def test_babi_end_to_end_from_bag_of_words(env, oracle, gold):
 # ---------------------------------------------------------------------------------------------
 # Hamming family
 # ---------------------------------------------------------------------------------------------
-def run_hamming_case(env, oracle, mode, D, S_list, B, seed, iwl=5, num_bit=8, sigma=40.0, extra=None, from_bytes=False):
-    """mode 3 (CUDA approximate attention, int8 keys) or 10 / 11 (packed bit planes + popcount)."""
+def ham_hop_kind(src, wk, att):
+    """csrc/qfmt.h::ham_hop_kind -- what a byte per operand can carry of mode 3's word arithmetic"""
+    u_in = src[0] <= att[0] and src[1] <= att[1]
+    k_in = wk[0] <= att[0] and wk[1] <= att[1]
+    if u_in and k_in:
+        return "same"
+    if src[1] + 1 <= att[1] and wk[1] + 1 <= att[1]:
+        return "coarse"
+    if u_in and wk[1] == att[1] + 1 and wk[0] + 1 <= att[0]:
+        return "fine"
+    return None
+
+
+def ham_key_bytes(values, mode, kind, wk, att):
+    """The key BYTES of a Hamming-family attention for float keys on the weight grid `wk` (what the embedding kernels store):
+    sign from the value | magnitude on the attention grid, truncated toward zero and clamped at 127 -- the top byte of the
+    reference's Q(iwl_att, 31 - iwl_att) operand word (a saturated word reads 127 there) --, exactly -2^iwl_att is the word's
+    "minus zero", and mode 3 on a finer key grid keeps the key's own code (ham_common.h)."""
+    v = values.astype(np.float64)
+    if mode == 3 and kind == "fine":
+        mag = np.minimum(np.floor(np.abs(v) * (1 << wk[1])), 127)
+    else:
+        mag = np.minimum(np.floor(np.abs(v) * (1 << att[1])), 127)
+        mag[v == -float(1 << att[0])] = 0
+    return (mag.astype(np.uint8) | np.where(v < 0, 0x80, 0).astype(np.uint8)).view(np.int8)
+
+
+def run_hamming_case(env, oracle, mode, D, S_list, B, seed, iwl=5, num_bit=8, sigma=40.0, extra=None, from_bytes=False, mq=False):
+    """mode 3 (CUDA approximate attention, int8 keys) or 10 / 11 (packed bit planes + popcount).
+    mq: EN_MQ weight formats -- the keys are floats on the weight grid of their hop, u0 on hop 0's, saturating and
+    minus-zero values among them; the bytes follow ham_key_bytes, the oracle gets the floats."""
     torch, model = env.torch, env.model
     H, V = 3, 40
     frac = 7 - iwl
     fmt = [(iwl, frac)] * H
     cfg = dict(n_hop=H, dim_emb=D, dim_input=V, attention_mode=mode, softmax_variant=0, f_fixed=True,
                en_lin_map=True, fmt=fmt, fmt_w=list(fmt), fmt_att=list(fmt), fmt_bin=(iwl, frac), num_bit=num_bit)
+    if mq:
+        cfg["fmt_w"] = [(iwl + 1, frac - 1), (iwl, frac), (iwl - 1, frac + 1)]
     cfg.update(extra or {})
     rng = np.random.default_rng(seed)
     wts = weights(seed, H, D, V, 1.0, with_emb=False)
@@ -256,7 +287,28 @@ def run_hamming_case(env, oracle, mode, D, S_list, B, seed, iwl=5, num_bit=8, si
     m0 = (1 << sum(w0)) - 1
     u0 = (np.clip(np.rint(rng.normal(0, sigma, (B, D))), -m0, m0) / (1 << w0[1])).astype(np.float32)
     u0[:, ::7] = np.float32(m0 / (1 << w0[1])) * np.sign(u0[:, ::7] + 0.1)
-    dk = torch.from_numpy(model.to_signmag(keys)).to(env.dev)
+    key_floats = [keys[h].astype(np.float32) / (1 << cfg["fmt_att"][h][1]) for h in range(H)]
+    key_bytes = model.to_signmag(keys)
+    if mq:
+        edge = np.float32(1 << iwl)                  # 2^iwl_att: +edge saturates the operand word, -edge is its minus zero
+        u0[:, 3::11] = -edge; u0[:, 5::13] = edge; u0[:, 6::17] = -edge - np.float32(0.5)
+        key_bytes = np.zeros((H, R, Dp), np.int8)
+        for h in range(H):
+            wk, att = cfg["fmt_w"][h], cfg["fmt_att"][h]
+            mk = (1 << sum(wk)) - 1
+            kf = np.zeros((R, Dp), np.float32)
+            kf[:, :D] = np.clip(np.rint(rng.normal(0, sigma, (R, D))), -mk, mk) / np.float32(1 << wk[1])
+            kf[::3, : D // 2] = np.clip(kf[::3, : D // 2] * 3, -mk / (1 << wk[1]), mk / (1 << wk[1]))
+            kf[1::5, :D:4] = 0
+            if wk[0] > att[0]:
+                kf[2::7, 1:D:5] = -edge; kf[4::9, 2:D:6] = edge; kf[::4, 3:D:9] = np.float32(mk / (1 << wk[1]))
+            key_floats[h] = kf
+            src = cfg["fmt_w"][0] if h == 0 else cfg["fmt"][h - 1]
+            kind = ham_hop_kind(src, wk, att)
+            assert kind is not None
+            key_bytes[h] = ham_key_bytes(kf, mode, kind, wk, att)
+            key_bytes[h, :, D:] = 0
+    dk = torch.from_numpy(key_bytes).to(env.dev)
     dv = torch.from_numpy(model.to_signmag(vals)).to(env.dev)
     dro = torch.from_numpy(row_off).to(env.dev); du0 = torch.from_numpy(u0).to(env.dev)
     if mode == 3:
@@ -276,7 +328,7 @@ def run_hamming_case(env, oracle, mode, D, S_list, B, seed, iwl=5, num_bit=8, si
     excused = 0
     for q in range(B):
         a, b = int(row_off[q]), int(row_off[q + 1])
-        kf = np.stack([keys[h, a:b, :D].astype(np.float32) / (1 << cfg["fmt_att"][h][1]) for h in range(H)])
+        kf = np.stack([key_floats[h][a:b, :D] for h in range(H)])
         vf = np.stack([vals[h, a:b, :D].astype(np.float32) / (1 << cfg["fmt"][h][1]) for h in range(H)])
         _, t = oracle.forward_mem(m, kf, vf, u0[q])
         ok = True
@@ -303,6 +355,45 @@ def test_hops_appx_cuda_hamming_bit_exact(env, oracle, D):
 def test_hops_appx_other_iwl_and_full_size(env, oracle):
     run_hamming_case(env, oracle, 3, 128, [10, 50], B=6, seed=5, iwl=2)
     run_hamming_case(env, oracle, 3, 128, [10000, 4097], B=3, seed=6, sigma=25.0)
+
+
+@pytest.mark.parametrize("iwl", [5, 3])
+@pytest.mark.parametrize("D,S_list", [(60, [1, 5, 10, 33, 50, 64]), (128, [2, 17, 64]), (256, [9, 40]),          # lean / one-wavefront kernels
+                                      (60, [65, 200, 700]), (128, [70, 300]), (256, [130, 1000])])               # streaming kernel
+def test_hops_appx_under_mixed_quantisation(env, oracle, D, S_list, iwl):
+    """mode 3 with EN_MQ's weight formats (the stock define.h once ATTENTION_MODE is 3): hop 0 coarse with saturated and
+    minus-zero operands, hop 1 on the attention grid, hop 2 with keys one bit finer -- scores bit-exact against the oracle's
+    32-bit word arithmetic in every kernel that carries mode 3"""
+    run_hamming_case(env, oracle, 3, D, S_list, B=12, seed=77 + D + iwl, iwl=iwl, mq=True)
+
+
+@pytest.mark.parametrize("mode,num_bit", [(10, 8), (10, 2), (11, 8), (11, 4)])
+@pytest.mark.parametrize("D,S_list", [(60, [3, 50, 64]), (128, [20, 64]), (128, [65, 300]), (256, [130, 500])])
+@pytest.mark.parametrize("from_bytes", [True, False])
+def test_hops_hamming_v0_v1_under_mixed_quantisation(env, oracle, mode, num_bit, D, S_list, from_bytes):
+    """modes 10 / 11 compare the top bits of the operand words as they are: any operand grid, given the byte rule"""
+    if not from_bytes and D == 60 and num_bit == 1:
+        pytest.skip("a single plane of 64 columns is under 16 bytes")
+    run_hamming_case(env, oracle, mode, D, S_list, B=10, seed=5 + D + num_bit, num_bit=num_bit, mq=True, from_bytes=from_bytes)
+
+
+def test_appx_operand_grids_a_byte_cannot_carry_are_refused(env):
+    """u on a coarser, wider grid while the keys sit on the attention grid itself (code 127 would be both a value and the
+    saturation mark), or keys two bits finer: QMANN_EUNSUPPORTED, as before round 3 for every grid outside the attention's"""
+    torch, model = env.torch, env.model
+    from qmann_amd import abi
+    H, D, V = 3, 60, 40
+    att = [(5, 2)] * H
+    for fmt, fmt_w in (([(6, 1), (5, 2), (5, 2)], att),                 # hop 1: u (an sv[0] output) coarse, keys on the attention grid
+                       (att, [(5, 2), (5, 2), (3, 4)])):                # hop 2: keys two bits finer
+        cfg = dict(n_hop=H, dim_emb=D, dim_input=V, attention_mode=3, softmax_variant=0, f_fixed=True, en_lin_map=True,
+                   fmt=list(fmt), fmt_w=list(fmt_w), fmt_att=list(att), fmt_bin=(5, 2), num_bit=8)
+        net = model.QNet(cfg, weights(3, H, D, V, 1.0, with_emb=False), device="cuda:0")
+        k = torch.zeros((H, 4, net.Dp), dtype=torch.int8, device=env.dev)
+        ro = torch.tensor([0, 4], dtype=torch.int32, device=env.dev)
+        u0 = torch.zeros((1, D), device=env.dev)
+        with pytest.raises(RuntimeError, match=f"code {abi.QMANN_EUNSUPPORTED}"):
+            net.hops(k, k.clone(), ro, 4, u0)
 
 
 @pytest.mark.parametrize("mode", [10, 11])
@@ -778,16 +869,31 @@ def test_host_model_forward_equals_oracle(env, oracle, gold, name, mode, num_bit
     """qmann_model_forward_words / _bow (C++ orchestration inside the library) on the reference's own
     bag-of-words vectorisation of real bAbI stories, every attention mode, against the oracle's composite
     forward: final hop state exact (fixed-point modes), predictions equal, match / cost bookkeeping."""
+    iwl = 2 if mode in (2, 1) else 5
+    host_model_vs_oracle(env, oracle, gold, name, mode, num_bit, iwl, mode in (2, 1), 0.8 if iwl == 2 else 4.0)
+
+
+@pytest.mark.parametrize("sigma", [4.0, 14.0])
+@pytest.mark.parametrize("mode,num_bit,iwl", [(3, 8, 5), (3, 8, 4), (3, 8, 2), (10, 8, 5), (10, 2, 5), (11, 8, 5), (11, 4, 3)])
+@pytest.mark.parametrize("name", ["babi_qa1_test64.npz", "babi_qa3_test16.npz"])
+def test_host_model_hamming_attention_under_mixed_quantisation(env, oracle, gold, name, mode, num_bit, iwl, sigma):
+    """EN_MQ (MemN2N.c:748-754, the stock define.h) with the Hamming-family attentions: hop 0's operands lie on a wider,
+    coarser grid than the attention's (they saturate in the reference's Q(iwl, 31 - iwl) operand words: sigma 14 makes a
+    few per cent of the embedding sums do so), hop 2's keys on a finer one.  The oracle works on the words as the reference does;
+    the kernels carry one byte per operand (ham_common.h: kHamCoarse / kHamFine)."""
+    host_model_vs_oracle(env, oracle, gold, name, mode, num_bit, iwl, True, sigma)
+
+
+def host_model_vs_oracle(env, oracle, gold, name, mode, num_bit, iwl, en_mq, sigma):
     torch, model = env.torch, env.model
     b = gold(name)
     V, dd = int(b["dim_input"]), int(b["dim_dict"])
     story = b["story"].astype(np.float32); ques = b["question"].astype(np.float32)
     n_sen = b["n_sen"].astype(np.int64)
     ans = b["answer"].argmax(1).astype(np.int32)
-    iwl = 2 if mode in (2, 1) else 5               # Hamming forms need u grids inside the attention grid
-    cfg = model.babi_cfg(V, mode, 0, iwl=iwl, en_mq=(mode in (2, 1)))
+    cfg = model.babi_cfg(V, mode, 0, iwl=iwl, en_mq=en_mq)
     cfg["num_bit"] = num_bit
-    wts = weights(1000 + mode, 3, 60, V, 0.8 if iwl == 2 else 4.0)
+    wts = weights(1000 + mode, 3, 60, V, sigma)
     row_off = np.concatenate([[0], np.cumsum(n_sen)]).astype(np.int32)
     hm = model.HostModel(cfg, wts)
     d_ro = torch.from_numpy(row_off).to(env.dev); d_ans = torch.from_numpy(ans).to(env.dev)
@@ -1083,9 +1189,15 @@ def test_hops_hamming_random_formats(env, oracle, seed):
         wl = int(rng.integers(2, 8)); i = int(rng.integers(0, wl + 1))
         return (i, wl - i)
     H = 3
-    extra = dict(fmt=[inside() for _ in range(H)], fmt_w=[inside()] + [free() for _ in range(H - 1)],
-                 fmt_att=[att] * H, fmt_bin=free(), en_lin_map=bool(rng.integers(0, 5)))
     mode = [3, 10, 11][seed % 3]
+
+    def key_grid():
+        # mode 3 reads the keys' grid off w[h] (qfmt.h::ham_hop_kind; the mixed-quantisation cases have their own tests);
+        # here the keys are codes of the attention grid, so for mode 3 w[h] lies inside it
+        wf = free()
+        return inside() if (mode == 3 and not (wf[0] <= ia and wf[1] <= 7 - ia)) else wf
+    extra = dict(fmt=[inside() for _ in range(H)], fmt_w=[inside()] + [key_grid() for _ in range(H - 1)],
+                 fmt_att=[att] * H, fmt_bin=free(), en_lin_map=bool(rng.integers(0, 5)))
     nb = int(rng.choice([1, 2, 4, 8]))
     D = int(rng.choice([60, 128, 256]))
     S_list = [1, 5, 33, 64] if seed % 2 else [70, 300]

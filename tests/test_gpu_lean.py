@@ -77,6 +77,15 @@ def test_lean_equals_general_all_modes(env, mode, nb, D):
     both_paths(env, cfg_of(mode, D=D, nb=nb), B=300, S_list=[0, 1, 2, 3, 9, 10, 16, 17, 33, 50, 63, 64], seed=100 + mode * 7 + D)
 
 
+@pytest.mark.parametrize("mode,nb", [(3, 8), (10, 8), (11, 4)])
+@pytest.mark.parametrize("iwl", [5, 3])
+def test_lean_equals_general_hamming_under_mixed_quantisation(env, mode, nb, iwl):
+    """EN_MQ weight formats: mode 3 runs its three lane sums (kHamCoarse, kHamSame, kHamFine: ham_common.h), one per hop"""
+    frac = 7 - iwl
+    c = cfg_of(mode, iwl=iwl, nb=nb, fmt_w=[(iwl + 1, frac - 1), (iwl, frac), (iwl - 1, frac + 1)])
+    both_paths(env, c, B=300, S_list=[0, 1, 2, 9, 10, 17, 33, 50, 64], seed=900 + mode + iwl, sigma_u=40.0)
+
+
 @pytest.mark.parametrize("iwl", [2, 3, 6])
 @pytest.mark.parametrize("mode", [2, 3, 11])
 def test_lean_other_word_splits(env, mode, iwl):

@@ -27,7 +27,7 @@ HOST_MODES = [("each", "0"), ("each", "1"), ("loop", "1"), ("loop", "verify")]
 
 
 @pytest.mark.parametrize("host,defer", HOST_MODES)
-@pytest.mark.parametrize("att_mode,iwl,en_mq", [(2, 2, 1), (2, 2, 0), (3, 2, 0), (2, 5, 1)])
+@pytest.mark.parametrize("att_mode,iwl,en_mq", [(2, 2, 1), (2, 2, 0), (3, 2, 0), (2, 5, 1), (3, 2, 1), (3, 5, 1)])
 def test_reference_layer_api_drives_our_library(oracle, gold, tmp_path, att_mode, iwl, en_mq, host, defer):
     if not BIN.exists():
         pytest.skip("oracle/_ref/ref_host_infer not built (needs /root/reference at build time)")
@@ -113,11 +113,12 @@ def test_reference_layer_api_drives_our_library(oracle, gold, tmp_path, att_mode
 
 # (binary, attention mode it prints, required drop of the training error, cap on the test error)
 # last column: does the validation / test phase of this build go through the batched forward (deferred queue)?
-#   mode3 with EN_MQ: no -- the embedding grids (Q6.1 / Q4.3) do not lie inside the Hamming attention's grid (Q5.2), the
-#   byte arithmetic of the batched kernels cannot carry them; cfg1: no -- EN_FIXED_POINT false, nothing is quantised
+#   mode3 (the stock define.h with ATTENTION_MODE 3, EN_MQ on): yes since round 3 -- its embedding grids (Q6.1 / Q4.3) do not
+#   lie inside the Hamming attention's grid (Q5.2), the batched kernels carry them as kHamCoarse / kHamFine bytes (ham_common.h);
+#   cfg1: no -- EN_FIXED_POINT false, nothing is quantised
 @pytest.mark.parametrize("binary,mode_name,drop,cap,batched", [
     ("MemN2N_ref", "quantized", 0.2, 0.75, True),
-    ("MemN2N_ref_mode3", "approximate", 0.1, 0.95, False),
+    ("MemN2N_ref_mode3", "approximate", 0.1, 0.95, True),
     ("MemN2N_ref_cfg1", "normal", 0.2, 0.75, False),   # BASELINE config 1: float dot attention, no fixed point, one hop
     # shift-based softmax + scale layer + RELU layers switched on together: their verbs inside the reference's
     # own loops; a functional run (finite errors), not a learning claim for this combination
@@ -174,7 +175,7 @@ def _bow(words, V, with_time):
     return out
 
 
-@pytest.mark.parametrize("binary,att_mode,en_mq", [("MemN2N_ref", 2, True), ("MemN2N_ref_mode3nomq", 3, False)])
+@pytest.mark.parametrize("binary,att_mode,en_mq", [("MemN2N_ref", 2, True), ("MemN2N_ref_mode3nomq", 3, False), ("MemN2N_ref_mode3", 3, True)])
 def test_trained_weights_batched_forward_equals_the_reference_programs_own_test_error(gold, oracle, tmp_path, binary, att_mode, en_mq):
     """End to end on TRAINED weights (peaky softmaxes, saturated codes -- what seeded random weights never show).
     The reference's unmodified program trains on bAbI task 1 and tests; the library, in verify mode, computes the test

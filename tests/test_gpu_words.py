@@ -205,6 +205,25 @@ def test_full_joint_test_set(env, oracle, mode, nb):
     oracle_full(oracle, cfg, wts, sw, qw, n_sen, pred, u, max_excused=JOINT_EXCUSED[mode])
 
 
+@pytest.mark.parametrize("sigma", [1.0, 7.0])
+@pytest.mark.parametrize("mode,nb", [(3, 8), (10, 8), (11, 8)])
+def test_full_joint_test_set_under_the_stock_mixed_quantisation(env, oracle, mode, nb, sigma):
+    """BASELINE config 3 as the reference's define.h builds it once ATTENTION_MODE is a Hamming one: EN_MQ stays on, so hop 0
+    embeds on Q6.1 (values of 32 and beyond saturate the attention's operand words: sigma 7 makes thousands of rows do so),
+    hop 2 on Q4.3 (one bit finer than the attention grid).  All 20 000 stories: the host model against the hand-chained
+    kernels (float-row embedding, general hop kernel) and against the oracle's word arithmetic."""
+    g = np.load(GOLD / "babi_joint20_test20000_words.npz")
+    sw, qw = words16(g["story_words"], 16), words16(g["question_words"], 16)
+    n_sen, ans = g["n_sen"].astype(np.int64), g["answer"].astype(np.int64)
+    ans = np.where(ans == 0xFF, 0xFFFF, ans)
+    V = int(g["dim_input"])
+    cfg = env.model.babi_cfg(V, attention_mode=mode, en_mq=True)
+    cfg["num_bit"] = nb
+    wts = weights(13 + mode, 3, 60, V, sigma)
+    pred, u = run_both(env, cfg, wts, sw, qw, n_sen, ans)
+    oracle_full(oracle, cfg, wts, sw, qw, n_sen, pred, u, max_excused=0)
+
+
 def random_stories(rng, B, V, dd, W, S_list, dup_every=3):
     n_sen = np.array([S_list[i % len(S_list)] for i in range(B)], np.int64)
     rng.shuffle(n_sen)
