@@ -120,7 +120,12 @@ int qmann_quantize_i8(const float *src, int8_t *dst, size_t rows, uint32_t cols,
  * Replaces, per query and hop, the reference sequence dot_mat_vec_fwd -> softmax_fwd ->
  * dot_mat_vec_fwd(trans) -> dense_fwd(lin_map) -> sum_vec_fwd (MemN2N/MemN2N.c:2644-2666).
  * attention_mode QMANN_ATT_FIXED (define.h mode 2), QMANN_ATT_APPX (mode 3; needs att formats with
- * iwl + frac = 7 and u grids no finer / wider than the attention grid, else QMANN_EUNSUPPORTED) or
+ * iwl + frac = 7; the key bytes are the ones the embedding entry points store -- sign of the value | magnitude
+ * on the attention grid, or the key's own code where w[h] is one bit finer than att[h], exactly -2^iwl_att as
+ * 0x80 -- and carry the reference's 32-bit operand words for these grids: u and the keys inside the attention
+ * grid; both at least one fractional bit coarser (wider range: they saturate); u inside and the keys one bit
+ * finer.  EN_MQ's formats, MemN2N/MemN2N.c:748-754, are the second, first and third case at hops 0, 1, 2.
+ * Any other combination: QMANN_EUNSUPPORTED) or
  * QMANN_ATT_FLOAT (mode 1: float scores / softmax / read-out over the same int8 memories, which
  * then carry Q(w[h]) codes -- the embedding outputs, not re-quantised), or QMANN_ATT_HAMMING_V0 / _V1
  * computed straight from the int8 keys (the top num_bit bits of a sign-magnitude byte are its bit planes):
