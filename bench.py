@@ -83,6 +83,9 @@ for _n, _m, _nb in (("babi_joint20_v1", 11, 8), ("babi_joint20_v0", 10, 8), ("ba
     WORKLOADS[_n] = dict(S=64, D=60, V=238, B=262000, mode=_m, nb=_nb, ans="f32", joint=True)
 # the same with the embedding matrices tied across the hops as the reference trains them (TYPE_WEIGHT_TYING 2,
 # MemN2N/define.h:287; MemN2N.c:1770-1773): the host model then embeds the stories once for all hops
+# configs[2] as the reference's stock define.h builds it once ATTENTION_MODE is 3: EN_MQ stays on (hop 0 embeds on Q6.1,
+# hop 2 on Q4.3, the attention works on Q5.2 operand words; csrc/ham_common.h "APPX under EN_MQ")
+WORKLOADS["babi_joint20_appx_mq"] = dict(S=64, D=60, V=238, B=262000, mode=3, nb=8, ans="f32", joint=True, mq=True)
 WORKLOADS["babi_joint20_v1_tied"] = dict(S=64, D=60, V=238, B=262000, mode=11, nb=8, ans="f32", joint=True, tied=True)
 # BASELINE.json configs[1] on TRAINED weights: the matrices the reference's unmodified host program trained on bAbI task 1
 # through this library (tools/make_trained_fixture.py -> tests/golden/trained_qa1/), the 1 000 real test stories read from the
@@ -445,7 +448,8 @@ def run_joint(args, name, wl, cfg, wts, hm, dev, rank, world, model):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int8",
         "data": "bAbI 20-task joint test stories (2 000-story fixture made by the reference's sample.c, replicated), seeded random weights",
         "config": {"workload": name, "slots": f"2..{max_slots} (mean {n_sen.mean():.1f})", "dim_emb": cfg["dim_emb"],
-                   "dim_input": cfg["dim_input"], "hops": cfg["n_hop"], "queries_per_gpu": B, "format": "Q5.2",
+                   "dim_input": cfg["dim_input"], "hops": cfg["n_hop"], "queries_per_gpu": B,
+                   "format": "Q5.2; weights Q6.1 / Q5.2 / Q4.3 (EN_MQ)" if wl.get("mq") else "Q5.2",
                    "attention_mode": cfg["attention_mode"], "num_bit": cfg.get("num_bit", 8),
                    "stages": "one qmann_model_forward_words call: story embedding (int8 MFMA) + question embedding + hops + answer layer",
                    "weight_tying": "layer-wise (hop 0's embedding matrices on every hop): one shared memory plane" if wl.get("tied") else "none (independent matrices per hop)",
@@ -739,7 +743,7 @@ def run_workload(args, name, dev, rank, world):
     S, D, V, mode, nb = wl["S"], wl["D"], wl["V"], wl["mode"], wl["nb"]
     B = args.queries or wl["B"]
     H = 3
-    cfg = model.babi_cfg(V, attention_mode=mode, softmax_base=0, iwl=5, n_hop=H, D=D, en_mq=bool(wl.get("bow")))
+    cfg = model.babi_cfg(V, attention_mode=mode, softmax_base=0, iwl=5, n_hop=H, D=D, en_mq=bool(wl.get("bow") or wl.get("mq")))
     cfg["num_bit"] = nb
     if os.environ.get("QMANN_BENCH_NO_LINMAP"):            # experiment: what the in-kernel linear map costs
         cfg["en_lin_map"] = False

@@ -129,8 +129,6 @@ def test_lean_options(env, mode, variant):
     if mode != 2 and variant == "exp_shift_scaled":
         extra["att_scale"] = [0.002, 0.001, 0.0015]
     cfg = cfg_of(mode, H=H)
-    if "fmt_w" in extra and mode != 2:
-        extra["fmt_w"] = [(5, 2), (6, 1), (4, 3)]       # the Hamming byte forms need u0's grid inside the attention grid
     cfg.update(extra)
     if "att_scale" in cfg:
         cfg["att_scale"] = (cfg["att_scale"] * 2)[:H]

@@ -17,4 +17,5 @@ timeout -k 10 300 bash tools/collect_profiles.sh ${T}_idx babi_task1_idx
 timeout -k 10 300 bash tools/collect_profiles.sh ${T}_trained babi_task1_trained
 timeout -k 10 300 bash tools/collect_profiles.sh ${T}_j20v1 babi_joint20_v1
 timeout -k 10 300 bash tools/collect_profiles.sh ${T}_j20tied babi_joint20_v1_tied
+timeout -k 10 300 bash tools/collect_profiles.sh ${T}_j20appxmq babi_joint20_appx_mq
 timeout -k 10 300 bash tools/collect_profiles.sh ${T}_bow babi_task1_bow

@@ -44,7 +44,7 @@ def main():
     print("soak seed base", seed, flush=True)
     while time.time() - t0 < budget:
         rng = np.random.default_rng(seed + n)
-        kind = n % 10
+        kind = n % 11
         if kind == 0:                                        # lean kernel vs general kernel, random formats (fixed-point attention)
             def fmt(lo=2, hi=7):
                 wl = int(rng.integers(lo, hi + 1)); iwl = int(rng.integers(0, wl + 1))
@@ -112,9 +112,13 @@ def main():
                 wl = int(rng.integers(2, 8)); i = int(rng.integers(0, wl + 1))
                 return (i, wl - i)
             H = 3
-            extra = dict(fmt=[inside() for _ in range(H)], fmt_w=[inside()] + [free() for _ in range(H - 1)],
-                         fmt_att=[att] * H, fmt_bin=free(), en_lin_map=bool(rng.integers(0, 5)))
             mode = int(rng.choice([3, 10, 11])); nb = int(rng.choice([1, 2, 4, 8])); D = int(rng.choice([60, 128, 256]))
+
+            def key_grid():                                  # mode 3 reads the keys' grid off w[h]: inside the attention grid here (kind 10: EN_MQ)
+                wf = free()
+                return inside() if (mode == 3 and not (wf[0] <= ia and wf[1] <= 7 - ia)) else wf
+            extra = dict(fmt=[inside() for _ in range(H)], fmt_w=[inside()] + [key_grid() for _ in range(H - 1)],
+                         fmt_att=[att] * H, fmt_bin=free(), en_lin_map=bool(rng.integers(0, 5)))
             S_list = [int(x) for x in rng.integers(1, 65, 4)] if rng.integers(0, 2) else [int(x) for x in rng.integers(65, 500, 2)]
             from_bytes = (bool(rng.integers(0, 2)) or (D <= 64 and nb == 1)) and mode != 3
             Bh = int(rng.integers(1, 8))
@@ -169,6 +173,18 @@ def main():
                 TM.both_paths(env, cfg, oracle=oracle, n_oracle=3, nonzero=False, max_excused=3, **args)
             except AssertionError:
                 print("FAILED mid case", n, "seed base", seed, "cfg", cfg, "args", args, flush=True)
+                raise
+        if kind == 10:                                       # the Hamming family under EN_MQ's weight formats (saturating / finer operands) against the oracle
+            ia = int(rng.integers(1, 7))
+            mode = int(rng.choice([3, 3, 10, 11])); nb = 8 if mode == 3 else int(rng.choice([1, 2, 4, 8])); D = int(rng.choice([60, 128, 256]))
+            S_list = [int(x) for x in rng.integers(1, 65, 4)] if rng.integers(0, 2) else [int(x) for x in rng.integers(65, 500, 2)]
+            from_bytes = (bool(rng.integers(0, 2)) or (D <= 64 and nb == 1)) and mode != 3
+            Bh = int(rng.integers(1, 8)); sg = float(rng.uniform(5, 70))
+            try:
+                TB.run_hamming_case(env, oracle, mode, D, S_list, B=Bh, seed=seed + n, iwl=ia, num_bit=nb, sigma=sg, from_bytes=from_bytes, mq=True)
+            except AssertionError:
+                print("FAILED mixed-quantisation hamming case", n, "seed base", seed, "args", dict(mode=mode, D=D, S_list=S_list, B=Bh, seed=seed + n,
+                      iwl=ia, num_bit=nb, sigma=sg, from_bytes=from_bytes), flush=True)
                 raise
         n += 1
         if n % 100 == 0:

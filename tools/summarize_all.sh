@@ -12,6 +12,6 @@ python tools/summarize_profiles.py ${T}_float synth10k_d128_float 31457280000
 python tools/summarize_profiles.py ${T}_m50 babi_mem50 2516582400
 python tools/summarize_profiles.py ${T}_mid200 synth200_d64 5033164800
 python tools/summarize_profiles.py ${T}_mid1000 synth1000_d64 6291456000
-for w in "idx babi_task1_idx" "trained babi_task1_trained" "j20v1 babi_joint20_v1" "j20tied babi_joint20_v1_tied" "bow babi_task1_bow"; do
+for w in "idx babi_task1_idx" "trained babi_task1_trained" "j20v1 babi_joint20_v1" "j20tied babi_joint20_v1_tied" "j20appxmq babi_joint20_appx_mq" "bow babi_task1_bow"; do
   set -- $w; python tools/summarize_profiles.py ${T}_$1 $2 1
 done
