@@ -140,7 +140,7 @@ int qmann_hops_i8(const qmann_net *net, const int8_t *keys, const int8_t *vals, 
 
 /* Packed binary codes for the Hamming forms: sign-magnitude bytes [rows][Dp] -> bit planes
  * uint64 [rows][Dp/64][num_bit] (plane 0 = sign bits, plane i = magnitude bit 7-i; bit b of a word
- * is column 64.g + b).  num_bit in 1..8. */
+ * is column 64.g + b).  num_bit in 1..8.  sm_codes 16-byte aligned, planes 8-byte aligned (QMANN_EINVAL otherwise). */
 int qmann_pack_bitplanes(const int8_t *sm_codes, uint64_t *planes, size_t rows, uint32_t dim_emb_pad,
                          uint32_t num_bit, void *stream);
 

@@ -211,28 +211,46 @@ k_hops_ham(const HopArgs a, const uint32_t key_row_bytes, const uint32_t lds_slo
     if (tid < D) a.u_out[(size_t)q * D + tid] = relu_if(u_f[tid], a.en_non_lin != 0);
 }
 
-// sign-magnitude bytes [rows][Dp] -> bit-planes [rows][Dp/64][nb]: one wavefront per (row, group), four of
-// them per iteration (four loads in flight); the nb plane words of an item are gathered into lanes 0..nb-1 and
-// leave as one contiguous store.  Grid-stride (a launch may not exceed 2^32 threads, memories run to 10^8 rows).
+// sign-magnitude bytes [rows][Dp] -> bit-planes [rows][Dp/64][nb].  A lane loads 16 columns (one 16-byte load; round 2 loaded
+// one byte per lane and ran at 0.7 TB/s), a quad of lanes is one 64-column group.  Bit 7-i of the four bytes of a dword is
+// gathered into a nibble by one multiply (m = (x >> (7-i)) & 0x01010101; m . 0x01020408 puts byte j's bit at 24 + j, no two
+// partial products share a bit); four nibbles are a lane's 16 plane bits, two quad-permute moves make every lane of the quad
+// hold the group's 64-bit word, and lane t keeps the words of planes t and t + 4: an item's nb words leave as one contiguous
+// piece per quad.  Grid-stride (a launch may not exceed 2^32 threads, memories run to 10^8 rows).
 __global__ void __launch_bounds__(kBlock)
 k_pack_planes(const uint8_t *__restrict__ sm, uint64_t *__restrict__ planes, size_t rows, uint32_t Dp, uint32_t nb)
 {
-    constexpr int R = 4;
-    const uint32_t lane = threadIdx.x & (kWave - 1);
-    const size_t n = rows * (Dp / 64);                   // items: 64-column groups, in memory order
-    const size_t stride = (size_t)gridDim.x * (kBlock / kWave) * R;
-    for (size_t w0 = ((size_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave) * R; w0 < n; w0 += stride) {
-        uint32_t b[R];
+    const uint32_t t = threadIdx.x & 3u;
+    const size_t n = rows * (Dp / 16);                   // 16-byte pieces, in memory order; piece p belongs to item p / 4
+    const size_t stride = (size_t)gridDim.x * kBlock;
+    for (size_t p0 = (size_t)blockIdx.x * kBlock + threadIdx.x; p0 - t < n; p0 += 2 * stride) {     // (a quad enters together: n is a multiple of 4)
+        i32x4 x[2];
+        bool ok[2];
 #pragma unroll
-        for (int r = 0; r < R; r++) b[r] = (w0 + r < n) ? sm[(w0 + r) * 64 + lane] : 0u;     // item w covers bytes 64w .. 64w+63
+        for (int r = 0; r < 2; r++) {
+            const size_t p = p0 + r * stride;
+            ok[r] = p < n;
+            x[r] = ok[r] ? __builtin_nontemporal_load((const i32x4 *)(sm + p * 16)) : i32x4{0, 0, 0, 0};
+        }
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            uint64_t mine = 0;
+        for (int r = 0; r < 2; r++) {
+            uint64_t mine[2] = {0, 0};
             for (uint32_t i = 0; i < nb; i++) {
-                const uint64_t word = __ballot((b[r] >> (7 - i)) & 1u);
-                if (lane == i) mine = word;
+                uint32_t h = 0;
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    const uint32_t m = ((uint32_t)x[r][d] >> (7u - i)) & 0x01010101u;
+                    h |= ((m * 0x01020408u) >> 24) << (4 * d);
+                }
+                uint32_t v = h << (16u * (t & 1u));
+                v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]: lanes 0,1 low half, lanes 2,3 high half
+                const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]: the other half
+                const uint64_t word = (t & 2u) ? ((uint64_t)v << 32) | o : ((uint64_t)o << 32) | v;
+                if ((i & 3u) == t) mine[i >> 2] = word;
             }
-            if (w0 + r < n && lane < nb) planes[(w0 + r) * nb + lane] = mine;
+            const size_t item = (p0 + r * stride) / 4;
+            if (ok[r] && t < nb) planes[item * nb + t] = mine[0];
+            if (ok[r] && t + 4 < nb) planes[item * nb + t + 4] = mine[1];
         }
     }
 }
@@ -310,9 +328,10 @@ int qmann_pack_bitplanes(const int8_t *sm_codes, uint64_t *planes, size_t rows, 
     QmBatched qm_scope;
     if (!sm_codes || !planes) return QMANN_EINVAL;
     if (dim_emb_pad % 64 != 0 || num_bit < 1 || num_bit > 8) return QMANN_EINVAL;
-    const size_t items = rows * (dim_emb_pad / 64);
-    if (items == 0) return QMANN_OK;
-    const size_t blocks = (items + (kBlock / kWave) * 4 - 1) / ((kBlock / kWave) * 4);
+    const size_t pieces = rows * (dim_emb_pad / 16);
+    if (pieces == 0) return QMANN_OK;
+    if (((uintptr_t)sm_codes & 15u) || ((uintptr_t)planes & 7u)) return QMANN_EINVAL;       // 16-byte loads, 8-byte stores
+    const size_t blocks = (pieces + 2 * kBlock - 1) / (2 * kBlock);
     k_pack_planes<<<(unsigned)(blocks < 65536 ? blocks : 65536), kBlock, 0, (hipStream_t)stream>>>(
         (const uint8_t *)sm_codes, planes, rows, dim_emb_pad, num_bit);
     QM_LAUNCH_CHECK();

@@ -396,6 +396,26 @@ def test_appx_operand_grids_a_byte_cannot_carry_are_refused(env):
             net.hops(k, k.clone(), ro, 4, u0)
 
 
+@pytest.mark.parametrize("Dp", [64, 128, 256])
+@pytest.mark.parametrize("rows", [1, 5, 1000, 70001])
+def test_pack_bitplanes_layout(env, Dp, rows):
+    """include/qmann_batch.h: planes [rows][Dp/64][num_bit] uint64, plane 0 = sign bits, plane i = magnitude bit 7-i,
+    bit b of a word = column 64 g + b -- every byte value, every num_bit, against numpy"""
+    torch, model = env.torch, env.model
+    rng = np.random.default_rng(rows + Dp)
+    sm = rng.integers(0, 256, (rows, Dp), dtype=np.uint8)
+    sm[0, :] = np.arange(Dp) % 256 if rows else 0
+    net = model.QNet(cfg_synth(Dp, 40), weights(1, 3, Dp, 40, 1.0, with_emb=False), device="cuda:0")
+    d = torch.from_numpy(sm.view(np.int8)).to(env.dev)
+    for nb in range(1, 9):
+        got = net.pack_planes(d, nb).cpu().numpy().view(np.uint64)
+        assert got.shape == (rows, Dp // 64, nb)
+        for i in range(nb):
+            bits = ((sm >> (7 - i)) & 1).reshape(rows, Dp // 64, 64)
+            want = np.packbits(bits, axis=-1, bitorder="little").view(np.uint64)[..., 0]
+            np.testing.assert_array_equal(got[:, :, i], want, err_msg=f"num_bit {nb}, plane {i}")
+
+
 @pytest.mark.parametrize("mode", [10, 11])
 @pytest.mark.parametrize("D,num_bit", [(60, 8), (64, 2), (128, 8), (128, 4), (128, 1), (200, 8), (256, 8), (256, 2), (256, 1)])
 def test_hops_packed_popcount_bit_exact(env, oracle, mode, D, num_bit):
