@@ -768,6 +768,7 @@ struct EmbedIdxArgs {
     uint32_t n_hop, D, Dp, V, rows, max_words, time_last;
     QFmt act[QMANN_MAX_HOP], w[QMANN_MAX_HOP], att[QMANN_MAX_HOP];   // att: the format of the KEY BYTES (fill_key_formats)
     uint32_t key_mz;              // bit h: hop h's keys follow the minus-zero rule
+    uint32_t qkinds;              // 2 bits per (hop, table): how the matrix-core kernel's epilogue may quantise (kQk*, below)
 };
 
 // integer count c >= 0 as a code of the format in units of 2^-frac: Qw(c), saturating at the format maximum
@@ -844,6 +845,43 @@ __device__ __forceinline__ uint32_t ew_to_bytes(s16x2 x, int maxw, QFmt fw, QFmt
     mag = __builtin_elementwise_min(mag, u16x2{md, md});
     const u16x2 sgn = __builtin_bit_cast(u16x2, (s16x2)(x >> 8)) & (unsigned short)0x0080;
     return __builtin_bit_cast(uint32_t, (u16x2)(mag | sgn));
+}
+
+// ew_to_bytes for the usual format pairs, on FOUR values at once in the byte domain (the matrix-core kernel's epilogue is a
+// third of its instructions).  With word lengths of at most 8 the clamped sum fits a byte; its sign-magnitude form is
+// (x ^ s) + (s & 1) per byte (s = 0xFF where x < 0: a negative byte becomes |x| - 1, then + 1, never a carry), and the target
+// grid is at most one bit away in EN_MQ (MemN2N.c:748-754) and equal without it:
+//   kQkSame   dst.frac == fw.frac, dst clamp not below the source's:   nothing to do
+//   kQkLeft   dst.frac == fw.frac + 1, dst word length 8:              m + m per byte (<= 254), bytes >= 128 saturate to 127
+//   kQkRight  dst.frac == fw.frac - 1, dst clamp not below maxw >> 1:  (m >> 1) per byte; the sign stays the VALUE's
+//   kQkGeneral anything else (and keys under the minus-zero rule):     ew_to_bytes
+enum { kQkSame = 0, kQkLeft = 1, kQkRight = 2, kQkGeneral = 3 };
+__host__ __device__ inline uint32_t qkind_of(QFmt fw, QFmt dst, bool mz)
+{
+    const uint32_t maxw = (1u << (fw.iwl + fw.frac)) - 1u, md = (1u << (dst.iwl + dst.frac)) - 1u;
+    if (mz || maxw > 127u) return kQkGeneral;
+    if (dst.frac == fw.frac && md >= maxw) return kQkSame;
+    if (dst.frac == fw.frac + 1u && md == 127u) return kQkLeft;
+    if (dst.frac + 1u == fw.frac && md >= (maxw >> 1)) return kQkRight;
+    return kQkGeneral;
+}
+// x01 / x23: the four sums as packed int16 pairs (columns 0, 1 and 2, 3 of a dword); returns the dword of memory bytes
+__device__ __forceinline__ uint32_t ew_to_bytes4(s16x2 x01, s16x2 x23, int maxw, uint32_t kind)
+{
+    const short mw = (short)maxw;
+    x01 = __builtin_elementwise_min(__builtin_elementwise_max(x01, s16x2{(short)-mw, (short)-mw}), s16x2{mw, mw});
+    x23 = __builtin_elementwise_min(__builtin_elementwise_max(x23, s16x2{(short)-mw, (short)-mw}), s16x2{mw, mw});
+    const uint32_t d = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, x23), __builtin_bit_cast(uint32_t, x01), 0x06040200u);   // two's complement bytes
+    const uint32_t sg = d & 0x80808080u;
+    const uint32_t sm = __builtin_amdgcn_perm(0u, 0u, sg);               // 0xFF where negative (selector bytes >= 0x80 give 0xFF, 0 gives byte 0 = 0)
+    uint32_t m = (d ^ sm) + (sm & 0x01010101u);                           // |x| per byte
+    if (kind == kQkLeft) {
+        m += m;
+        m = (m | __builtin_amdgcn_perm(0u, 0u, m & 0x80808080u)) & 0x7F7F7F7Fu;
+    } else if (kind == kQkRight) {
+        m = (m >> 1) & 0x3F3F3F3Fu;
+    }
+    return m | sg;
 }
 
 template <bool TAB16>
@@ -1118,13 +1156,20 @@ k_embed_story_mfma(const EmbedIdxArgs a)
 #pragma unroll
         for (uint32_t t = 0; t < 2; t++) {
             const QFmt dstf = t ? f_act : f_att;
+            const uint32_t qk = (a.qkinds >> (4u * h + 2u * t)) & 3u;    // (workgroup-uniform)
 #pragma unroll
             for (uint32_t cb = 0; cb < 4; cb++) {
                 const i32x4 v = acc[t][cb];                              // v[r]: story row nrow, column 16 cb + 4 kq + r
                 const s16x2 x01 = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm((uint32_t)v[1], (uint32_t)v[0], 0x05040100u));
                 const s16x2 x23 = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm((uint32_t)v[3], (uint32_t)v[2], 0x05040100u));
-                const uint32_t b01 = ew_to_bytes(x01, maxw, fw, dstf, t == 0 && kmz), b23 = ew_to_bytes(x23, maxw, fw, dstf, t == 0 && kmz);
-                *(uint32_t *)(stage + nrow * SP + cb * 16u + kq * 4u) = __builtin_amdgcn_perm(b23, b01, 0x06040200u);
+                uint32_t out;
+                if (qk != kQkGeneral) {
+                    out = ew_to_bytes4(x01, x23, maxw, qk);
+                } else {
+                    const uint32_t b01 = ew_to_bytes(x01, maxw, fw, dstf, t == 0 && kmz), b23 = ew_to_bytes(x23, maxw, fw, dstf, t == 0 && kmz);
+                    out = __builtin_amdgcn_perm(b23, b01, 0x06040200u);
+                }
+                *(uint32_t *)(stage + nrow * SP + cb * 16u + kq * 4u) = out;
             }
             // a row whose repeated word leaves the format: its sums term by term, Qw(Qw(count) . kw) over the row's distinct
             // words (the non-zero bytes of its X row), lane = column; replaces the row in the staging tile
@@ -1265,6 +1310,15 @@ static void fill_key_formats(Args &a, const qmann_net *net)
         a.att[h] = ham_key_format(net->attention_mode, QFmt{src.iwl, src.frac}, a.w[h], QFmt{net->att[h].iwl, net->att[h].frac}, &mz);
         if (mz) a.key_mz |= 1u << h;
     }
+}
+static void fill_qkinds(EmbedIdxArgs &a)
+{
+    a.qkinds = 0;
+    for (uint32_t h = 0; h < a.n_hop; h++) {
+        a.qkinds |= qkind_of(a.w[h], a.att[h], (a.key_mz >> h) & 1u) << (4u * h);
+        a.qkinds |= qkind_of(a.w[h], a.act[h], false) << (4u * h + 2u);
+    }
+    if (getenv("QMANN_EMBED_GENERAL_EPILOGUE")) a.qkinds = 0xFFFFFFFFu;     // A/B: ew_to_bytes everywhere
 }
 
 }  // namespace
@@ -1510,6 +1564,7 @@ int qmann_embed_story_idx(const qmann_net *net, const uint16_t *words, uint32_t 
         a.t_a[h] = t_a[h]; a.t_c[h] = t_c[h];
     }
     fill_key_formats(a, net);
+    fill_qkinds(a);
     if (rows_total == 0) return QMANN_OK;
     if ((net->dim_emb_pad & 3u) || (hop_stride & 3u) || ((uintptr_t)keys & 3u) || ((uintptr_t)vals & 3u)) return QMANN_EINVAL;
     if (net->dim_emb_pad % 64 != 0) return QMANN_EUNSUPPORTED;          // 16 lanes x 4 columns per round
