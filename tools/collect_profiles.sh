@@ -13,7 +13,9 @@ cd /tmp && export TMPDIR=/tmp
 # counter files are cut down to our kernels' rows
 prune() { find "$1" -type f ! -name '*kernel_stats.csv' ! -name '*counter_collection.csv' -delete; 
           for c in $(find "$1" -name '*counter_collection.csv'); do { head -1 "$c"; grep -E 'k_hops|k_answer|k_embed|k_logits|k_fwd' "$c" || true; } > "$c.tmp"; mv "$c.tmp" "$c"; done; }
-rocprofv3 --kernel-trace --stats --output-format csv -d $P/${tag}_stats -- python3 $R/bench.py --workload $wl --steps 10 --no-cpu-baseline --no-secondary --no-sustained > $P/${tag}_stats.log 2>&1
+# 30 timed steps (+ 3 warm-up launches, which the statistics include): the first ~5 launches of a VALU-heavy kernel run up to 15 %
+# slower than the rest (tools/trace_seq.sh shows them one by one); 13 launches would average mostly that transient
+rocprofv3 --kernel-trace --stats --output-format csv -d $P/${tag}_stats -- python3 $R/bench.py --workload $wl --steps 30 --no-cpu-baseline --no-secondary --no-sustained > $P/${tag}_stats.log 2>&1
 prune $P/${tag}_stats
 for pass in "$@"; do
   case $pass in

@@ -18,7 +18,7 @@ st = glob.glob(str(src / f"{tag}_stats" / "*" / "*kernel_stats.csv"))
 if st:
     rows = list(csv.DictReader(open(st[0])))
     with open(out / f"{tag}_kernel_stats_{workload}.csv", "w") as f:
-        f.write(f"# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --workload {workload} --steps 10 --no-cpu-baseline --no-secondary --no-sustained   (MI355X)\n")
+        f.write(f"# rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --workload {workload} --steps 30 --no-cpu-baseline --no-secondary --no-sustained   (MI355X)\n")
         f.write("# kernel names cut to 100 chars; torch kernels are the synthetic-data generation\n")
         w = csv.writer(f); w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
         for r in rows:
