@@ -246,10 +246,13 @@ def test_trained_weights_batched_forward_equals_the_reference_programs_own_test_
         p_max.append(float(np.max(t["probs"][H - 1])))
         top2 = np.sort(t["out_probs"])[-2:]
         if top2[1] - top2[0] <= 1e-6:
+            # two answers within the float tolerance of each other (a run of the Hamming build that has learnt little gives
+            # hundreds of those: training is seeded by the clock, sample.c:111): the batched answer must be one of them
+            assert t["out_probs"][int(pred[q])] >= top2[1] - 1e-6, f"story {q}: batched {int(pred[q])} is not among the oracle's tied answers"
             near_tie += 1
             continue
         assert int(pred[q]) == op, f"story {q}: batched {int(pred[q])}, oracle {op}"
         agree += 1
-    assert agree >= ds["n_query"] - 5, (agree, near_tie)
+    assert agree + near_tie == ds["n_query"]
     print(f"oracle: {agree} of {ds['n_query']} predictions equal ({near_tie} near-ties skipped); last-hop max p: mean {np.mean(p_max):.3f}, "
           f"{np.mean(np.array(p_max) > 0.9) * 100:.0f} % above 0.9")
