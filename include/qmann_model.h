@@ -5,8 +5,11 @@
  * 31 layer calls :2626-2697, bookkeeping :2701-2702) this does per batch: story embedding ->
  * question embedding -> every hop -> answer layer -> prediction / match / cost, through the batched
  * kernels of qmann_batch.h.  The object owns the device copies of the parameters in the layouts the
- * kernels want (int8 gather tables, sign-magnitude lin_map codes, packed bit planes are made per
- * batch) and a workspace for the int8 memories that grows on demand.  Host language is C++ inside
+ * kernels want (int8 gather tables, sign-magnitude lin_map codes; packed bit planes are made per
+ * batch, and only where one plane serves several hops -- tied matrices, long memories, num_bit < 8 --
+ * since packing re-reads the key bytes: otherwise the Hamming scores come from the int8 keys
+ * themselves) and a workspace for the int8 memories that grows on demand.  Every attention mode of
+ * qmann_batch.h, the Hamming ones also under EN_MQ's per-hop weight formats.  Host language is C++ inside
  * the library; the interface is plain C.
  *
  * Inputs are DEVICE pointers (the reference's cuda_data_in pools, or word-index arrays); every call
