@@ -60,18 +60,23 @@ k_hops_mid(const HopArgs a, const LeanArgs la)
     slots_of(q, r0, S);
 
     // Group g of a query = its rows 64 g .. 64 g + 63: four 16-byte loads per lane (rows gs + 16 j + sub, piece `chunk`), one
-    // lane offset and immediate row offsets.  A group that would run past the END OF THE PLANE is moved back to end there
-    // (gs < 64 g; the rows it repeats are skipped when the scores are stored); rows past the query's own end belong to the
-    // next query -- valid memory, their sums are dropped.  A query with fewer than 64 rows left in the plane (the batch's
-    // last ones: "irregular") takes a plain loop with per-row clamping instead, without prefetch.
+    // lane offset and immediate row offsets.  A group that would run past the END OF THE STORY is moved back to end there
+    // (gs = S - 64 < 64 g: the rows it repeats were requested a moment ago by the group before it -- the two are in flight
+    // together, so the repeat is served by the cache, not by HBM -- and only the passes that hold new rows are summed).  Round 3's
+    // first version let such a group run into the next story's rows: 1.26 x the algorithmic bytes at 200 slots, and at 0.62 of
+    // the peak in USEFUL bytes the kernel was in fact moving 0.78 of it.  A story shorter than one group still reads into the
+    // next story (moved back only at the plane's end).  A query with fewer than 64 rows left in the plane (the batch's last
+    // ones: "irregular") takes a plain loop with per-row clamping instead, without prefetch.
     // The steady-state loop holds no branch around a load: the compiler then counts its outstanding loads exactly
     // (s_waitcnt vmcnt(4) before a group's sums, the other group still in flight).
     const uint32_t lane_off = sub * Dp + chunk * 16u;
     i32x4 xa[4], xb[4];
     auto key_plane = [&](uint32_t h, uint32_t r0_) { return (const uint8_t *)a.keys + (size_t)h * a.key_hop_stride + (size_t)r0_ * Dp; };
-    // np: the passes of 16 rows this group really has (4 for a full group; the story's last group may have fewer, and the
-    // arithmetic of the passes it lacks is skipped -- their loads still run, branch-free, into the next story's rows).
+    // the passes of 16 rows a group at its own place really has (4 for a full group; a short story's only group has fewer: the
+    // arithmetic of the passes it lacks is skipped, their loads still run, branch-free)
     auto passes_of = [&](uint32_t g, uint32_t S_) { const uint32_t left = S_ > g * 64u ? S_ - g * 64u : 0u; return left >= 64u ? 4u : (left + 15u) / 16u; };
+    // where a story's groups may start at the latest, relative to its first row: its own end - 64, or the plane's for a short story
+    auto lim_of = [&](uint32_t r0_, uint32_t S_) { return S_ >= 64u ? S_ - 64u : R_end - r0_ - 64u; };
     auto issue = [&](i32x4 (&x)[4], const uint8_t *plane, uint32_t lim, uint32_t g) {      // regular queries only
         const uint32_t gs = g * 64u < lim ? g * 64u : lim;
         const uint8_t *p = plane + (size_t)gs * Dp + lane_off;
@@ -80,7 +85,7 @@ k_hops_mid(const HopArgs a, const LeanArgs la)
     };
     auto is_regular = [&](uint32_t r0_, uint32_t S_) { return S_ > 0u && R_end - r0_ >= 64u; };
     bool regular = is_regular(r0, S);
-    if (regular) { issue(xa, key_plane(0, r0), R_end - r0 - 64u, 0); issue(xb, key_plane(0, r0), R_end - r0 - 64u, 1); }
+    if (regular) { issue(xa, key_plane(0, r0), lim_of(r0, S), 0); issue(xb, key_plane(0, r0), lim_of(r0, S), 1); }
     float u_next = (lane < D) ? a.u0[(size_t)q * D + lane] : 0.0f;
 
     for (; q < n_query; q += q_stride) {
@@ -90,7 +95,7 @@ k_hops_mid(const HopArgs a, const LeanArgs la)
         const bool regular_n = qn < n_query && is_regular(r0n, Sn);
         float u = u_next;
         const uint32_t n_g = (S + 63u) / 64u;
-        const uint32_t lim = R_end - r0 - 64u;                        // (meaningful for regular queries)
+        const uint32_t lim = lim_of(r0, S);                           // (meaningful for regular queries)
         for (uint32_t h = 0; h < H; h++) {
             const QFmt fa = a.act[h], fm = a.att[h], fb = a.bin, fw = a.w[h];
             const int maxa = (1 << (fa.iwl + fa.frac)) - 1;
@@ -109,11 +114,11 @@ k_hops_mid(const HopArgs a, const LeanArgs la)
             // ---- scan: scores of all rows, 64 rows per step ---------------------------------------------------------
             const uint8_t *kp = key_plane(h, r0);
             int mx = -128;
-            auto consume = [&](const i32x4 (&x)[4], uint32_t g, uint32_t gs, uint32_t np) {
+            auto consume = [&](const i32x4 (&x)[4], uint32_t g, uint32_t gs, uint32_t p_lo, uint32_t p_hi) {
                 int s[4] = {0, 0, 0, 0};
 #pragma unroll
                 for (uint32_t j = 0; j < 4; j++)
-                    if (j < np) s[j] = row_lanes_sum<4>(lane_sum_w<W7>(x[j], csc, csh));      // wavefront-uniform
+                    if (j >= p_lo && j < p_hi) s[j] = row_lanes_sum<4>(lane_sum_w<W7>(x[j], csc, csh));      // wavefront-uniform
                 // every lane of a row group holds its row's sum: lane (sub, chunk) keeps row gs + 16 chunk + sub
                 int v = s[0];
                 v = chunk == 1u ? s[1] : v; v = chunk == 2u ? s[2] : v; v = chunk == 3u ? s[3] : v;
@@ -122,20 +127,23 @@ k_hops_mid(const HopArgs a, const LeanArgs la)
                 if (r >= g * 64u && r < S) { sc[r] = (int8_t)code; mx = code > mx ? code : mx; }
             };
             auto gstart = [&](uint32_t g) { return g * 64u < lim ? g * 64u : lim; };
-            // passes with live rows in group g: a group moved back from the plane's end (gstart(g) < 64 g) holds its live rows in
-            // its LAST passes, not its first -- all four are taken then (the row test in consume() drops the repeated rows)
-            auto passes_at = [&](uint32_t g) { return gstart(g) == g * 64u ? passes_of(g, S) : (g * 64u < S ? 4u : 0u); };
+            // passes with NEW rows in group g: a group at its own place has them in its first passes_of() passes; a group moved
+            // back (gstart(g) < 64 g) holds them in its LAST passes -- pass j covers rows gstart + 16 j .. + 15 and is new from
+            // (64 g - gstart) / 16 on (the row test in consume() drops the repeated rows of a half-new pass); a group wholly past
+            // the story's end has none
+            auto pass_lo = [&](uint32_t g) { return gstart(g) == g * 64u ? 0u : (g * 64u < S ? (g * 64u - gstart(g)) / 16u : 4u); };
+            auto pass_hi = [&](uint32_t g) { return gstart(g) == g * 64u ? passes_of(g, S) : 4u; };
             if (regular) {
                 __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): groups 0 and 1, requested a hop ago, have landed
                 uint32_t g = 0;
                 for (; g + 2 < n_g; g += 2) {                         // steady state: two groups in flight, no branch around a load
-                    consume(xa, g, gstart(g), 4);
+                    consume(xa, g, gstart(g), 0, 4);
                     issue(xa, kp, lim, g + 2);
-                    consume(xb, g + 1, gstart(g + 1), 4);
+                    consume(xb, g + 1, gstart(g + 1), 0, 4);
                     issue(xb, kp, lim, g + 3);
                 }
-                consume(xa, g, gstart(g), passes_at(g));
-                consume(xb, g + 1, gstart(g + 1), passes_at(g + 1));       // (a group past the story's end: no pass, nothing stored)
+                consume(xa, g, gstart(g), pass_lo(g), pass_hi(g));
+                consume(xb, g + 1, gstart(g + 1), pass_lo(g + 1), pass_hi(g + 1));       // (a group past the story's end: no pass, nothing stored)
                 // in flight during the rest of the hop: the next hop's first two groups, or the next query's
                 if (h + 1 < H) { issue(xa, key_plane(h + 1, r0), lim, 0); issue(xb, key_plane(h + 1, r0), lim, 1); }
             } else if (S > 0) {
@@ -146,11 +154,11 @@ k_hops_mid(const HopArgs a, const LeanArgs la)
                         r = r < S ? r : S - 1u;
                         xa[j] = *(const i32x4 *)(kp + (size_t)r * Dp + chunk * 16u);
                     }
-                    consume(xa, g, g * 64u, 4);
+                    consume(xa, g, g * 64u, 0, 4);
                 }
             }
             if (h + 1 == H && regular_n) {
-                issue(xa, key_plane(0, r0n), R_end - r0n - 64u, 0); issue(xb, key_plane(0, r0n), R_end - r0n - 64u, 1);
+                issue(xa, key_plane(0, r0n), lim_of(r0n, Sn), 0); issue(xb, key_plane(0, r0n), lim_of(r0n, Sn), 1);
             }
             if (h + 1 == H && qn < n_query) u_next = (lane < D) ? a.u0[(size_t)qn * D + lane] : 0.0f;
             wave_sync();                                              // the score bytes are visible to every lane

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Soak run on a GPU box: the random-configuration parity checks of tests/ with fresh seeds, for as long as asked.
 usage: python tools/soak.py [seconds]   (run from the repo root; prints one line per hundred cases)"""
+import os
 import sys
 import time
 from pathlib import Path
@@ -44,7 +45,7 @@ def main():
     print("soak seed base", seed, flush=True)
     while time.time() - t0 < budget:
         rng = np.random.default_rng(seed + n)
-        kind = n % 11
+        kind = int(os.environ["SOAK_KIND"]) if os.environ.get("SOAK_KIND") else n % 11       # SOAK_KIND=9: one kind only
         if kind == 0:                                        # lean kernel vs general kernel, random formats (fixed-point attention)
             def fmt(lo=2, hi=7):
                 wl = int(rng.integers(lo, hi + 1)); iwl = int(rng.integers(0, wl + 1))
