@@ -183,17 +183,23 @@ __device__ __forceinline__ void lean_stage_tables(const HopArgs &a, const LeanAr
 // is clamped and published, the linear map H.u runs on the pre-split rows in LDS, and u' = Qa(Qa(Hu) + Qa(o)) replaces `u`.
 //   kb_code   Q_bin(u) of column `lane` (the linear map's operand)
 //   csc / csh the scan constants still in registers; `reuse`: they are already those of (word length of w[h], frac_bin)
-template <bool W7>
+//   acc_of()  the read-out code of column `lane`; called AFTER the linear map's row sums, so that value rows requested from
+//             global memory just before this function (the sparse read-out of lean_hop) arrive while those sums are taken
+template <bool W7, typename AccOf>
 __device__ __forceinline__ void lean_finish_hop(const HopArgs &a, uint32_t h, uint32_t lane, uint8_t *lw, const uint8_t *lmap, float &u,
-                                                int acc, int kb_code, ScanConst &csc, uint32_t &csh, bool reuse)
+                                                AccOf acc_of, int kb_code, ScanConst &csc, uint32_t &csh, bool reuse)
 {
     constexpr uint32_t LPR = 4;
     const uint32_t sub = lane >> 2, chunk = lane & 3u, D = a.D;
     const QFmt fa = a.act[h], fb = a.bin, fw = a.w[h];
     const int maxa = (1 << (fa.iwl + fa.frac)) - 1;
     const uint32_t wl_w = fw.iwl + fw.frac;
-    acc = acc > maxa ? maxa : (acc < -maxa ? -maxa : acc);
-    *(int16_t *)(lw + kLwOc + lane * 2) = (int16_t)acc;
+    auto publish_o = [&]() {
+        int acc = acc_of();
+        acc = acc > maxa ? maxa : (acc < -maxa ? -maxa : acc);
+        *(int16_t *)(lw + kLwOc + lane * 2) = (int16_t)acc;
+        return acc;
+    };
 
     // ---- linear map + hop update ---------------------------------------------------------------------
     if (a.en_lin_map) {
@@ -215,6 +221,8 @@ __device__ __forceinline__ void lean_finish_hop(const HopArgs &a, uint32_t h, ui
             }
         }
         // lane (sub, chunk) now holds the sum of row o = 16 . chunk + sub
+        (void)publish_o();
+        wave_sync();                                              // every column's read-out code is in LDS
         const uint32_t o_i = chunk * 16u + sub;
         const int kw = keep > maxw ? maxw : (keep < -maxw ? -maxw : keep);       // Qw of the row sum
         const uint32_t mag = (uint32_t)(kw < 0 ? -kw : kw);
@@ -227,7 +235,7 @@ __device__ __forceinline__ void lean_finish_hop(const HopArgs &a, uint32_t h, ui
         wave_sync();
         u = (lane < D) ? *(const float *)(lw + kLwUn + lane * 4) : 0.0f;
     } else {
-        int un = ((lane < D) ? qm_code(u, fa.iwl, fa.frac) : 0) + acc;
+        int un = ((lane < D) ? qm_code(u, fa.iwl, fa.frac) : 0) + publish_o();
         un = un > maxa ? maxa : (un < -maxa ? -maxa : un);
         u = qm_scale_down((float)un, fa.frac);
     }
@@ -239,10 +247,14 @@ __device__ __forceinline__ void lean_finish_hop(const HopArgs &a, uint32_t h, ui
 //   before_readout()  called once the read-out weights are known, before the value tile `vt` is read
 //                     (wait for / produce the tile; must leave the wavefront synchronised)
 // `lw`: this wavefront's small arrays (kLwBytes); `lmap` / `etab`: the workgroup's tables.
-template <int MODE, int NB, bool W7, typename KeyOf, typename BeforeReadout>
+//   vg / SPARSE       SPARSE: there is no value tile `vt`; the rows whose weight code is non-zero (at most 2^frac of
+//                     them, four at the default Q5.2) are fetched from global memory `vg` (this story's rows of the hop's value
+//                     plane), the first four requested BEFORE before_readout() and the linear map, which hide their round trip.
+//                     At |mem| = 50 the whole-tile read doubled the kernel's HBM traffic and the kernel was bound by it.
+template <int MODE, int NB, bool W7, bool SPARSE, typename KeyOf, typename BeforeReadout>
 __device__ __forceinline__ void lean_hop(const HopArgs &a, const LeanArgs &la, uint32_t h, uint32_t S, uint32_t lane, const uint8_t *vt,
                                          uint8_t *lw, const uint8_t *lmap, const float *etab, float &u, KeyOf key_of,
-                                         BeforeReadout before_readout)
+                                         BeforeReadout before_readout, const uint8_t *vg = nullptr)
 {
     constexpr uint32_t Dp = 64, LPR = 4;
     const uint32_t sub = lane >> 2, chunk = lane & 3u, D = a.D;
@@ -318,29 +330,53 @@ __device__ __forceinline__ void lean_hop(const HopArgs &a, const LeanArgs &la, u
     kp = kp > maxa ? maxa : kp;
 
     // ---- read-out over the rows whose weight code is non-zero (lane c owns column c) -----------------
-    before_readout();
+    uint64_t m = __ballot(kp != 0);
+    int rr[4], kk[4];
+    uint32_t bb[4];
     int acc = 0;
-    for (uint64_t m = __ballot(kp != 0); m;) {                    // up to four surviving rows per round, their bytes requested together
-        int rr[4], kk[4];
-        uint32_t bb[4];
+    auto pick = [&]() {                                           // the next (up to) four surviving rows and their weight codes
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             rr[i] = m ? __builtin_ctzll(m) : -1;                  // (wavefront-uniform)
             m &= m - 1;                                           // (0 stays 0)
             kk[i] = rr[i] >= 0 ? __builtin_amdgcn_readlane(kp, rr[i] >= 0 ? rr[i] : 0) : 0;
-            bb[i] = rr[i] >= 0 ? vt[(uint32_t)rr[i] * Dp + lane] : 0u;
         }
+    };
+    auto add = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             uint32_t t = ((uint32_t)kk[i] * (bb[i] & 0x7Fu)) >> fa.frac;   // |Q(p) . v| / 2^frac toward zero
             t = t > (uint32_t)maxa ? (uint32_t)maxa : t;
             acc += (bb[i] & 0x80u) ? -(int)t : (int)t;
         }
+    };
+    const bool reuse = MODE == kModeFixed && wl_w == wl_m && !relu;
+    if (SPARSE) {
+        auto fetch = [&]() {
+#pragma unroll
+            for (int i = 0; i < 4; i++) bb[i] = rr[i] >= 0 ? (uint32_t)vg[(uint32_t)rr[i] * Dp + lane] : 0u;
+        };
+        pick();
+        fetch();                                                  // requested first: older than the key prefetch below
+        before_readout();
+        lean_finish_hop<W7>(a, h, lane, lw, lmap, u, [&]() {
+            add();
+            while (m) { pick(); fetch(); add(); }                 // more than four survivors: formats with frac > 2, rarely
+            return acc;
+        }, kb_code, csc, csh, reuse);
+        return;
     }
-    lean_finish_hop<W7>(a, h, lane, lw, lmap, u, acc, kb_code, csc, csh, MODE == kModeFixed && wl_w == wl_m && !relu);
+    before_readout();
+    while (m) {                                                   // up to four surviving rows per round, their bytes read together
+        pick();
+#pragma unroll
+        for (int i = 0; i < 4; i++) bb[i] = rr[i] >= 0 ? vt[(uint32_t)rr[i] * Dp + lane] : 0u;
+        add();
+    }
+    lean_finish_hop<W7>(a, h, lane, lw, lmap, u, [&]() { return acc; }, kb_code, csc, csh, reuse);
 }
 
-template <int MODE, int NB, bool W7>
+template <int MODE, int NB, bool W7, bool SPARSE>
 __global__ void __launch_bounds__(kLeanBlock)
 k_hops_lean(const HopArgs a, const LeanArgs la)
 {
@@ -395,26 +431,29 @@ k_hops_lean(const HopArgs a, const LeanArgs la)
         float u = u_next;
         for (uint32_t h = 0; h < H; h++) {
             // this hop's value rows: global memory -> this wavefront's LDS tile, 1 KiB (16 rows) per instruction
-            const uint8_t *vb = (const uint8_t *)a.vals + (size_t)h * a.hop_stride + (size_t)r0 * Dp + chunk * 16;
+            const uint8_t *vg = (const uint8_t *)a.vals + (size_t)h * a.hop_stride + (size_t)r0 * Dp;
+            const uint8_t *vb = vg + chunk * 16;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint32_t r = j * 16 + sub;
-                if (j * 16 < (int)S) {                                    // wavefront-uniform
+                if (!SPARSE && j * 16 < (int)S) {                         // wavefront-uniform (SPARSE: no tile, see lean_hop)
                     if (r < S)
                         __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(vb + (size_t)r * Dp),
                                                          (void __attribute__((address_space(3))) *)(vt + j * 1024), 16, 0, 0);   // (the nt policy on this DMA measured no different)
                 }
             }
-            lean_hop<MODE, NB, W7>(a, la, h, S, lane, vt, lw, lmap, etab, u, [&](int j) { return kq[j]; }, [&]() {
-                __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0): the value tile has landed
-                wave_sync();
+            lean_hop<MODE, NB, W7, SPARSE>(a, la, h, S, lane, vt, lw, lmap, etab, u, [&](int j) { return kq[j]; }, [&]() {
+                if (!SPARSE) {
+                    __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): the value tile has landed
+                    wave_sync();
+                }
                 // in flight during the read-out and the linear map: the next hop's keys, or the next query's first keys
                 if (h + 1 < H) load_keys_of(h + 1, r0, S);
                 else if (qn < n_query) {
                     load_keys_of(0, r0n, Sn);
                     u_next = (lane < D) ? a.u0[qn * D + lane] : 0.0f;
                 }
-            });
+            }, vg);
         }
         if (lane < D) a.u_out[q * D + lane] = relu_if(u, a.en_non_lin != 0);
         r0 = r0n; S = Sn;
@@ -428,21 +467,21 @@ inline bool lean_supported(const HopArgs &a, uint32_t max_slots, uint32_t key_ro
            !a.tap_o && !a.tap_u && getenv("QMANN_NO_LEAN") == nullptr;
 }
 
-template <int MODE, int NB, bool W7>
+template <int MODE, int NB, bool W7, bool SPARSE>
 inline void launch_lean_w(HopArgs a, uint32_t max_slots, uint32_t n_query, hipStream_t st)
 {
     LeanArgs la{};
-    la.rows_pad = ((max_slots ? max_slots : 1u) + 15u) & ~15u;
+    la.rows_pad = SPARSE ? 0u : ((max_slots ? max_slots : 1u) + 15u) & ~15u;       // (SPARSE: no value tile)
     la.exp_table = (MODE == kModeFixed && a.softmax_base == QMANN_SOFTMAX_EXP && !a.softmax_shift && !a.en_att_scale) ? 1u : 0u;
     la.lm_in_lds = a.en_lin_map ? 1u : 0u;
     a.rows_total = n_query;                                               // (the kernel has no taps: the field carries the query count)
     const size_t lds = (la.exp_table ? a.n_hop * 1024u : 0u) + (la.lm_in_lds ? a.n_hop * kLmHopBytes : 0u) +
                        (size_t)kLeanWaves * (la.rows_pad * 64u + kLwBytes);
     if (lds > kLdsDefaultLimit)
-        QM_HIP(hipFuncSetAttribute((const void *)k_hops_lean<MODE, NB, W7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        QM_HIP(hipFuncSetAttribute((const void *)k_hops_lean<MODE, NB, W7, SPARSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint32_t need = (n_query + kLeanWaves - 1) / kLeanWaves;
     const uint32_t resident = 256u * (uint32_t)(160u * 1024u / (lds + 256u) > 8 ? 8 : 160u * 1024u / (lds + 256u));
-    k_hops_lean<MODE, NB, W7><<<need < resident ? need : resident, kLeanBlock, lds, st>>>(a, la);
+    k_hops_lean<MODE, NB, W7, SPARSE><<<need < resident ? need : resident, kLeanBlock, lds, st>>>(a, la);
 }
 
 template <int MODE, int NB>
@@ -451,8 +490,19 @@ inline void launch_lean(const HopArgs &a, uint32_t max_slots, uint32_t n_query, 
     bool w7 = true;
     for (uint32_t h = 0; h < a.n_hop; h++)
         w7 = w7 && (MODE != kModeFixed || a.att[h].iwl + a.att[h].frac == 7) && (!a.en_lin_map || a.w[h].iwl + a.w[h].frac == 7);
-    if (w7) launch_lean_w<MODE, NB, true>(a, max_slots, n_query, st);
-    else launch_lean_w<MODE, NB, false>(a, max_slots, n_query, st);
+    // Sparse read-out (only the value rows that survive Q(p) are fetched, lean_hop) where those rows -- at most 2^frac_act per
+    // hop -- are a small part of the longest story; otherwise the whole value tile is copied to LDS at the start of the hop.
+    // QMANN_LEAN_SPARSE=0 / 1 forces the choice (A/B).
+    // Measured (A/B, 262 144 queries): 50-row stories +16 % (the whole-tile read doubled the HBM traffic of a kernel that was bound
+    // by it), the real 20-task set (2 .. 64 rows, mean 9.3) -1.4 % (the tile arrives during the scan, the sparse rows only during
+    // the linear map): the choice goes by the MEAN story length, which the launch knows from the plane size.
+    uint32_t surv = 1;
+    for (uint32_t h = 0; h < a.n_hop; h++) surv = surv > (1u << a.act[h].frac) ? surv : (1u << a.act[h].frac);
+    const uint32_t mean_slots = (a.rows_total && n_query) ? a.rows_total / n_query : max_slots / 8u;     // (tied hops: no plane size; real stories are short next to their cap)
+    bool sparse = surv * 4u <= mean_slots;
+    if (const char *e = getenv("QMANN_LEAN_SPARSE")) sparse = e[0] == '1';
+    if (w7) { if (sparse) launch_lean_w<MODE, NB, true, true>(a, max_slots, n_query, st); else launch_lean_w<MODE, NB, true, false>(a, max_slots, n_query, st); }
+    else { if (sparse) launch_lean_w<MODE, NB, false, true>(a, max_slots, n_query, st); else launch_lean_w<MODE, NB, false, false>(a, max_slots, n_query, st); }
 }
 
 }  // namespace

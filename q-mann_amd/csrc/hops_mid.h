@@ -211,7 +211,7 @@ k_hops_mid(const HopArgs a, const LeanArgs la)
                     }
                 }
             }
-            lean_finish_hop<W7>(a, h, lane, lw, lmap, u, acc, kb_code, csc, csh, wl_w == wl_m && !relu);
+            lean_finish_hop<W7>(a, h, lane, lw, lmap, u, [&]() { return acc; }, kb_code, csc, csh, wl_w == wl_m && !relu);
         }
         if (lane < D) a.u_out[(size_t)q * D + lane] = relu_if(u, a.en_non_lin != 0);
         r0 = r0n; S = Sn; regular = regular_n;

@@ -77,6 +77,18 @@ def test_lean_equals_general_all_modes(env, mode, nb, D):
     both_paths(env, cfg_of(mode, D=D, nb=nb), B=300, S_list=[0, 1, 2, 3, 9, 10, 16, 17, 33, 50, 63, 64], seed=100 + mode * 7 + D)
 
 
+@pytest.mark.parametrize("sparse", ["0", "1"])
+@pytest.mark.parametrize("mode,iwl", [(2, 5), (2, 2), (2, 6), (3, 5), (11, 3), (10, 5)])
+def test_lean_value_tile_and_sparse_read_out_agree_with_the_general_kernel(env, monkeypatch, mode, iwl, sparse):
+    """the lean kernel either copies a story's whole value tile to LDS or fetches only the rows whose weight code Q(p) is not
+    zero (the launcher chooses by mean story length and 2^frac; QMANN_LEAN_SPARSE forces it): both against the general kernel,
+    with formats of 1, 2, 4 and 5 fraction bits (up to 2, 4, 16, 32 surviving rows: several fetch rounds) and flat scores
+    (small sigma_k: many rows share the weight)"""
+    monkeypatch.setenv("QMANN_LEAN_SPARSE", sparse)
+    for sk in (30.0, 1.5):
+        both_paths(env, cfg_of(mode, iwl=iwl), B=200, S_list=[0, 1, 2, 5, 16, 17, 40, 50, 64], seed=40 + mode + iwl, sigma_k=sk)
+
+
 @pytest.mark.parametrize("mode,nb", [(3, 8), (10, 8), (11, 4)])
 @pytest.mark.parametrize("iwl", [5, 3])
 def test_lean_equals_general_hamming_under_mixed_quantisation(env, mode, nb, iwl):
