@@ -884,8 +884,9 @@ def run_workload(args, name, dev, rank, world):
     if mode == 1:
         counted = "keys + values (float read-out streams both)"
     elif lean:
-        counted = ("key planes only (the algorithmic figure of the long memories); with <= 64 slots most value rows survive "
-                   "Q(p), so this kernel streams the value plane as well: `traffic` is about keys + values")
+        counted = ("key planes only (the algorithmic figure of the long memories).  The one-wavefront kernel fetches only the value rows "
+                   "whose weight code Q(p) is not zero (<= 2^frac per hop) when stories are long next to that bound (mean slots >= 4 . 2^frac: "
+                   "this workload at 50 slots), and copies a short story's whole value tile otherwise (`traffic` is then about keys + values)")
     else:
         counted = "key planes only: Q(p) = 0 for all but <= 2^frac rows, the value plane is not streamed"
     if wl["ans"] == "i8":
