@@ -184,8 +184,18 @@ k_hops_ham(const HopArgs a, const uint32_t key_row_bytes, const uint32_t lds_slo
             for (uint32_t r = tid; r < S; r += kBlock) part += (double)sm_exp(slot_x(r) - xmax, smc);
             const double total = block_sum_double(part, red, lane, wave);
             const size_t tb = (size_t)h * a.rows_total + r0;
+            // Q(p) != 0 needs p >= 2^-frac, and p -- e / total in double then float, or e / (float)total -- is within 2^-23
+            // relative of the exact quotient: a slot with e < total . 2^-frac . (1 - 2^-20) cannot reach it, and only the others
+            // (a handful of 10 000) take the double-precision division and the quantiser.  That division per SLOT was a fifth of
+            // this kernel's vector instructions in mode 3 (4.78 lane-operations per key byte against 3.9 in the scan loop).
+            // With taps every slot's p is wanted, and the shift-based forms divide by a power of two up to sqrt(2) away from
+            // the total: threshold 0, every slot takes the exact path.
+            const bool every = a.tap_codes || a.tap_scores || a.tap_probs || smc.shift;
+            const float thr = every ? 0.0f : (float)(total * (double)qm_scale_down(1.0f, fa.frac) * (1.0 - 9.5367431640625e-07));
             for (uint32_t r = tid; r < S; r += kBlock) {
-                const float p = sm_quot(sm_exp(slot_x(r) - xmax, smc), total, smc);
+                const float e = sm_exp(slot_x(r) - xmax, smc);
+                if (!(e >= thr)) continue;
+                const float p = sm_quot(e, total, smc);
                 if (a.tap_codes) a.tap_codes[tb + r] = sc[r];
                 if (a.tap_scores) a.tap_scores[tb + r] = (float)sc[r] * scale;
                 if (a.tap_probs) a.tap_probs[tb + r] = p;
