@@ -1339,9 +1339,10 @@ int qmann_answer_f32(const qmann_net *net, const float *w_ans, const float *u, c
     if (lds > 48 * 1024)
         QM_HIP(hipFuncSetAttribute((const void *)k_answer<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // lanes per query / logits per lane / queries per lane group.  Short dictionaries: 16 lanes (one DPP row), four
-    // queries side by side in a wavefront (the reductions are most of the work there); the joint-task sizes: the whole
+    // lane groups side by side in a wavefront (the reductions are most of the work there); the joint-task sizes: the whole
     // wavefront on four queries at once, every weight read from LDS used four times (that kernel is bound by LDS reads)
-    const uint32_t lpq = V <= 128 ? 16u : 64u, qb = V <= 128 ? 1u : 4u;
+    // (two queries per lane group up to 96 logits: -6 % on this kernel at V = 80; with 8 logits per lane the second query's state spills)
+    const uint32_t lpq = V <= 128 ? 16u : 64u, qb = V <= 96 ? 2u : (V <= 128 ? 1u : 4u);
     uint32_t vpt = (V + lpq - 1) / lpq;
     vpt = vpt <= 2 ? 2u : vpt <= 4 ? 4u : vpt <= 6 ? 6u : 8u;
     const uint32_t qpw = kWave / lpq * qb;
@@ -1360,9 +1361,9 @@ int qmann_answer_f32(const qmann_net *net, const float *w_ans, const float *u, c
             QM_ANS_SMALL(64, 4, 4);                         // V in 129 .. 256
         } else {
             switch (vpt) {
-            case 2: QM_ANS_SMALL(16, 2, 1); break;
-            case 4: QM_ANS_SMALL(16, 4, 1); break;
-            case 6: QM_ANS_SMALL(16, 6, 1); break;
+            case 2: QM_ANS_SMALL(16, 2, 2); break;
+            case 4: QM_ANS_SMALL(16, 4, 2); break;
+            case 6: QM_ANS_SMALL(16, 6, 2); break;
             default: QM_ANS_SMALL(16, 8, 1); break;
             }
         }
