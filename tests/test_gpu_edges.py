@@ -123,6 +123,13 @@ def test_caller_errors_come_back_as_codes(env):
     taps = abi.Taps(0, 0, 0, u0.data_ptr(), 0)
     rc = abi.lib.qmann_hops_i8(C.byref(net.net), p(keys), p(keys), 0, p(ro), S, p(u0), p(u1), C.byref(taps), B, None)
     assert rc == abi.QMANN_EINVAL
+    # qmann_pack_bitplanes reads 16 bytes per lane and stores 8: a misaligned array is refused, not faulted on
+    planes = torch.zeros((rows, 1, 8), dtype=torch.int64, device=env.dev)
+    pack = lambda k, pl, nb: abi.lib.qmann_pack_bitplanes(k, pl, rows, 64, nb, None)
+    assert pack(p(keys), p(planes), 8) == 0
+    assert pack(C.c_void_p(keys.data_ptr() + 1), p(planes), 8) == abi.QMANN_EINVAL
+    assert pack(p(keys), C.c_void_p(planes.data_ptr() + 4), 8) == abi.QMANN_EINVAL
+    assert pack(p(keys), p(planes), 9) == abi.QMANN_EINVAL and pack(None, p(planes), 8) == abi.QMANN_EINVAL
     torch.cuda.synchronize()
 
 
