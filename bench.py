@@ -6,13 +6,19 @@
 One "step" = one pass of the hot path (all hops of every query, then the answer layer) over
 one resident batch of synthetic queries.  Prints ONE JSON line (rank 0).
 
-Workloads (config.workload):
+Workloads (config.workload; `--workload NAME` runs one alone):
   synth10k_d128   BASELINE.json configs[3], one GPU's shard: |memory| = 10 000 slots, D = 128,
                   int8 Q5.2 (run.sh default iwl = 5), 3 hops, fixed-point dot attention
                   (ATTENTION_MODE 2), 8 192 queries per GPU, per-query memories (62.9 GB).  Default:
                   this is the configuration the north-star roofline target is quoted on.
-  babi_mem50      bAbI-shaped: |memory| = 50 (MAX_SEN_LEN cap), D = 60, V = 30+50, 3 hops, int8 --
-                  the |mem| = 50 size of BASELINE.json's metric string; latency/VALU bound.
+The DEFAULT line (no --workload) carries, beside that headline, one object per BASELINE.json config under `configs`
+(each: value, ms_per_step, roofline or "QPS only" as SURVEY.md 8(d) says, cpu_baseline) -- all under the driver's clock:
+  mem50  babi_mem50             |memory| = 50 (MAX_SEN_LEN cap), D = 60: the size BASELINE.json's metric string names
+                                (also promoted to top-level keys mem50_queries_per_s / mem50_roofline_frac)
+  cfg2   babi_task1_idx         configs[1]: bAbI task 1, 3 hops, int8, dot attention, whole forward from word indices
+  cfg3   babi_joint20_appx_mq   configs[2] as the stock define.h builds it: 20-task joint, ATTENTION_MODE 3, EN_MQ
+  cfg4   synth10k_d128_q25      configs[3] as SURVEY.md 8(d) specifies it: Q2.5, codes N(0, 6), int8 answer matrix
+  cfg5   synth10k_d256_ham      configs[4]: D = 256, binary-code Hamming attention + int8 MFMA output GEMM
 
 N > 1: one rank per GPU.  Either the caller starts the ranks (torch.distributed.run sets WORLD_SIZE /
 RANK / LOCAL_RANK) or, when `--gpus N` is given with no WORLD_SIZE in the environment, this script
@@ -54,6 +60,9 @@ WORKLOADS = {
     # S slots, D, V, B queries per GPU, attention mode (define.h:10-15; 10 = packed popcount V0), planes,
     # answer layer ("f32" | "i8" = int8 MFMA), sigma of key/query codes and of value codes
     "synth10k_d128": dict(S=10000, D=128, V=256, B=8192, mode=2, nb=8, ans="f32", sk=3.5, sv=30.0, su=3.5),
+    # BASELINE.json configs[3] EXACTLY as SURVEY.md 8(d) words it: format Q2.5 (define.h:18-19's commented preset), key / value /
+    # query codes clip(round(N(0, 6)), +-127), linear-map codes sigma 6, int8 answer matrix [256][128] (the MFMA projection)
+    "synth10k_d128_q25": dict(S=10000, D=128, V=256, B=8192, mode=2, nb=8, ans="i8", sk=6.0, sv=6.0, su=6.0, iwl=2, wh_codes=6.0),
     "synth10k_d256_ham": dict(S=10000, D=256, V=256, B=8192, mode=10, nb=1, ans="i8", sk=30.0, sv=30.0, su=30.0),
     # config 5 with the larger of its two dictionary sizes (V in {256, 4 096}): the int8 MFMA projection is 17 GOP
     "synth10k_d256_ham_v4096": dict(S=10000, D=256, V=4096, B=8192, mode=10, nb=1, ans="i8", sk=30.0, sv=30.0, su=30.0),
@@ -92,6 +101,9 @@ WORKLOADS["babi_joint20_v1_tied"] = dict(S=64, D=60, V=238, B=262000, mode=11, n
 # record files (replicated), labels from the files: reports queries/s AND the test error, beside the err(test) the reference
 # program itself printed for these weights
 WORKLOADS["babi_task1_trained"] = dict(S=10, D=60, V=0, B=262000, mode=2, nb=8, ans="f32", trained=True)
+# the default line's secondary configs: (key under `configs`, workload, with the >= 1 s sustained window)
+SECONDARY = [("mem50", "babi_mem50", True), ("cfg2", "babi_task1_idx", False), ("cfg3", "babi_joint20_appx_mq", False),
+             ("cfg4", "synth10k_d128_q25", False), ("cfg5", "synth10k_d256_ham", False)]
 KERNEL_OF_MODE = {1: "k_hops_float", 2: "k_hops_fixed", 3: "k_hops_ham", 10: "k_hops_ham", 11: "k_hops_ham"}
 
 
@@ -104,6 +116,81 @@ def with_bcast(out, bcast):
         out["param_broadcast_ms"] = bcast["ms"]
         out["param_broadcast"] = bcast
     return out
+
+
+def data_rank(rank: int) -> int:
+    """Which rank's synthetic data this process generates: its own -- or, for a one-rank run that stands in for rank r of
+    an N-rank job (tests/test_gpu_dist.py compares the two), QMANN_BENCH_AS_RANK = r."""
+    return int(os.environ.get("QMANN_BENCH_AS_RANK", rank))
+
+
+def shard_report(out, pred, B, rank, world, dev):
+    """Which global queries each rank owned ([lo, hi) in rank order: weak scaling, rank r owns [r B, (r + 1) B)) and the CRC-32
+    of each rank's last-step predictions (rank 0 collects them; one small all-gather after the timed region)."""
+    import zlib
+    crc = zlib.crc32(pred.to(torch.int32).cpu().numpy().tobytes())
+    r = data_rank(rank)
+    if world == 1:
+        out["shards"] = [[r * B, (r + 1) * B]]
+        out["pred_crc32"] = [crc]
+        return
+    import torch.distributed as dist
+    t = torch.tensor([float(r * B), float((r + 1) * B), float(crc)], dtype=torch.float64, device=dev)
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t)
+    m = torch.stack(parts).cpu().numpy()
+    out["shards"] = [[int(a), int(b)] for a, b, _ in m]
+    out["pred_crc32"] = [int(c) for _, _, c in m]
+
+
+def _round(x, sig=6):
+    if isinstance(x, float):
+        return float(f"{x:.{sig}g}")
+    if isinstance(x, dict):
+        return {k: _round(v, sig) for k, v in x.items()}
+    if isinstance(x, list):
+        return [_round(v, sig) for v in x]
+    return x
+
+
+def compact(res, primary=False):
+    """A result dict reduced to what the driver-timed line needs (the driver keeps a few KB of stdout): numbers to six
+    digits, no prose beyond short labels.  `--workload NAME` alone prints the full record."""
+    keep_cfg = ("workload", "slots", "dim_emb", "hops", "queries_per_gpu", "format", "attention_mode", "key_row_bytes",
+                "answer_layer", "dim_answer", "num_bit", "input", "parallelism")
+    keep_roof = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "bytes_per_query",
+                 "kernel_ms", "frac_sustained", "frac_by_survey_formula")
+    out = {k: res[k] for k in (("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                "vs_baseline", "dtype", "data") if primary else ("value", "unit", "ms_per_step", "data")) if k in res}
+    out["config"] = {k: v for k, v in res["config"].items() if k in keep_cfg}
+    r = res["roofline"]
+    out["roofline"] = {k: r[k] for k in keep_roof if k in r}
+    if "whole forward" in str(r.get("kernel", "")):
+        out["roofline"]["kernel"] = "whole forward"
+        out["roofline"]["note"] = "QPS only (SURVEY 8(d): latency-bound size); achieved = input bytes / time"
+    elif r.get("traffic") is None:
+        out["roofline"]["traffic_note"] = str(r.get("traffic_source") or "no counter pass on these kernel sources")[:60]
+    else:
+        out["roofline"]["traffic_note"] = "rocprofv3 --pmc FETCH_SIZE pass (profiles/), x2 gfx950 correction"
+    c = res.get("cpu_baseline")
+    if c:
+        out["cpu_baseline"] = {"value": c["value"], "unit": c["unit"], "cores": c["cores"], "kind": c["kind"], "flags": c.get("flags"),
+                               "sample": c["sample"][:150], "one_thread": c.get("one_thread", {}).get("value"),
+                               "reference_flags_value": c.get("reference_flags", {}).get("value"),
+                               "pred_agree": c.get("pred_agree"), "pred_total": c.get("pred_total")}
+    a = res.get("answer_layer")
+    if a:
+        out["answer_layer"] = {k: a[k] for k in ("ms", "tops", "tflops", "frac_of_int8_peak", "mfma_busy_frac_counters") if k in a}
+    if "sustained" in res:
+        su = res["sustained"]
+        out["sustained"] = {k: su[k] for k in ("steps", "seconds", "queries_per_s", "kernel_ms", "frac") if k in su}
+    for k in ("param_broadcast_ms", "param_broadcast", "ranks", "shards", "pred_crc32", "accuracy"):
+        if k in res and (primary or k in ("accuracy",)):
+            out[k] = res[k]
+    if "accuracy" in out:
+        out["accuracy"] = {k: out["accuracy"][k] for k in ("test_error_from_labels", "reference_program_err_test", "equals_reference_program")
+                           if k in out["accuracy"]}
+    return _round(out)
 
 
 def gauss_i8(shape, sigma, gen, dev, pad_from=None):
@@ -122,9 +209,9 @@ def gauss_i8(shape, sigma, gen, dev, pad_from=None):
     return out
 
 
-def make_params(cfg, D, V, seed):
+def make_params(cfg, D, V, seed, wh_sigma=None):
     rng = np.random.default_rng(seed)
-    sig = float(os.environ.get("QMANN_BENCH_WH_SIGMA", "1.0"))      # (experiments: how dense the per-product clamps of the linear map are)
+    sig = float(os.environ.get("QMANN_BENCH_WH_SIGMA", "1.0")) if wh_sigma is None else wh_sigma   # (env: clamp-density experiments)
     return {"w_h": [rng.normal(0, sig, (D, D)).astype(np.float32) for _ in range(cfg["n_hop"])],
             "w_ans": rng.normal(0, 0.1, (V, D)).astype(np.float32)}
 
@@ -254,8 +341,13 @@ def cpu_baseline_port(cfg, wts, pool, what, gpu_preds=None, budget_s=6.0):
     return out
 
 
+CPU_BUDGET_S = 4.0              # seconds per timed CPU leg (4 legs per workload: -O2 / -O0 x 1 thread / all cores); the default
+                                # line's secondary configs use a shorter one so that the whole run stays within minutes
+
+
 def cpu_baseline(cfg, wts, pool, what, gpu_preds=None):
-    return cpu_baseline_refport(cfg, wts, pool, what, gpu_preds) or cpu_baseline_port(cfg, wts, pool, what, gpu_preds)
+    return (cpu_baseline_refport(cfg, wts, pool, what, gpu_preds, budget_s=CPU_BUDGET_S)
+            or cpu_baseline_port(cfg, wts, pool, what, gpu_preds, budget_s=CPU_BUDGET_S))
 
 
 def run_bow(args, name, wl, net, cfg, wts, hm, dev, rank, world, model):
@@ -333,6 +425,7 @@ def run_bow(args, name, wl, net, cfg, wts, hm, dev, rank, world, model):
                      "frac": bytes_in * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, "traffic": None},
         "accuracy_note": "random weights: predictions are compared with the oracle, not with labels",
     }
+    shard_report(res, out["pred"], B, rank, world, dev)
     # the batched API takes device pointers; when the host owns the stories, one bulk H2D copy per batch
     # (cuda_data_in's role, lib/layer_cuda.cu:3960-4035) precedes it.  Measured from pinned memory, serial
     # with the compute (no overlap): reported beside `value`, never as `value`.
@@ -459,6 +552,7 @@ def run_joint(args, name, wl, cfg, wts, hm, dev, rank, world, model):
                      "frac": bytes_in * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, "traffic": None},
         "accuracy_note": "random weights: predictions are compared with the oracle, not with labels",
     }
+    shard_report(res, out[0], B, rank, world, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         V, dd = cfg["dim_input"], int(g["dim_dict"])
         offs = np.concatenate([[0], np.cumsum(n_sen)]).astype(np.int64)
@@ -541,6 +635,7 @@ def run_trained(args, name, wl, dev, rank, world, model, abi, replicate_model):
                      "reference_run": {k: rec[k] for k in ("binary", "argv", "verify_line", "train_error_first_epoch", "train_error_last_epoch", "epochs")},
                      "chance_error": 5.0 / 6.0},
     }
+    shard_report(res, out[0], B, rank, world, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         offs = ds["row_off"].astype(np.int64)
         pick = list(range(0, nq, 5))
@@ -556,10 +651,12 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="synth10k_d128", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="one workload alone (default: synth10k_d128 as the headline + every BASELINE config under `configs`)")
+    ap.add_argument("--secondary-cpu-s", type=float, default=1.2, help="CPU-baseline seconds per leg for the secondary configs")
     ap.add_argument("--queries", type=int, default=0, help="queries per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="default workload only: skip the |mem| = 50 figure")
+    ap.add_argument("--no-secondary", action="store_true", help="default line: the headline workload only")
     ap.add_argument("--no-sustained", action="store_true", help="skip the second, longer timing window")
     ap.add_argument("--sustain-s", type=float, default=2.0, help="length of the sustained window in seconds (default 2)")
     return ap.parse_args(argv)
@@ -653,15 +750,31 @@ def main(argv=None):
             if int(ok.item()) == 0 and COMM is not None:
                 COMM.close()
                 COMM, comm_info = None, {"error": "another rank could not join the C-level communicator"}
-        out = run_workload(args, args.workload, dev, rank, world)
-        # BASELINE.json quotes its metric at |mem| = 50 (the bAbI cap) and sets its target at |mem| = 10 000:
-        # the default line is the 10 000-slot configuration and carries the 50-slot figure beside it
-        if args.workload == "synth10k_d128" and not args.no_secondary:
-            sec = run_workload(argparse.Namespace(**{**vars(args), "queries": 0}), "babi_mem50", dev, rank, world)
+        default_line = args.workload is None
+        name = args.workload or "synth10k_d128"
+        out = run_workload(args, name, dev, rank, world)
+        # BASELINE.json quotes its metric at |mem| = 50 (the bAbI cap) and sets its target at |mem| = 10 000: the default
+        # line's `value` is the 10 000-slot configuration; beside it, under `configs`, one object per BASELINE.json config
+        # (SECONDARY above), all timed inside this one driver-clocked run; the |mem| = 50 figures are top-level keys too
+        if default_line and not args.no_secondary:
+            global CPU_BUDGET_S
+            CPU_BUDGET_S = args.secondary_cpu_s
+            cfgs = {}
+            for key, wname, sus in SECONDARY:
+                torch.cuda.empty_cache()
+                a2 = argparse.Namespace(**{**vars(args), "queries": 0, "no_sustained": args.no_sustained or not sus, "sustain_s": 1.0})
+                sec = run_workload(a2, wname, dev, rank, world)
+                if rank == 0:
+                    cfgs[key] = compact(sec)
             if rank == 0:
-                out["mem50"] = {k: sec[k] for k in ("value", "unit", "ms_per_step", "config", "roofline", "sustained", "cpu_baseline", "ranks") if k in sec}
-                out["config"]["value_is"] = ("the |mem| = 10 000 shard (BASELINE.json configs[3], the configuration the north-star "
-                                             "roofline target is set on); `mem50` is the |mem| = 50 size the metric string names")
+                out = compact(out, primary=True)
+                out["configs"] = cfgs
+                m50 = cfgs["mem50"]
+                out["mem50_queries_per_s"] = m50["value"]
+                out["mem50_roofline_frac"] = m50["roofline"]["frac"]
+                out["mem50_kernel_ms"] = m50["roofline"]["kernel_ms"]
+                out["config"]["value_is"] = "cfg4 shard at Q5.2 (roofline target); BASELINE metric size |mem|=50: mem50_* keys"
+                out["config"]["mem50"] = {"queries_per_s": m50["value"], "roofline_frac": m50["roofline"]["frac"]}
     if rank == 0:
         if world > 1:
             out["collective"] = {"backend": backend, "world_size_seen": world,
@@ -691,16 +804,19 @@ def rank_stats(world, dev, **vals):
 
 
 def run_plumbing(args, rank, world):
-    """The N > 1 host logic with no GPU: parameters made on rank 0 and broadcast once, a barrier-bracketed timed
-    region, max over ranks, per-rank statistics -- over gloo on CPU tensors.  Measures nothing."""
-    load_pkg_parallel = importlib.util.spec_from_file_location("qmann_parallel", ROOT / "q-mann_amd" / "parallel.py")
-    par = importlib.util.module_from_spec(load_pkg_parallel)
-    load_pkg_parallel.loader.exec_module(par)
+    """The N > 1 host logic with no GPU: rank 0 holds the committed QUANTISED parameter blob of the trained task-1 model
+    (tests/golden/trained_qa1/params_q.blob: the bytes qmann_comm_broadcast_params moves on GPUs), it is broadcast once over
+    gloo and vetted on every rank with the library's host-side qmann_params_validate; then a barrier-bracketed timed region,
+    max over ranks, per-rank statistics.  Measures nothing."""
+    import zlib
+    load_pkg()
+    from qmann_amd import parallel as par
     dev = torch.device("cpu")
-    cfg = dict(n_hop=3, dim_emb=8, dim_input=12)
-    wts = make_params(cfg, 8, 12, seed=0x51A44) if rank == 0 else None
-    wts, bcast_ms = par.broadcast_params(wts, cfg, dev, rank, world)
-    check = float(sum(float(np.abs(w).sum()) for w in wts["w_h"]) + float(np.abs(wts["w_ans"]).sum()))
+    blob_file = ROOT / "tests" / "golden" / "trained_qa1" / "params_q.blob"
+    raw, bcast_ms = blob_file.read_bytes() if rank == 0 else None, None
+    if world > 1:
+        raw, bcast_ms = par.broadcast_blob(raw, rank, world, dev)
+    net = par.blob_net(raw)                                          # (validates; the dimensions come out of the blob)
     B = 64
     lo, hi = par.shard_range(B * world, rank, world)
     if world > 1:
@@ -719,10 +835,12 @@ def run_plumbing(args, rank, world):
     out = {"metric": "plumbing (nothing measured)", "value": 0.0, "unit": "queries/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int8", "data": "none",
-           "config": {"workload": "plumbing", "shard": [lo, hi], "parallelism": f"replicas x{world}, query-sharded"}}
+           "config": {"workload": "plumbing", "shard": [lo, hi], "parallelism": f"replicas x{world}, query-sharded",
+                      "blob": {"bytes": len(raw), "dim_emb": net["dim_emb"], "dim_input": net["dim_input"], "n_hop": net["n_hop"]}}}
     if bcast_ms is not None:
         out["param_broadcast_ms"] = bcast_ms
-    st = rank_stats(world, dev, param_checksum=check, shard_size=hi - lo, rank=rank)
+        out["param_broadcast"] = {"ms": bcast_ms, "bytes": len(raw), "how": "process-group broadcast of the quantised blob (gloo)"}
+    st = rank_stats(world, dev, param_crc32=zlib.crc32(raw), shard_lo=lo, shard_hi=hi, shard_size=hi - lo, rank=rank)
     if st:
         out["ranks"] = st
     return out
@@ -743,7 +861,9 @@ def run_workload(args, name, dev, rank, world):
     S, D, V, mode, nb = wl["S"], wl["D"], wl["V"], wl["mode"], wl["nb"]
     B = args.queries or wl["B"]
     H = 3
-    cfg = model.babi_cfg(V, attention_mode=mode, softmax_base=0, iwl=5, n_hop=H, D=D, en_mq=bool(wl.get("bow") or wl.get("mq")))
+    iwl = int(wl.get("iwl", 5))
+    frac = 7 - iwl
+    cfg = model.babi_cfg(V, attention_mode=mode, softmax_base=0, iwl=iwl, n_hop=H, D=D, en_mq=bool(wl.get("bow") or wl.get("mq")))
     cfg["num_bit"] = nb
     if os.environ.get("QMANN_BENCH_NO_LINMAP"):            # experiment: what the in-kernel linear map costs
         cfg["en_lin_map"] = False
@@ -755,7 +875,7 @@ def run_workload(args, name, dev, rank, world):
     ans_fmt = (1, 6)
     hm = None
     if rank == 0:
-        wts = make_params(cfg, D, V, seed=0x51A44)
+        wts = make_params(cfg, D, V, seed=0x51A44, wh_sigma=(wl["wh_codes"] / (1 << frac)) if "wh_codes" in wl else None)
         rng = np.random.default_rng(0xBAB1)      # embedding matrices (the synthetic-memory workloads carry but do not use them)
         wts["w_q"] = rng.normal(0, 1.0, (D, V)).astype(np.float32)
         wts["w_a"] = [rng.normal(0, 1.0, (D, V)).astype(np.float32) for _ in range(H)]
@@ -781,10 +901,10 @@ def run_workload(args, name, dev, rank, world):
 
     # synthetic per-query memories, resident in HBM before the timed region
     gen = torch.Generator(device=dev)
-    gen.manual_seed(0x51A44 + rank)
+    gen.manual_seed(0x51A44 + data_rank(rank))
     keys = gauss_i8((H, B * S, Dp), wl["sk"], gen, dev, pad_from=D)
     vals = gauss_i8((H, B * S, Dp), wl["sv"], gen, dev, pad_from=D)
-    u0 = (torch.randn((B, D), device=dev, generator=gen) * wl["su"]).round_().clamp_(-127, 127) / 4.0
+    u0 = (torch.randn((B, D), device=dev, generator=gen) * wl["su"]).round_().clamp_(-127, 127) / float(1 << frac)
     row_off = (torch.arange(B + 1, device=dev, dtype=torch.int64) * S).to(torch.int32)
     u_out = torch.empty_like(u0)
     key_row_bytes = Dp
@@ -901,7 +1021,7 @@ def run_workload(args, name, dev, rank, world):
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int8", "data": "synthetic",
         "config": {"workload": name, "slots": S, "dim_emb": D, "dim_emb_pad": Dp, "hops": H,
-                   "queries_per_gpu": B, "format": "Q5.2", "attention_mode": mode,
+                   "queries_per_gpu": B, "format": f"Q{iwl}.{frac}", "attention_mode": mode,
                    "key_row_bytes": key_row_bytes, "answer_layer": wl["ans"], "dim_answer": V,
                    "parallelism": f"replicas x{world}, query-sharded"},
         "roofline": {"bound": "hbm", "kernel": "k_hops_lean" if lean else KERNEL_OF_MODE[mode], "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -936,6 +1056,7 @@ def run_workload(args, name, dev, rank, world):
     if st:
         out["ranks"] = st
     with_bcast(out, bcast)
+    shard_report(out, pred, B, rank, world, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         pool = mem_pool(cfg, keys, vals, u0, S, D)
         out["cpu_baseline"] = cpu_baseline(cfg, wts, pool, f"|mem| = {S}, D = {D}, {H} hops + answer layer",

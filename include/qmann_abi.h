@@ -299,7 +299,14 @@ unsigned int qmann_abi_symbol_count(void);
  * the last query is replayed verb by verb so that every layer's device buffer holds what the serial loop leaves there.
  * CONTRACT: device buffers written by forward verbs are up to date after the next non-forward cuda_* verb (as for the
  * reference host, which reads only through cuda_cross_entropy_*_load / cuda_copy_dev2host) or after qmann_abi_flush();
- * a host that reads them with its own hipMemcpy must call qmann_abi_flush() first, or switch the queue off.
+ * a host that reads them with its own hipMemcpy must call qmann_abi_flush() first, or switch the queue off.  The same call
+ * covers WRITES behind the library's back: the batched model built for a run of queries is cached, keyed on the weight
+ * pointers and formats (not on the values), and dropped by every cuda_* verb that can change a weight or an input pool;
+ * a host that overwrites weights or pools with its own hipMemcpy between two forward phases must call qmann_abi_flush(),
+ * which drains the record and forgets the cached model (the next run rebuilds it from the device matrices).
+ * A forward verb called with verbose = true is a synchronisation point too: the record is drained, the verb runs at once and
+ * prints its operands as the reference does (lib/layer_cuda.cu:13-47, 2450-2484).
+ * THREADS: the record is process-wide; the verbs serialise on one lock around it (recording, draining, these switches).
  *   mode 0: off -- every verb launches at once;  1: on (default);  2: verify -- every recognised run is computed BOTH ways,
  *   the verb-by-verb result goes into the accumulators and a line comparing the two match counts is printed on stderr.
  * Environment: QMANN_DEFER=0|1|verify (QMANN_NO_DEFER=1 = 0), QMANN_DEFER_STATS=1 prints the counters below at exit,

@@ -11,8 +11,9 @@
  * One rank = one GPU, driven by one host thread (threads of one process, as in examples/forward_sharded.c) or by one
  * process (as bench.py does under torch.distributed.run); the two set-ups use the same calls.
  *
- * librccl.so is loaded on first use (dlopen; QMANN_RCCL_PATH overrides the name), NOT linked: a host that never calls a
- * qmann_comm_* function -- the reference's unmodified single-GPU program among them -- does not load the 0.5 GB library.
+ * librccl.so is loaded on first use (dlopen), NOT linked: a host that never calls a qmann_comm_* function -- the
+ * reference's unmodified single-GPU program among them -- does not load the 0.5 GB library.  QMANN_RCCL_PATH, when set,
+ * is the only file tried (a process must hold ONE RCCL: point it at the copy the process already has).
  * Errors: QMANN_ECOMM when the library cannot be loaded or an RCCL call fails (message on stderr), QMANN_EHIP / QMANN_EINVAL
  * as elsewhere.
  */
@@ -38,6 +39,11 @@ void qmann_shard_range(uint32_t n_query, uint32_t rank, uint32_t world, uint32_t
  * qmann_comm_init_rank with its own GPU (hipSetDevice index; ranks of one communicator need distinct GPUs -- RCCL refuses
  * two ranks on one device).  The call blocks until all n_ranks have joined. */
 int qmann_comm_get_id(void *id /* QMANN_COMM_ID_BYTES */);
+/* Local and non-blocking: can this rank take part?  QMANN_OK when librccl loads with every entry point and `device` is a
+ * GPU of this process (device < 0: the library only); QMANN_ECOMM / QMANN_EHIP / QMANN_EINVAL otherwise.  A launcher has
+ * every rank call this and AGREE on the result (over whatever channel carried the id) BEFORE any rank enters
+ * qmann_comm_init_rank, which blocks until all n_ranks have joined: a rank that cannot join must keep the others out. */
+int qmann_comm_probe(int device);
 int qmann_comm_init_rank(qmann_comm **out, int n_ranks, int rank, const void *id, int device);
 void qmann_comm_destroy(qmann_comm *c);
 /* rank, size, GPU of this communicator and the RCCL version number the loaded library reports (any pointer may be NULL) */
@@ -45,8 +51,15 @@ int qmann_comm_info(const qmann_comm *c, int *rank, int *n_ranks, int *device, i
 
 /* The parameter broadcast.  On `root`, `root_model` is the model to replicate (NULL on the other ranks).  Every rank gets
  * *blob / *bytes: a device buffer on ITS GPU holding the root's parameter blob (the root gets a copy too), to be passed to
- * qmann_model_create_from_params and then released with qmann_params_free.  Two ncclBroadcast calls on `stream` (the size,
- * then the bytes); the call returns after synchronising the stream. */
+ * qmann_model_create_from_params and then released with qmann_params_free.  Collectives on `stream`: ncclBroadcast of the
+ * size, a one-word ncclAllGather (has every rank got its buffer?), ncclBroadcast of the bytes; the call returns after
+ * synchronising the stream.
+ * Errors keep the ranks in step: `c`, `root`, `blob`, `bytes` are checked first and must be valid on EVERY rank (same
+ * arguments, same verdict, no collective entered).  Whatever only ONE rank can get wrong is agreed on inside the call: a root
+ * without a valid model (NULL, empty, or on another GPU than the communicator's) still joins the size broadcast and sends 0
+ * -- it returns QMANN_EINVAL, the others QMANN_ECOMM; a rank whose buffer allocation fails still joins the status exchange --
+ * it returns QMANN_EHIP, the others QMANN_ECOMM, nobody enters the bytes broadcast.  Every rank has then returned and the
+ * communicator stays usable.  (An RCCL call that itself fails leaves the communicator undefined: destroy it on all ranks.) */
 int qmann_comm_broadcast_params(qmann_comm *c, int root, const qmann_model *root_model, void **blob, size_t *bytes, void *stream);
 void qmann_params_free(void *blob);
 

@@ -61,6 +61,14 @@ int qmann_model_params(const qmann_model *m, const void **blob, size_t *bytes);
  * Returns QMANN_EINVAL for a blob that is not one (magic, version, size or section offsets do not match). */
 int qmann_model_create_from_params(qmann_model **out, int device, const void *blob, size_t bytes, void *stream);
 
+/* Is this HOST buffer a parameter blob qmann_model_create_from_params would accept?  Pure host code, no GPU needed (a
+ * receiver can vet bytes that came over a wire or out of a file before any device is touched): magic and version, the size
+ * field against `bytes`, the net's dimensions (check of qmann_model_create), every Q-format (iwl + frac <= 7, the int8 word),
+ * enumerated fields in range, null lin_map pointers, and the section offsets against the canonical layout of those
+ * dimensions.  QMANN_OK, or QMANN_EINVAL / QMANN_EUNSUPPORTED exactly as create_from_params would answer.  When `net` is
+ * not NULL it receives the header's net (dimensions and formats of the model the blob holds). */
+int qmann_params_validate(const void *host_blob, size_t bytes, qmann_net *net);
+
 /* The net as the model uses it -- lin_map[h] filled with the device pointers into the blob -- and the answer matrix: for
  * hosts that drive qmann_hops_i8 / qmann_answer_f32 themselves on memories of their own but take the parameters from a
  * (broadcast) model.  Pointers are valid until the model is destroyed. */

@@ -49,6 +49,23 @@ class QoTaps(C.Structure):
                 ("u0", "keys", "vals", "scores", "probs", "o", "lu", "u", "logits", "out_probs")]
 
 
+def load_lazy(path) -> C.CDLL:
+    """Open one of oracle/_ref's shared objects with RTLD_LAZY.  They are the reference's objects + glue and nothing
+    else: layer.o's cuda_* imports stay undefined (no stand-ins are linked), which is fine as long as no such function is
+    ever CALLED (en_gpu_model = false everywhere here).  ctypes.CDLL always adds RTLD_NOW, so the handle comes from
+    dlopen itself.  RTLD_LOCAL: nothing else in the process binds to these symbols, and they cannot bind to a product
+    library the process may have loaded privately -- a stray cuda_* call ends the process with a symbol lookup error."""
+    import os
+    libc = C.CDLL(None)
+    libc.dlopen.restype = C.c_void_p
+    libc.dlopen.argtypes = [C.c_char_p, C.c_int]
+    libc.dlerror.restype = C.c_char_p
+    h = libc.dlopen(str(path).encode(), os.RTLD_LAZY | os.RTLD_LOCAL)
+    if not h:
+        raise OSError(f"dlopen({path}, RTLD_LAZY): {(libc.dlerror() or b'?').decode()}")
+    return C.CDLL(str(path), handle=h)
+
+
 class Oracle:
     def __init__(self, path: Path = ORACLE_SO):
         if not path.exists():
@@ -325,7 +342,7 @@ class Reference:
     def __init__(self, path: Path = REF_SO):
         if not path.exists():
             raise FileNotFoundError(f"{path} missing: run `make -C oracle ref` where /root/reference exists")
-        L = self.L = C.CDLL(str(path))
+        L = self.L = load_lazy(path)
         u, f = C.c_uint, C.c_float
         L.ref_float_quant.restype = f; L.ref_float_quant.argtypes = [f, u, u]
         L.ref_float2fixed.restype = C.c_int; L.ref_float2fixed.argtypes = [f, u, u]
@@ -387,7 +404,7 @@ class RefForward:
         path = HERE / "_ref" / f"libqmann_refcpu_{flags}.so"
         if not path.exists():
             raise FileNotFoundError(f"{path} missing: run `make -C oracle refcpu` where /root/reference exists")
-        L = self.L = C.CDLL(str(path))
+        L = self.L = load_lazy(path)
         u = C.c_uint
         pp = C.POINTER(_f32p)
         L.rf_create.restype = C.c_void_p; L.rf_create.argtypes = [C.POINTER(QoModel), u]

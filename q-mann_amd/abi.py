@@ -143,6 +143,7 @@ def defer_stats() -> dict:
 
 # ---- batched int8 API (include/qmann_batch.h) ----
 _proto("qmann_hops_lds_bytes", C.c_size_t, [C.c_uint32])
+_proto("qmann_tuning_reload", None, [])
 _proto("qmann_check_slots", C.c_int, [_vp, C.c_uint32, C.c_uint32, _vp, _vp])
 _proto("qmann_quantize_i8", C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, C.c_uint32, Fmt, C.c_int, _vp])
 _proto("qmann_hops_i8", C.c_int, [C.POINTER(Net), _vp, _vp, C.c_size_t, _vp, C.c_uint32, _vp, _vp,
@@ -168,11 +169,13 @@ _proto("qmann_model_create_on", C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(Net
 _proto("qmann_model_device", C.c_int, [_vp])
 _proto("qmann_model_params", C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)])
 _proto("qmann_model_create_from_params", C.c_int, [C.POINTER(_vp), C.c_int, _vp, C.c_size_t, _vp])
+_proto("qmann_params_validate", C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(Net)])
 _proto("qmann_model_net", C.c_int, [_vp, C.POINTER(Net), C.POINTER(_vp)])
 _proto("qmann_dequantize_table_f32", C.c_int, [_vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, Fmt, _vp])
 # ---- include/qmann_dist.h: shards, RCCL rendezvous, parameter broadcast ----
 COMM_ID_BYTES = 128
 _proto("qmann_shard_range", None, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)])
+_proto("qmann_comm_probe", C.c_int, [C.c_int])
 _proto("qmann_comm_get_id", C.c_int, [_vp])
 _proto("qmann_comm_init_rank", C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, _vp, C.c_int])
 _proto("qmann_comm_destroy", None, [_vp])

@@ -13,6 +13,7 @@
 #include "../../include/qmann_model.h"
 
 #include <chrono>
+#include <mutex>
 #include <stdlib.h>
 #include <string.h>
 #include <string>
@@ -21,7 +22,15 @@
 namespace qmdefer {
 namespace {
 
-constexpr size_t kQueueCap = 4u << 20;             // ops; a longer phase is drained at the next query boundary
+// ops; a longer phase is drained at the next query boundary.  About 4 000 queries of 31 verbs: batching gains nothing beyond
+// that, and the record (136 bytes per op) stays under 20 MB of host memory however long the host's test phase is.
+constexpr size_t kQueueCap = 1u << 17;
+
+// The verbs of boundary B are stateless launches in the reference; the record behind them is process-wide state, so every
+// entry into it (a forward verb recording itself, a synchronisation point draining, the switches below) takes this lock:
+// a host that calls cuda_* verbs from several threads gets them serialised, not a corrupted queue.  Recursive: a drain runs
+// library calls that are synchronisation points themselves.
+std::recursive_mutex g_lock;
 
 int g_mode = -1;                                    // Mode; -1 = not yet read from the environment
 std::vector<Op> g_queue;
@@ -463,6 +472,7 @@ void drain()
 
 bool submit(const Op &op)
 {
+    std::lock_guard<std::recursive_mutex> hold(g_lock);
     init_mode();
     if (g_mode == kOff || g_draining) return false;
     g_queue.push_back(op);
@@ -474,6 +484,7 @@ bool submit(const Op &op)
 
 void sync_point(bool writes)
 {
+    std::lock_guard<std::recursive_mutex> hold(g_lock);
     if (g_mode == kOff) return;
     init_mode();
     drain();
@@ -486,16 +497,20 @@ extern "C" {
 
 void qmann_abi_set_defer(int mode)
 {
+    std::lock_guard<std::recursive_mutex> hold(qmdefer::g_lock);
     qmdefer::init_mode();
     qmdefer::drain();
     qmdefer::g_mode = mode == 0 ? qmdefer::kOff : mode == 2 ? qmdefer::kVerify : qmdefer::kOn;
     if (mode == 2) { qmdefer::g_timing = true; qmdefer::exit_report(); }
 }
 
-void qmann_abi_flush(void) { qmdefer::sync_point(false); }
+// drains AND forgets the cached batched model: the cache is keyed on the weight POINTERS and formats, so a host that changes
+// weight values or input pools behind the library's back (its own hipMemcpy) must come through here (qmann_abi.h: CONTRACT)
+void qmann_abi_flush(void) { qmdefer::sync_point(true); }
 
 void qmann_abi_defer_stats(qmann_defer_stats *out)
 {
+    std::lock_guard<std::recursive_mutex> hold(qmdefer::g_lock);
     if (out) *out = qmdefer::g_stats;
 }
 

@@ -14,6 +14,7 @@
 // differs from the reference's serial loop (documented tolerance 1e-5 rel.).
 #include "qfmt.h"
 #include "rt.h"
+#include <vector>
 #include "defer.h"
 #include "../../include/qmann_abi.h"
 
@@ -387,6 +388,52 @@ int qmdefer::softmax_base() { return g_softmax_base; }
 
 using qmdefer::Op;
 
+namespace {
+
+// verbose = true on a forward verb: what the reference prints there (lib/layer_cuda.cu:13-47 -- one value per "%f, ", the
+// last of a row with a newline -- and the per-verb blocks :2450-2484, 2519-2553, 2868-2882, 3009-3027, 3210-3228, 3551-3567),
+// with the same labels, on stdout.  The reference prints from the device after cudaDeviceSynchronize(); here the verb is a
+// synchronisation point of the deferred queue (everything queued before it runs first), runs at once, and its operands are
+// copied back and printed by the host.
+void dump_head(const char *f_name)
+{
+    printf("\n< %s >\n", f_name);
+}
+void dump_vec(const char *label, const float *dev, unsigned n)
+{
+    printf("%s> dim: %u\n", label, n);
+    std::vector<float> h(n);
+    QM_HIP(hipDeviceSynchronize());
+    if (n) QM_HIP(hipMemcpy(h.data(), dev, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    for (unsigned i = 0; i < n; i++) printf(i + 1 == n ? "%f\n" : "%f, ", h[i]);
+}
+void dump_mat(const char *head_fmt, const float *dev, unsigned r, unsigned c)
+{
+    printf(head_fmt, r, c);
+    std::vector<float> h((size_t)r * c);
+    QM_HIP(hipDeviceSynchronize());
+    if (!h.empty()) QM_HIP(hipMemcpy(h.data(), dev, h.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (unsigned i = 0; i < r; i++)
+        for (unsigned j = 0; j < c; j++) printf(j + 1 == c ? "%f\n" : "%f, ", h[(size_t)i * c + j]);
+}
+// a verbose verb: drain what was queued before it, run it now
+void run_verbose(const Op &op)
+{
+    QM_SYNC_READS();
+    qmdefer::run_now(op);
+}
+void dump_dot(const char *f_name, const Op &op)
+{
+    dump_head(f_name);
+    printf(op.trans ? "f_trans: true\n" : "f_trans: false\n");
+    dump_mat("dev_in_mat> dim_mat_r: %d, dim_mat_c: %d\n", op.in, op.r, op.c);
+    dump_vec("dev_in_vec", op.in2, op.trans ? op.r : op.c);
+    dump_vec("dev_out_vec", op.out, op.trans ? op.c : op.r);
+    fflush(stdout);
+}
+
+}  // namespace
+
 extern "C" {
 
 void qmann_abi_set_softmax_base(int base)
@@ -426,10 +473,11 @@ void cuda_dot_mat_vec_fwd(float *dev_in_mat, float *dev_in_vec, float *dev_out_v
                           unsigned int frac_m, unsigned int iwl_v, unsigned int frac_v, unsigned int f_mode,
                           bool verbose)
 {
-    (void)dev_f_overflow; (void)f_mode; (void)verbose;
+    (void)dev_f_overflow; (void)f_mode;
     Op op{};
     op.kind = qmdefer::kDot; op.in = dev_in_mat; op.in2 = dev_in_vec; op.out = dev_out_vec; op.r = r; op.c = c;
     op.trans = f_trans; op.fixed = f_fixed; op.fa = QFmt{iwl_m, frac_m}; op.fb = QFmt{iwl_v, frac_v};
+    if (verbose) { run_verbose(op); dump_dot(__func__, op); return; }
     if (!qmdefer::submit(op)) qmdefer::run_now(op);
 }
 
@@ -447,6 +495,7 @@ void cuda_dot_mat_vec_fwd_appx(float *dev_in_mat, float *dev_in_vec, float *dev_
     Op op{};
     op.kind = qmdefer::kDotAppx; op.in = dev_in_mat; op.in2 = dev_in_vec; op.out = dev_out_vec; op.r = r; op.c = c;
     op.k = num_bit_attention; op.fixed = f_fixed; op.fa = QFmt{iwl, frac};
+    if (verbose) { run_verbose(op); dump_dot(__func__, op); return; }
     if (!qmdefer::submit(op)) qmdefer::run_now(op);
 }
 
@@ -478,9 +527,14 @@ void cuda_softmax_init(float *dev_out_vec, float *dev_grad_out, float *dev_max, 
 void cuda_softmax_fwd(float *dev_out_vec, float *dev_in_vec, float *out_vec, float *in_vec, float *dev_max,
                       unsigned int dim, bool f_shift_based, bool verbose)
 {
-    (void)out_vec; (void)in_vec; (void)verbose;
+    (void)out_vec; (void)in_vec;
     Op op{};
     op.kind = qmdefer::kSoftmax; op.in = dev_in_vec; op.out = dev_out_vec; op.aux = dev_max; op.r = dim; op.shift = f_shift_based;
+    if (verbose) {
+        run_verbose(op);
+        dump_head(__func__); dump_vec("dev_in_vec", dev_in_vec, dim); dump_vec("dev_out_vec", dev_out_vec, dim); fflush(stdout);
+        return;
+    }
     if (!qmdefer::submit(op)) qmdefer::run_now(op);
 }
 
@@ -508,10 +562,16 @@ void cuda_sum_vec_init(float *dev_out_vec, float *dev_grad_out, unsigned int dim
 void cuda_sum_vec_fwd(float *dev_in_vec_a, float *dev_in_vec_b, float *dev_out_vec, unsigned int dim,
                       bool f_fixed, unsigned int iwl, unsigned int frac, unsigned int f_mode, bool verbose)
 {
-    (void)f_mode; (void)verbose;
+    (void)f_mode;
     Op op{};
     op.kind = qmdefer::kSumVec; op.in = dev_in_vec_a; op.in2 = dev_in_vec_b; op.out = dev_out_vec; op.r = dim;
     op.fixed = f_fixed; op.fa = QFmt{iwl, frac};
+    if (verbose) {
+        run_verbose(op);
+        dump_head(__func__); dump_vec("dev_in_vec_a", dev_in_vec_a, dim); dump_vec("dev_in_vec_b", dev_in_vec_b, dim);
+        dump_vec("dev_out_vec", dev_out_vec, dim); fflush(stdout);
+        return;
+    }
     if (!qmdefer::submit(op)) qmdefer::run_now(op);
 }
 
@@ -561,12 +621,19 @@ void cuda_dense_fwd(float *dev_w_mat, float *dev_bias, float *dev_in_vec, float 
                     bool f_fixed, unsigned int iwl_in, unsigned int frac_in, unsigned int iwl_w,
                     unsigned int frac_w, unsigned int f_mode, bool verbose)
 {
-    (void)dev_bias; (void)dev_f_overflow; (void)f_mode; (void)verbose;
+    (void)dev_bias; (void)dev_f_overflow; (void)f_mode;
     if (f_fixed && iwl_w + frac_w == 0)
         qm_fail(__func__, "binary-weight (iwl_w+frac_w==0) rescale path is not part of this library");
     Op op{};
     op.kind = qmdefer::kDense; op.w = dev_w_mat; op.in = dev_in_vec; op.out = dev_out_vec; op.r = dim_out; op.c = dim_in;
     op.act = act_id(activation); op.fixed = f_fixed; op.fa = QFmt{iwl_in, frac_in}; op.fb = QFmt{iwl_w, frac_w};
+    if (verbose) {
+        run_verbose(op);
+        dump_head(__func__); dump_vec("dev_in_vec", dev_in_vec, dim_in);
+        dump_mat("dev_w_mat> dim_out: %d, dim_in: %d\n", dev_w_mat, dim_out, dim_in);
+        dump_vec("dev_out_vec", dev_out_vec, dim_out); fflush(stdout);
+        return;
+    }
     if (!qmdefer::submit(op)) qmdefer::run_now(op);
 }
 
@@ -623,12 +690,19 @@ void cuda_dense_mat_fwd(float *dev_w_mat, float *dev_bias, float *dev_in_mat, fl
                         float *dev_f_overflow, unsigned int dim_in, unsigned int dim_out, unsigned int dim_len,
                         bool f_fixed, unsigned int iwl, unsigned int frac, unsigned int f_mode, bool verbose)
 {
-    (void)dev_bias; (void)dev_f_overflow; (void)f_mode; (void)verbose;
+    (void)dev_bias; (void)dev_f_overflow; (void)f_mode;
     if (f_fixed && iwl + frac == 0)
         qm_fail(__func__, "binary-weight (iwl+frac==0) rescale path is not part of this library");
     Op op{};
     op.kind = qmdefer::kDenseMat; op.w = dev_w_mat; op.in = dev_in_mat; op.out = dev_out_mat; op.r = dim_len; op.c = dim_in;
     op.k = dim_out; op.fixed = f_fixed; op.fa = QFmt{iwl, frac};
+    if (verbose) {
+        run_verbose(op);
+        dump_head(__func__); dump_mat("dev_in_mat> dim_len: %d, dim_in: %d\n", dev_in_mat, dim_len, dim_in);
+        dump_mat("dev_w_mat> dim_out: %d, dim_in: %d\n", dev_w_mat, dim_out, dim_in);
+        dump_mat("dev_out_mat>dim_len: %d, dim_out: %d\n", dev_out_mat, dim_len, dim_out); fflush(stdout);
+        return;
+    }
     if (!qmdefer::submit(op)) qmdefer::run_now(op);
 }
 
@@ -763,7 +837,7 @@ void cuda_scale_init(float *dev_w, float *dev_w_del, float *dev_out, float *dev_
 void cuda_scale_fwd(float *dev_in, float *dev_w, float *dev_out, unsigned int dim, bool f_fixed,
                     unsigned int iwl, unsigned int frac, unsigned int f_mode, bool verbose)
 {
-    (void)f_fixed; (void)iwl; (void)frac; (void)f_mode; (void)verbose;
+    (void)f_fixed; (void)iwl; (void)frac; (void)f_mode; (void)verbose;      // (the reference's scale verb prints nothing either: :4818-4826)
     Op op{};
     op.kind = qmdefer::kScale; op.in = dev_in; op.w = dev_w; op.out = dev_out; op.r = dim;
     if (!qmdefer::submit(op)) qmdefer::run_now(op);

@@ -316,7 +316,7 @@ int qmann_hops_i8(const qmann_net *net, const int8_t *keys, const int8_t *vals, 
     } while (0)
 #define QM_LAUNCH_HOPS(LPR, UN, NT, MINW)                                                               \
     do { if (w7) QM_LAUNCH_HOPS_W(LPR, UN, NT, MINW, true); else QM_LAUNCH_HOPS_W(LPR, UN, NT, MINW, false); } while (0)
-    bool w7 = getenv("QMANN_NO_W7") == nullptr;
+    bool w7 = !qm_tuning().no_w7;
     for (uint32_t h = 0; h < net->n_hop; h++) w7 = w7 && net->att[h].iwl + net->att[h].frac == 7;
     // (bounding the kernel to 96 VGPRs for a fifth wavefront per SIMD measured 1-3 % slower: MINW stays 1)
     if (net->dim_emb_pad == 64) QM_LAUNCH_HOPS(4, kUnrollDefault, true, 1);

@@ -1318,7 +1318,7 @@ static void fill_qkinds(EmbedIdxArgs &a)
         a.qkinds |= qkind_of(a.w[h], a.att[h], (a.key_mz >> h) & 1u) << (4u * h);
         a.qkinds |= qkind_of(a.w[h], a.act[h], false) << (4u * h + 2u);
     }
-    if (getenv("QMANN_EMBED_GENERAL_EPILOGUE")) a.qkinds = 0xFFFFFFFFu;     // A/B: ew_to_bytes everywhere
+    if (qm_tuning().embed_general_epilogue) a.qkinds = 0xFFFFFFFFu;     // A/B: ew_to_bytes everywhere
 }
 
 }  // namespace
@@ -1395,7 +1395,7 @@ int qmann_answer_i8(const qmann_net *net, const int8_t *w_ans_i8, qmann_fmt w_fm
     hipStream_t st = (hipStream_t)stream;
     const QFmt fuq{fu.iwl, fu.frac};
     // (the running-maximum normaliser needs a true exponential: the piece-wise linear exp_plan takes the two-pass form)
-    if (!probs && net->softmax_base != QMANN_SOFTMAX_EXP_PLAN && !getenv("QMANN_ANSWER_TWO_PASS")) {
+    if (!probs && net->softmax_base != QMANN_SOFTMAX_EXP_PLAN && !qm_tuning().answer_two_pass) {
         // one pass: no logits round trip; the workspace holds the per-slice records
         const uint32_t qblocks = (n_query + 16 * kWaves - 1) / (16 * kWaves), n_tiles = (V + kAnsTile - 1) / kAnsTile;
         // ~2 workgroups per CU (measured at 8 192 x 4 096 x 256: 128 workgroups 86 us, 256: 55, 512: 45, 1 024: 46)
@@ -1571,7 +1571,7 @@ int qmann_embed_story_idx(const qmann_net *net, const uint16_t *words, uint32_t 
     if (net->dim_emb_pad % 64 != 0) return QMANN_EUNSUPPORTED;          // 16 lanes x 4 columns per round
     // dictionaries of up to 256 entries with 1.0 representable in every weight format: the matrix-core kernel
     bool mfma_ok = net->dim_input <= 256 && net->dim_emb_pad == 64 && (max_words & 3u) == 0u && ((uintptr_t)words & 7u) == 0u &&
-                   !getenv("QMANN_EMBED_VALU");
+                   !qm_tuning().embed_valu;
     for (uint32_t h = 0; h < net->n_hop; h++) mfma_ok = mfma_ok && net->w[h].iwl >= 1;
     if (mfma_ok) {
         const uint32_t K = net->dim_input <= 64 ? 64u : (net->dim_input <= 128 ? 128u : 256u), Dp = net->dim_emb_pad;

@@ -8,6 +8,7 @@
 #include <new>
 #include <rccl/rccl.h>          // types and prototypes only: no symbol of it is linked
 #include <string.h>
+#include <vector>
 
 struct qmann_comm {
     ncclComm_t comm = nullptr;
@@ -33,8 +34,13 @@ std::once_flag g_rccl_once;
 
 void load_rccl()
 {
-    const char *names[4] = {getenv("QMANN_RCCL_PATH"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char *n : names) {
+    // QMANN_RCCL_PATH, when set, is the ONLY name tried: an override that cannot be loaded must not end in some other copy
+    // of the library being picked up silently (a process may hold one RCCL only, see the header)
+    const char *forced = getenv("QMANN_RCCL_PATH");
+    const char *names[4] = {forced, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    const int n_names = (forced && *forced) ? 1 : 4;
+    for (int i = 0; i < n_names; i++) {
+        const char *n = names[i];
         if (!n || !*n) continue;
         // RTLD_GLOBAL is not wanted: nothing else should bind to it through us.  A process that already holds an RCCL
         // (PyTorch's, say) gets that same copy back when the soname matches.
@@ -91,6 +97,15 @@ void qmann_shard_range(uint32_t n_query, uint32_t rank, uint32_t world, uint32_t
     const uint32_t a = rank * base + (rank < rem ? rank : rem);
     if (lo) *lo = a;
     if (hi) *hi = a + base + (rank < rem ? 1u : 0u);
+}
+
+int qmann_comm_probe(int device)
+{
+    if (!rccl()) return QMANN_ECOMM;
+    if (device < 0) return QMANN_OK;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess) { (void)hipGetLastError(); return QMANN_EHIP; }
+    return device < n_dev ? QMANN_OK : QMANN_EINVAL;
 }
 
 int qmann_comm_get_id(void *id)
@@ -180,37 +195,69 @@ int qmann_comm_allgather_u32(qmann_comm *c, const uint32_t *send, uint32_t *recv
 int qmann_comm_broadcast_params(qmann_comm *c, int root, const qmann_model *root_model, void **blob, size_t *bytes, void *stream)
 {
     QmBatched qm_scope;
+    // arguments every rank passes alike (the contract in the header): an error here is the same error on every rank
     if (!c || !blob || !bytes || root < 0 || root >= c->n_ranks) return QMANN_EINVAL;
     *blob = nullptr; *bytes = 0;
     const bool is_root = c->rank == root;
+    // what only the root can get wrong: it still JOINS the size broadcast (with size 0, which every receiver maps to
+    // QMANN_ECOMM) -- the other ranks are already waiting in it
     const void *src = nullptr;
     size_t n = 0;
+    int root_err = QMANN_OK;
     if (is_root) {
-        if (!root_model || qmann_model_params(root_model, &src, &n) != QMANN_OK || !src || n == 0) return QMANN_EINVAL;
-        if (qmann_model_device(root_model) != c->device) return QMANN_EINVAL;      // the blob must sit on this rank's GPU
+        if (!root_model || qmann_model_params(root_model, &src, &n) != QMANN_OK || !src || n == 0) root_err = QMANN_EINVAL;
+        else if (qmann_model_device(root_model) != c->device) root_err = QMANN_EINVAL;      // the blob must sit on this rank's GPU
+        if (root_err) { src = nullptr; n = 0; }
     }
     const Rccl *r = rccl();
-    if (!r) return QMANN_ECOMM;
+    if (!r) return QMANN_ECOMM;                 // (unreachable with a live communicator: it was made through this library)
     OnDevice on(c->device);
     hipStream_t st = (hipStream_t)stream;
+    // one small device scratch: [0] the size, [1] this rank's status, [2 ..] every rank's status
+    const size_t n_scr = 2 + (size_t)c->n_ranks;
+    unsigned long long *d_scr = nullptr;
+    QM_HIP(hipMalloc((void **)&d_scr, n_scr * sizeof *d_scr));
+    if (!d_scr) return QMANN_EHIP;              // (a 100-byte allocation failing means the device is gone: nothing to agree on)
     // 1. the size (the other ranks need not know the model's dimensions beforehand)
-    unsigned long long *d_n = nullptr, h_n = (unsigned long long)n;
-    QM_HIP(hipMalloc((void **)&d_n, sizeof *d_n));
-    if (!d_n) return QMANN_EHIP;
-    QM_HIP(hipMemcpyAsync(d_n, &h_n, sizeof h_n, hipMemcpyHostToDevice, st));
-    int rc = nccl_rc(r, r->Broadcast(d_n, d_n, 1, ncclUint64, root, c->comm, st), "ncclBroadcast(size)");
+    unsigned long long h_n = (unsigned long long)n;
+    QM_HIP(hipMemcpyAsync(d_scr, &h_n, sizeof h_n, hipMemcpyHostToDevice, st));
+    int rc = nccl_rc(r, r->Broadcast(d_scr, d_scr, 1, ncclUint64, root, c->comm, st), "ncclBroadcast(size)");
     if (rc == QMANN_OK) {
-        QM_HIP(hipMemcpyAsync(&h_n, d_n, sizeof h_n, hipMemcpyDeviceToHost, st));
+        QM_HIP(hipMemcpyAsync(&h_n, d_scr, sizeof h_n, hipMemcpyDeviceToHost, st));
         QM_HIP(hipStreamSynchronize(st));
         rc = qm_scope.rc();
     }
-    QM_HIP(hipFree(d_n));
-    if (rc != QMANN_OK) return rc;
-    if (h_n == 0 || h_n > (1ull << 34)) return QMANN_ECOMM;
-    // 2. the bytes, into a fresh buffer on every rank (the root's model keeps its own)
+    if (rc != QMANN_OK) { QM_HIP(hipFree(d_scr)); return rc; }
+    if (h_n == 0 || h_n > (1ull << 34)) {       // the root had nothing valid to send: every rank leaves here, in step
+        QM_HIP(hipFree(d_scr));
+        return root_err ? root_err : QMANN_ECOMM;
+    }
+    // 2. a fresh buffer on every rank (the root's model keeps its own) -- and an agreement that every rank HAS one, so that
+    //    no rank waits in the bytes broadcast for one that left with an allocation failure
     void *dst = nullptr;
-    QM_HIP(hipMalloc(&dst, (size_t)h_n));
-    if (!dst) return QMANN_EHIP;
+    const hipError_t e_alloc = hipMalloc(&dst, (size_t)h_n);
+    if (e_alloc != hipSuccess) {
+        fprintf(stderr, "[*E] HIP : qmann_comm_broadcast_params : %zu bytes : %s\n", (size_t)h_n, hipGetErrorString(e_alloc));
+        (void)hipGetLastError();
+        dst = nullptr;
+    }
+    std::vector<unsigned long long> stat(n_scr, 0);
+    stat[1] = dst ? 1ull : 0ull;
+    QM_HIP(hipMemcpyAsync(d_scr + 1, &stat[1], sizeof stat[1], hipMemcpyHostToDevice, st));
+    rc = nccl_rc(r, r->AllGather(d_scr + 1, d_scr + 2, 1, ncclUint64, c->comm, st), "ncclAllGather(status)");
+    if (rc == QMANN_OK) {
+        QM_HIP(hipMemcpyAsync(stat.data() + 2, d_scr + 2, (size_t)c->n_ranks * sizeof stat[0], hipMemcpyDeviceToHost, st));
+        QM_HIP(hipStreamSynchronize(st));
+        rc = qm_scope.rc();
+    }
+    QM_HIP(hipFree(d_scr));
+    bool all_ok = rc == QMANN_OK;
+    for (int i = 0; i < c->n_ranks && all_ok; i++) all_ok = stat[2 + (size_t)i] == 1ull;
+    if (!all_ok) {
+        if (dst) QM_HIP(hipFree(dst));
+        return rc != QMANN_OK ? rc : (stat[1] ? QMANN_ECOMM /* a peer could not allocate */ : QMANN_EHIP);
+    }
+    // 3. the bytes
     rc = nccl_rc(r, r->Broadcast(is_root ? src : dst, dst, (size_t)h_n, ncclUint8, root, c->comm, st), "ncclBroadcast(params)");
     QM_HIP(hipStreamSynchronize(st));
     if (rc == QMANN_OK) rc = qm_scope.rc();

@@ -464,7 +464,7 @@ k_hops_lean(const HopArgs a, const LeanArgs la)
 inline bool lean_supported(const HopArgs &a, uint32_t max_slots, uint32_t key_row_bytes)
 {
     return a.Dp == 64 && key_row_bytes == 64 && max_slots <= (uint32_t)kWave && !a.tap_codes && !a.tap_scores && !a.tap_probs &&
-           !a.tap_o && !a.tap_u && getenv("QMANN_NO_LEAN") == nullptr;
+           !a.tap_o && !a.tap_u && !qm_tuning().no_lean;
 }
 
 template <int MODE, int NB, bool W7, bool SPARSE>
@@ -500,7 +500,7 @@ inline void launch_lean(const HopArgs &a, uint32_t max_slots, uint32_t n_query, 
     for (uint32_t h = 0; h < a.n_hop; h++) surv = surv > (1u << a.act[h].frac) ? surv : (1u << a.act[h].frac);
     const uint32_t mean_slots = (a.rows_total && n_query) ? a.rows_total / n_query : max_slots / 8u;     // (tied hops: no plane size; real stories are short next to their cap)
     bool sparse = surv * 4u <= mean_slots;
-    if (const char *e = getenv("QMANN_LEAN_SPARSE")) sparse = e[0] == '1';
+    if (qm_tuning().lean_sparse >= 0) sparse = qm_tuning().lean_sparse == 1;
     if (w7) { if (sparse) launch_lean_w<MODE, NB, true, true>(a, max_slots, n_query, st); else launch_lean_w<MODE, NB, true, false>(a, max_slots, n_query, st); }
     else { if (sparse) launch_lean_w<MODE, NB, false, true>(a, max_slots, n_query, st); else launch_lean_w<MODE, NB, false, false>(a, max_slots, n_query, st); }
 }

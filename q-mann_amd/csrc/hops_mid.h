@@ -224,7 +224,7 @@ inline bool mid_supported(const HopArgs &a, uint32_t max_slots)
 {
     return a.Dp == 64 && max_slots > (uint32_t)kWave && max_slots <= kMidMaxSlots && a.softmax_base == QMANN_SOFTMAX_EXP &&
            !a.softmax_shift && !a.en_att_scale && !a.tap_codes && !a.tap_scores && !a.tap_probs && !a.tap_o && !a.tap_u &&
-           getenv("QMANN_NO_MID") == nullptr;
+           !qm_tuning().no_mid;
 }
 
 template <bool W7>

@@ -130,6 +130,31 @@ int check_net(const qmann_net *net)
     return QMANN_OK;
 }
 
+// a blob header as it must be: what qmann_params_validate answers and qmann_model_create_from_params relies on
+int check_header(const BlobHeader &hd, size_t bytes)
+{
+    if (hd.magic != kBlobMagic || hd.version != kBlobVersion || hd.bytes != bytes || hd.tied > 1u || hd.reserved != 0u) return QMANN_EINVAL;
+    const int rc = check_net(&hd.net);
+    if (rc != QMANN_OK) return rc;
+    const qmann_net &n = hd.net;
+    switch (n.attention_mode) {
+    case QMANN_ATT_FLOAT: case QMANN_ATT_FIXED: case QMANN_ATT_APPX: case QMANN_ATT_HAMMING_V0: case QMANN_ATT_HAMMING_V1: break;
+    default: return QMANN_EINVAL;
+    }
+    if (n.softmax_base > QMANN_SOFTMAX_EXP_PLAN || n.en_lin_map > 1u || n.num_bit > 8u || n.softmax_shift_based > 1u ||
+        n.en_att_scale > 1u || n.en_non_linearity > 1u || n.en_pe > 1u)
+        return QMANN_EINVAL;
+    auto fmt_ok = [](qmann_fmt f) { return f.iwl + f.frac <= 7u && f.iwl <= 7u; };
+    for (uint32_t h = 0; h < n.n_hop; h++) {
+        if (!fmt_ok(n.act[h]) || !fmt_ok(n.w[h]) || !fmt_ok(n.att[h])) return QMANN_EINVAL;
+        if (n.lin_map[h] != nullptr) return QMANN_EINVAL;             // a blob carries offsets, never pointers
+    }
+    if (!fmt_ok(n.bin)) return QMANN_EINVAL;
+    BlobHeader want = hd;
+    if (blob_layout(n, &want) != bytes || memcmp(&want, &hd, sizeof hd) != 0) return QMANN_EINVAL;   // offsets must be the canonical ones
+    return QMANN_OK;
+}
+
 // dimensions, the embedding formats and the section pointers of a model whose blob is in place
 void bind_sections(qmann_model *m, const BlobHeader &h)
 {
@@ -272,7 +297,7 @@ int qmann_model_create_on(qmann_model **out, int device, const qmann_net *net, c
     const uint32_t H = net->n_hop, D = net->dim_emb, Dp = net->dim_emb_pad, V = net->dim_input;
     const size_t DV = (size_t)D * V, DD = (size_t)D * D;
     // tied embedding matrices (see the struct); mode 1 compares the formats its embedding really uses
-    bool tied = H > 1 && !getenv("QMANN_NO_TIED");
+    bool tied = H > 1 && !qm_tuning().no_tied;
     for (uint32_t h = 1; h < H && tied; h++) {
         const bool fl = net->attention_mode == QMANN_ATT_FLOAT;
         const qmann_fmt a0 = fl ? net->w[0] : net->att[0], ah = fl ? net->w[h] : net->att[h];
@@ -334,10 +359,7 @@ int qmann_model_create_from_params(qmann_model **out, int device, const void *bl
     QM_HIP(hipMemcpyAsync(&hd, blob, sizeof hd, hipMemcpyDefault, st));
     QM_HIP(hipStreamSynchronize(st));
     if (qm_scope.rc()) return qm_scope.rc();
-    if (hd.magic != kBlobMagic || hd.version != kBlobVersion || hd.bytes != bytes) return QMANN_EINVAL;
-    if ((rc = check_net(&hd.net)) != QMANN_OK) return rc;
-    BlobHeader want = hd;
-    if (blob_layout(hd.net, &want) != bytes || memcmp(&want, &hd, sizeof hd) != 0) return QMANN_EINVAL;   // offsets must be the canonical ones
+    if ((rc = check_header(hd, bytes)) != QMANN_OK) return rc;
 
     qmann_model *m = new (std::nothrow) qmann_model();
     if (!m) return QMANN_ERANGE;
@@ -350,6 +372,16 @@ int qmann_model_create_from_params(qmann_model **out, int device, const void *bl
     if (qm_scope.rc()) { qmann_model_destroy(m); return qm_scope.rc(); }
     *out = m;
     return QMANN_OK;
+}
+
+int qmann_params_validate(const void *host_blob, size_t bytes, qmann_net *net)
+{
+    if (!host_blob || bytes < sizeof(BlobHeader)) return QMANN_EINVAL;
+    BlobHeader hd;
+    memcpy(&hd, host_blob, sizeof hd);
+    const int rc = check_header(hd, bytes);
+    if (rc == QMANN_OK && net) *net = hd.net;
+    return rc;
 }
 
 void qmann_model_destroy(qmann_model *m)

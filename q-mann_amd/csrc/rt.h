@@ -48,4 +48,16 @@ static inline void qm_alloc(T **p, size_t n)
     QM_HIP(hipMalloc((void **)p, (n ? n : 1) * sizeof(T)));
 }
 
+// The library's A/B and tuning switches (INTEGRATION.md lists them) are read from the environment ONCE per process -- on
+// first use, through a thread-safe function-local static -- and then live in this struct: no launch calls getenv(), which
+// is not safe against a setenv() running in another thread of a threaded host (examples/forward_sharded.c is one).
+// qmann_tuning_reload() (include/qmann_batch.h) reads the environment again, for hosts and tests that change a switch
+// after the first launch; it must not run while another thread launches.
+struct QmTuning {
+    bool no_w7, no_mid, no_lean, no_tied, embed_general_epilogue, embed_valu, answer_two_pass;
+    int lean_sparse;                                  // -1 = the launcher chooses, 0 / 1 forced
+    int lean_pair;                                    // -1 = default
+};
+const QmTuning &qm_tuning();                          // (tuning.hip)
+
 static inline unsigned qm_cdiv(unsigned a, unsigned b) { return (a + b - 1) / b; }

@@ -31,6 +31,17 @@ def load_pkg():
     return mod
 
 
+@pytest.fixture(autouse=True)
+def _tuning_switches_follow_the_environment():
+    """The library reads its QMANN_* A/B switches once per process (csrc/tuning.hip).  A test that sets one calls
+    qmann_tuning_reload() itself; this puts the library back in step with the restored environment afterwards (set up
+    before `monkeypatch`, so it is finalised after monkeypatch has undone its changes)."""
+    yield
+    abi = sys.modules.get("qmann_amd.abi")
+    if abi is not None:
+        abi.lib.qmann_tuning_reload()
+
+
 @pytest.fixture(scope="session")
 def pkg():
     return load_pkg()

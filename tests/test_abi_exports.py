@@ -64,16 +64,23 @@ def test_reference_objects_link_against_the_library(abi):
 
 def test_fixture_generator_holds_no_product_code():
     """The reference's CPU code that pins the oracle (libqmann_ref*.so) and serves as the CPU baseline
-    (libqmann_refcpu_*.so) binds its cuda_* imports to oracle/cuda_stubs.c, not to the product library."""
+    (libqmann_refcpu_*.so) is reference objects + glue and nothing else: it depends on no product library, DEFINES no
+    cuda_* symbol (no stand-ins for the CUDA object: layer.o's imports stay undefined and, with en_gpu_model = false,
+    uncalled) and loads with lazy binding."""
+    import sys
+    sys.path.insert(0, str(ROOT / "oracle"))
+    from pyoracle import load_lazy
     ref = ROOT / "oracle" / "_ref"
     libs = sorted(ref.glob("libqmann_ref*.so"))
     if not libs:
         pytest.skip("reference build not present (built only where /root/reference exists)")
+    assert not (ROOT / "oracle" / "cuda_stubs.c").exists()
     for so in libs:
-        assert not [s for s in _nm_undefined(so) if s.startswith("cuda_")], so
+        dyn = subprocess.run(["nm", "-D", "--defined-only", str(so)], capture_output=True, text=True, check=True).stdout
+        assert not [l for l in dyn.splitlines() if l.split()[-1].startswith("cuda_")], so
         needed = subprocess.run(["readelf", "-d", str(so)], capture_output=True, text=True, check=True).stdout
         assert "qmann_hip" not in needed and "amdhip" not in needed, so
-        L = ctypes.CDLL(str(so))
+        L = load_lazy(so)
         assert hasattr(L, "dense_mat_fwd") and hasattr(L, "softmax_fwd") and hasattr(L, "hamming_similarity")
 
 

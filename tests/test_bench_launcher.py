@@ -47,9 +47,14 @@ def test_self_launch_two_ranks():
     assert out["param_broadcast_ms"] >= 0.0
     rk = out["ranks"]
     assert (rk["rank"]["min"], rk["rank"]["max"]) == (0.0, 1.0)
-    # every rank ended up with rank 0's parameters, and the shards tile the batch
-    assert rk["param_checksum"]["min"] == rk["param_checksum"]["max"] > 0
+    # every rank ended up with rank 0's QUANTISED blob (the committed one), and the shards tile the batch
+    import zlib
+    blob = (ROOT / "tests" / "golden" / "trained_qa1" / "params_q.blob").read_bytes()
+    assert rk["param_crc32"]["min"] == rk["param_crc32"]["max"] == float(zlib.crc32(blob))
+    assert out["param_broadcast"]["bytes"] == len(blob) == out["config"]["blob"]["bytes"]
+    assert out["config"]["blob"]["dim_emb"] == 60 and out["config"]["blob"]["n_hop"] == 3
     assert rk["shard_size"]["min"] == rk["shard_size"]["max"] == 64
+    assert (rk["shard_lo"]["min"], rk["shard_hi"]["min"], rk["shard_lo"]["max"], rk["shard_hi"]["max"]) == (0.0, 64.0, 64.0, 128.0)
 
 
 def test_gpus_must_match_world_size():

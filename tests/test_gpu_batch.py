@@ -166,6 +166,15 @@ def test_hops_full_size_memory(env, oracle):
              sigma_u=12.0, sigma_k=20.0)
 
 
+@pytest.mark.parametrize("sigma_u,sigma_k,sigma_h", [(6.0, 6.0, 6.0), (20.0, 30.0, 12.0)])
+def test_hops_full_size_memory_q25_as_specified(env, oracle, sigma_u, sigma_k, sigma_h):
+    """BASELINE config 4 as SURVEY.md 8(d) specifies it: format Q2.5, codes clip(round(N(0, 6))) for keys, values, query and
+    linear map (bench.py's synth10k_d128_q25) -- 10 000 slots against the oracle; and once with wider codes so that scores
+    saturate and weights survive Q(p) at five fraction bits (up to 32 value rows per hop)."""
+    run_case(env, oracle, cfg_synth(128, 256, 2), B=5, S_list=[10000, 9999, 10000], seed=110 + int(sigma_k),
+             sigma_u=sigma_u, sigma_k=sigma_k, sigma_h=sigma_h / 32.0)
+
+
 def test_hops_full_size_d256(env, oracle):
     run_case(env, oracle, cfg_synth(256, 256, 5), B=3, S_list=[10000], seed=12, sigma_u=8.0, sigma_k=16.0)
 

@@ -300,3 +300,63 @@ def test_sharded_host_one_rank_per_gpu_over_rccl(sharded_setup):
     p2, m2, _ = read_out(out, nq)
     np.testing.assert_array_equal(p2, p1)
     assert m2 == m1
+
+
+# ---- the N > 1 host logic of bench.py, executed -------------------------------------------------------------------------
+def _bench(args, **env_extra):
+    import json
+    import os
+    import sys
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "QMANN_BENCH_AS_RANK")}
+    e.update(env_extra)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), *args], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                                   # rank 0 only
+    return json.loads(lines[0])
+
+
+def test_committed_blob_is_what_the_library_produces(env):
+    """tests/golden/trained_qa1/params_q.blob (what the CPU-only two-rank tests broadcast and vet) = the parameter blob the
+    library makes today from the float matrices beside it (tools/make_params_blob.py)"""
+    import sys
+    sys.path.insert(0, str(ROOT / "tools"))
+    from make_params_blob import trained_cfg
+    cfg = trained_cfg()
+    hm = env.model.HostModel(cfg, env.model.load_weights(ROOT / "tests" / "golden" / "trained_qa1", cfg), device="cuda:0")
+    raw = hm.params_bytes()
+    want = (ROOT / "tests" / "golden" / "trained_qa1" / "params_q.blob").read_bytes()
+    assert len(raw) == len(want) and raw == want
+    assert env.abi.lib.qmann_params_validate(raw, len(raw), None) == 0
+    hm.close()
+
+
+@pytest.mark.parametrize("workload,queries", [("synth10k_d128", 192), ("babi_task1_trained", 2000)])
+def test_bench_two_ranks_rehearsal_equals_the_single_rank_runs(workload, queries):
+    """`bench.py --gpus 2` started as a fresh child process tree (the launcher, torch.distributed.run, two ranks), both ranks
+    on this box's one GPU over gloo (QMANN_BENCH_REHEARSE=1: RCCL refuses two ranks on one device; everything but the
+    transport of the one broadcast is the code an 8-GPU node runs): n_gpus = 2, the shards are disjoint and tile the
+    global batch, the broadcast carried exactly the model's quantised blob, and each rank's predictions -- computed by a
+    replica built from the RECEIVED bytes -- equal those of a single-rank run that built its model from the float weights."""
+    common = ["--steps", "3", "--warmup", "1", "--workload", workload, "--queries", str(queries), "--no-sustained", "--no-cpu-baseline"]
+    two = _bench(["--gpus", "2", *common], QMANN_BENCH_REHEARSE="1")
+    assert two["n_gpus"] == 2 and two["steps"] == 3
+    assert two["collective"]["world_size_seen"] == 2 and two["collective"]["backend"] == "gloo" and two["collective"]["self_launched"] is True
+    B = two["config"]["queries_per_gpu"]
+    assert two["shards"] == [[0, B], [B, 2 * B]]
+    ones = [_bench(["--gpus", "1", *common], QMANN_BENCH_AS_RANK=str(r)) for r in range(2)]
+    assert [o["shards"][0] for o in ones] == two["shards"]
+    assert two["pred_crc32"] == [o["pred_crc32"][0] for o in ones]
+    if workload == "synth10k_d128":
+        assert two["pred_crc32"][0] != two["pred_crc32"][1]           # (different queries on the two ranks)
+    # the one collective: the quantised blob, once
+    pb = two["param_broadcast"]
+    assert pb["bytes"] > 0 and "quantised blob" in pb["how"] and two["param_broadcast_ms"] >= 0.0
+    if workload == "babi_task1_trained":
+        want = (ROOT / "tests" / "golden" / "trained_qa1" / "params_q.blob").read_bytes()
+        assert pb["bytes"] == len(want)                                # the committed blob's size: the same model
+        assert two["accuracy"]["equals_reference_program"] is True     # rank 0's shard (the 1 000 test stories, replicated) scores the program's own error
+    else:
+        assert two["ranks"]["queries_per_s"]["min"] > 0
+    # weak scaling: the whole-job figure counts both ranks' queries
+    assert abs(two["value"] - 2 * B * 3 / (two["ms_per_step"] * 3e-3)) / two["value"] < 1e-6

@@ -85,6 +85,7 @@ def test_lean_value_tile_and_sparse_read_out_agree_with_the_general_kernel(env, 
     with formats of 1, 2, 4 and 5 fraction bits (up to 2, 4, 16, 32 surviving rows: several fetch rounds) and flat scores
     (small sigma_k: many rows share the weight)"""
     monkeypatch.setenv("QMANN_LEAN_SPARSE", sparse)
+    env.model.abi.lib.qmann_tuning_reload()                 # (the switches are read once per process; conftest re-reads them after the test)
     for sk in (30.0, 1.5):
         both_paths(env, cfg_of(mode, iwl=iwl), B=200, S_list=[0, 1, 2, 5, 16, 17, 40, 50, 64], seed=40 + mode + iwl, sigma_k=sk)
 

@@ -349,15 +349,16 @@ def test_forward_verbs_random_shapes_and_formats(env, oracle, seed):
 # ---------------------------------------------------------------------------------------------
 # the deferred queue behind the forward verbs (include/qmann_abi.h "Deferred execution"), driven verb by verb
 # ---------------------------------------------------------------------------------------------
-def _host_loop(env, cfg, wts, story, ques, ans_onehot, n_sen, nq, defer, stray=None):
+def _host_loop(env, cfg, wts, story, ques, ans_onehot, n_sen, nq, defer, stray=None, dev_wts=None):
     """MemN2N.c's test loop (:2378-2702) in ctypes: per query the 31 verbs in the reference's order on FIXED layer buffers
     (as the host's structs hold them), accumulators fetched once at the end.  `stray`: a query index after which an
     unrelated verb (a vector sum on scratch) is issued -- the pattern breaks there and must fall back to the verbs."""
     lib, up, ptr, empty, torch = env.lib, env.up, env.ptr, env.empty, env.torch
     V, D, H = cfg["dim_input"], cfg["dim_emb"], cfg["n_hop"]
     lib.qmann_abi_set_defer(defer)
-    dwq, dwans = up(wts["w_q"]), up(wts["w_ans"])
-    dwa = [up(w) for w in wts["w_a"]]; dwc = [up(w) for w in wts["w_c"]]; dwh = [up(w) for w in wts["w_h"]]
+    if dev_wts is None:
+        dev_wts = {k: ([up(w) for w in v] if isinstance(v, list) else up(v)) for k, v in wts.items()}
+    dwq, dwans, dwa, dwc, dwh = dev_wts["w_q"], dev_wts["w_ans"], dev_wts["w_a"], dev_wts["w_c"], dev_wts["w_h"]
     offs = np.concatenate([[0], np.cumsum(n_sen[:nq])]).astype(np.int64)
     dm, dq, da = up(story[:offs[nq]]), up(ques[:nq]), up(ans_onehot[:nq])
     S = int(n_sen[:nq].max())
@@ -430,6 +431,36 @@ def test_deferred_queue_equals_the_verbs(env, gold):
         np.testing.assert_array_equal(r["last_u"], off["last_u"])
         np.testing.assert_array_equal(r["last_scores"], off["last_scores"])
         np.testing.assert_array_equal(r["last_p"], off["last_p"])
+
+
+def test_flush_forgets_the_cached_model_when_the_host_rewrites_weights(env, gold):
+    """the batched model behind the queue is cached on the weight POINTERS.  A host that overwrites the weight
+    values in place with its own copies (here: torch) between two forward phases calls qmann_abi_flush(), which drops the
+    cache: the second phase computes with the new values (= the verbs with the queue off) and a new model was built."""
+    import importlib.util
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("gen_golden", ROOT / "oracle" / "gen_golden.py")
+    gg = importlib.util.module_from_spec(spec); spec.loader.exec_module(gg)
+    b = gold("babi_qa1_test64.npz")
+    V, D, H, nq = int(b["dim_input"]), 60, 3, 32
+    cfg = gg.babi_cfg(V, 2, 0)
+    w1, w2 = gg.seeded_weights(11, H, D, V, 1.0), gg.seeded_weights(12, H, D, V, 1.0)
+    dev = {k: ([env.up(w) for w in v] if isinstance(v, list) else env.up(v)) for k, v in w1.items()}
+    args = (env, cfg, None, b["story"].astype(np.float32), b["question"].astype(np.float32), b["answer"].astype(np.float32),
+            b["n_sen"].astype(np.int64), nq)
+    first = _host_loop(*args, defer=1, dev_wts=dev)
+    for k, v in w2.items():                                             # the host's own writes: same pointers, new values
+        for t, w in zip(dev[k] if isinstance(v, list) else [dev[k]], v if isinstance(v, list) else [v]):
+            t.copy_(env.torch.from_numpy(np.ascontiguousarray(w, np.float32)))
+    env.torch.cuda.synchronize()
+    env.lib.qmann_abi_flush()
+    second = _host_loop(*args, defer=1, dev_wts=dev)
+    plain = _host_loop(*args, defer=0, dev_wts=dev)
+    assert second["stats"]["models_built"] == first["stats"]["models_built"] + 1
+    assert second["stats"]["queries_batched"] - first["stats"]["queries_batched"] == nq
+    assert second["match"] == plain["match"] and second["last_pred"] == plain["last_pred"]
+    np.testing.assert_array_equal(second["last_u"], plain["last_u"])
+    assert not np.array_equal(second["last_u"], first["last_u"])         # (the two weight sets do give different states)
 
 
 def test_deferred_verbs_become_visible_at_a_flush(env):

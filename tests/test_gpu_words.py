@@ -356,6 +356,7 @@ def test_tied_detection_needs_equal_formats_and_matrices(env, monkeypatch):
     cfg = env.model.babi_cfg(V, attention_mode=2, D=D, en_mq=False)
     run_both(env, cfg, wts2, sw, qw, n_sen, rng.integers(0, V, 100))
     monkeypatch.setenv("QMANN_NO_TIED", "1")
+    env.model.abi.lib.qmann_tuning_reload()                 # (the switches are read once per process; conftest re-reads them after the test)
     run_both(env, cfg, wts, sw, qw, n_sen, rng.integers(0, V, 100))
 
 
