@@ -162,6 +162,14 @@ def compact(res, primary=False):
                  "kernel_ms", "frac_sustained", "frac_by_survey_formula")
     out = {k: res[k] for k in (("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                                 "vs_baseline", "dtype", "data") if primary else ("value", "unit", "ms_per_step", "data")) if k in res}
+    if not primary:                                        # secondaries: what repeats the headline's constants goes
+        keep_cfg = tuple(k for k in keep_cfg if k not in ("parallelism", "hops"))
+        keep_roof = tuple(k for k in keep_roof if k not in ("peak", "unit", "frac_by_survey_formula", "algorithmic_bytes_per_launch"))
+        out.pop("unit", None)
+        if out.get("data") == "synthetic":
+            out.pop("data")
+        elif "data" in out:
+            out["data"] = out["data"][:60]
     out["config"] = {k: v for k, v in res["config"].items() if k in keep_cfg}
     r = res["roofline"]
     out["roofline"] = {k: r[k] for k in keep_roof if k in r}
@@ -175,7 +183,7 @@ def compact(res, primary=False):
     c = res.get("cpu_baseline")
     if c:
         out["cpu_baseline"] = {"value": c["value"], "unit": c["unit"], "cores": c["cores"], "kind": c["kind"], "flags": c.get("flags"),
-                               "sample": c["sample"][:150], "one_thread": c.get("one_thread", {}).get("value"),
+                               "sample": c["sample"][:150 if primary else 100], "one_thread": c.get("one_thread", {}).get("value"),
                                "reference_flags_value": c.get("reference_flags", {}).get("value"),
                                "pred_agree": c.get("pred_agree"), "pred_total": c.get("pred_total")}
     a = res.get("answer_layer")

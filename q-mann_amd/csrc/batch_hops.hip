@@ -115,7 +115,9 @@ k_hops_fixed(const HopArgs a)
                 ptab[d] = e;
                 if (hist[d]) part += (double)hist[d] * (double)e;
             }
-            const double total = block_sum_double(part, red, lane, wave);
+            // e^x base: the CUDA kernel's double total; the CPU bases: the CPU softmax's float total, slot by slot (hops_common.h)
+            const double total = smc.base == QMANN_SOFTMAX_EXP ? block_sum_double(part, red, lane, wave)
+                                                               : block_serial_total_f32(S, lane, wave, red, [&](uint32_t r) { return ptab[(int)sc[r] + 127]; });
             for (uint32_t d = tid; d < 256; d += nthreads) {
                 const float p = hist[d] ? sm_quot(ptab[d], total, smc) : 0.0f;
                 ptab[d] = p;

@@ -97,7 +97,8 @@ k_hops_float(const HopArgs a)
             xmax = block_max<float>(xmax, (float *)red, lane, wave);
             double psum = 0.0;
             for (uint32_t r = tid; r < S; r += kBlock) psum += (double)sm_exp(slot_x(sc[r]) - xmax, smc);
-            const double total = block_sum_double(psum, red, lane, wave);
+            const double total = smc.base == QMANN_SOFTMAX_EXP ? block_sum_double(psum, red, lane, wave)       // (CPU bases: the CPU softmax's serial float total)
+                                                               : block_serial_total_f32(S, lane, wave, red, [&](uint32_t r) { return sm_exp(slot_x(sc[r]) - xmax, smc); });
             // stock e^x softmax: e . (1/total) is within an ulp of e / total, and p is not quantised in this
             // mode (tolerance 1e-5); the variants go through the general quotient
             const bool stock = smc.base == QMANN_SOFTMAX_EXP && !smc.shift;

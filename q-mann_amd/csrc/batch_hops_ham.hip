@@ -141,7 +141,8 @@ k_hops_ham(const HopArgs a, const uint32_t key_row_bytes, const uint32_t lds_slo
                 v0_p[d] = e;
                 if (v0_hist[d]) part += (double)v0_hist[d] * (double)e;
             }
-            const double total = block_sum_double(part, red, lane, wave);
+            const double total = smc.base == QMANN_SOFTMAX_EXP ? block_sum_double(part, red, lane, wave)
+                                                               : block_serial_total_f32(S, lane, wave, red, [&](uint32_t r) { return v0_p[sc[r]]; });
             for (uint32_t d = tid; d < nbins; d += kBlock) {
                 const float p = v0_hist[d] ? sm_quot(v0_p[d], total, smc) : 0.0f;
                 v0_p[d] = p;
@@ -182,7 +183,8 @@ k_hops_ham(const HopArgs a, const uint32_t key_row_bytes, const uint32_t lds_slo
             xmax = block_max<float>(xmax, (float *)red, lane, wave);
             double part = 0.0;
             for (uint32_t r = tid; r < S; r += kBlock) part += (double)sm_exp(slot_x(r) - xmax, smc);
-            const double total = block_sum_double(part, red, lane, wave);
+            const double total = smc.base == QMANN_SOFTMAX_EXP ? block_sum_double(part, red, lane, wave)
+                                                               : block_serial_total_f32(S, lane, wave, red, [&](uint32_t r) { return sm_exp(slot_x(r) - xmax, smc); });
             const size_t tb = (size_t)h * a.rows_total + r0;
             // Q(p) != 0 needs p >= 2^-frac, and p -- e / total in double then float, or e / (float)total -- is within 2^-23
             // relative of the exact quotient: a slot with e < total . 2^-frac . (1 - 2^-20) cannot reach it, and only the others
@@ -192,7 +194,15 @@ k_hops_ham(const HopArgs a, const uint32_t key_row_bytes, const uint32_t lds_slo
             // the total: threshold 0, every slot takes the exact path.
             const bool every = a.tap_codes || a.tap_scores || a.tap_probs || smc.shift;
             const float thr = every ? 0.0f : (float)(total * (double)qm_scale_down(1.0f, fa.frac) * (1.0 - 9.5367431640625e-07));
+            // ... and for the e^x base without a scale layer that test does not need the exponential either: e^(x - max) >= thr
+            // needs x - max >= log(thr) (up to the rounding of expf and logf, far inside the 1e-3 taken off here), x = score .
+            // scale exactly, so a slot below the integer `code_lo` is out without an exp -- 2 instead of ~20 vector operations
+            // for all but a handful of the 10 000 slots of a hop.  The slots that pass still take the test on e itself.
+            int code_lo = INT_MIN;
+            if (!every && smc.base == QMANN_SOFTMAX_EXP && !smc.en_scale)
+                code_lo = (int)floorf((logf(thr) - 1e-3f + xmax) / scale) - 1;
             for (uint32_t r = tid; r < S; r += kBlock) {
+                if ((int)sc[r] < code_lo) continue;
                 const float e = sm_exp(slot_x(r) - xmax, smc);
                 if (!(e >= thr)) continue;
                 const float p = sm_quot(e, total, smc);

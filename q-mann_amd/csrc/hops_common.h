@@ -160,19 +160,21 @@ __device__ __forceinline__ uint32_t pk_mul_sat_i16(uint32_t a, uint32_t b)
     asm("v_pk_mad_i16 %0, %1, %2, 0 clamp" : "=v"(d) : "v"(a), "v"(b));
     return d;
 }
+// four columns: key dword w against the constants ue / uo / s7 of those columns
+__device__ __forceinline__ int dword_sum7(uint32_t w, uint32_t ue, uint32_t uo, uint32_t s7, int acc)
+{
+    const uint32_t pe = pk_mul_sat_i16(w & 0x007F007Fu, ue);                    // bytes 0 and 2
+    const uint32_t po = pk_mul_sat_i16((w >> 8) & 0x007F007Fu, uo);             // bytes 1 and 3
+    const uint32_t tb = __builtin_amdgcn_perm(po, pe, 0x07030501u);             // the four high bytes, in column order
+    const uint32_t sb = (w ^ s7) & 0x80808080u;
+    const uint32_t sg = __builtin_amdgcn_perm(0x01010101u, 0x01010101u, sb);
+    return __builtin_amdgcn_sdot4((int)tb, (int)sg, acc, false);
+}
 __device__ __forceinline__ int lane_row_sum7(const i32x4 x, const ScanConst &c)
 {
     int acc = 0;
 #pragma unroll
-    for (int d = 0; d < 4; d++) {
-        const uint32_t w = (uint32_t)x[d];
-        const uint32_t pe = pk_mul_sat_i16(w & 0x007F007Fu, c.ue[d]);           // bytes 0 and 2
-        const uint32_t po = pk_mul_sat_i16((w >> 8) & 0x007F007Fu, c.uo[d]);    // bytes 1 and 3
-        const uint32_t tb = __builtin_amdgcn_perm(po, pe, 0x07030501u);         // the four high bytes, in column order
-        const uint32_t sb = (w ^ c.s7[d]) & 0x80808080u;
-        const uint32_t sg = __builtin_amdgcn_perm(0x01010101u, 0x01010101u, sb);
-        acc = __builtin_amdgcn_sdot4((int)tb, (int)sg, acc, false);
-    }
+    for (int d = 0; d < 4; d++) acc = dword_sum7((uint32_t)x[d], c.ue[d], c.uo[d], c.s7[d], acc);
     return acc;
 }
 // make_scan_const for that form: |u| << (8 - fv), saturated at 0x7FFF
@@ -370,6 +372,53 @@ __device__ __forceinline__ float wave_serial_sum_f32(float e, uint32_t S)
     float tot = 0.0f;
     for (uint32_t r = 0; r < S; r++) tot += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e), (int)r));
     return tot;
+}
+
+// The same total for memories of any length: ONE wavefront walks the slots 64 at a time.  Every lane fetches its slot's term
+// (e_of(slot): a table look-up or an exp, 64 in flight), then the 64 dependent additions run in the last lane of each 16-lane
+// row through DPP row shifts (lane 15 of a row reads lane 15 - k), the four rows one after the other, a row's sum handed to the
+// next row by row_bcast:15 and a group's to the next group through lane 63: one vector instruction per slot, and exactly the
+// float additions of lib/layer.c:1236 in their order.  (An order-free double sum -- what these kernels did through round 3 --
+// agrees within 1e-7 relative, which is enough to move a weight code where p sits on a truncation step of Q(p).)
+// Every lane of the calling wavefront gets the total.
+template <typename EOf>
+__device__ __forceinline__ float wave_serial_total_f32(uint32_t S, uint32_t lane, EOf e_of)
+{
+    float t = 0.0f;
+    for (uint32_t g = 0; g < S; g += (uint32_t)kWave) {
+        const uint32_t r = g + lane;
+        const float e = r < S ? e_of(r) : 0.0f;                        // (+0 leaves the sum as it is)
+        const int eb = __builtin_bit_cast(int, e);
+#define QM_SER_STEP(K) t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, eb, 0x110 + K, 0xF, 0xF, true))
+#define QM_SER_ROW()                                                                                                   \
+        QM_SER_STEP(15); QM_SER_STEP(14); QM_SER_STEP(13); QM_SER_STEP(12); QM_SER_STEP(11); QM_SER_STEP(10); QM_SER_STEP(9);    \
+        QM_SER_STEP(8); QM_SER_STEP(7); QM_SER_STEP(6); QM_SER_STEP(5); QM_SER_STEP(4); QM_SER_STEP(3); QM_SER_STEP(2);        \
+        QM_SER_STEP(1); t += e
+#define QM_SER_NEXT(ROWMASK) t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, t), __builtin_bit_cast(int, t), 0x142, ROWMASK, 0xF, false))
+        QM_SER_ROW(); QM_SER_NEXT(0x2);                                 // row 0, its sum to lane 31
+        QM_SER_ROW(); QM_SER_NEXT(0x4);
+        QM_SER_ROW(); QM_SER_NEXT(0x8);
+        QM_SER_ROW();                                                   // lane 63: the total so far
+#undef QM_SER_NEXT
+#undef QM_SER_ROW
+#undef QM_SER_STEP
+        t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 63));
+    }
+    return t;
+}
+// ... for a workgroup: wavefront 0 walks, the others wait; `slot` one LDS double all of them can see
+template <typename EOf>
+__device__ __forceinline__ double block_serial_total_f32(uint32_t S, uint32_t lane, uint32_t wave, double *slot, EOf e_of)
+{
+    __syncthreads();                                                    // the tables e_of reads are complete
+    if (wave == 0) {
+        const float t = wave_serial_total_f32(S, lane, e_of);
+        if (lane == 0) slot[0] = (double)t;
+    }
+    __syncthreads();
+    const double r = slot[0];
+    __syncthreads();
+    return r;
 }
 
 // Stages after the softmax, shared by every attention mode:

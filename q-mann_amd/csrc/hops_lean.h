@@ -114,7 +114,7 @@ __device__ __forceinline__ uint32_t fetch_scan_const(ScanConst &c, const uint8_t
     return 16u - wl;
 }
 
-// W7: every matrix format of the launch (attention and linear-map weights) has word length 7
+// W7: every format of the launch (attention, linear-map weights, activations) has word length 7 -- the stock 8-bit configurations
 template <bool W7>
 __device__ __forceinline__ void publish_const(uint8_t *lw, uint32_t lane, int k, uint32_t wl, int fv)
 {
@@ -179,6 +179,42 @@ __device__ __forceinline__ void lean_stage_tables(const HopArgs &a, const LeanAr
     }
 }
 
+// does a story of S rows end in a narrow pass (see lean_hop)?
+template <int MODE, bool W7>
+__device__ __forceinline__ bool lean_tail_rows(uint32_t S)
+{
+    return MODE == kModeFixed && W7 && (S & 15u) != 0u && (S & 15u) <= 4u;
+}
+
+// The read-out weight code Q(p) = min(trunc(p . 2^frac), maxa) of a slot, p = the softmax quotient of `sm_quot`.
+// For the e^x base the reference's quotient is (float)((double)e / total) (lib/layer_cuda.cu:2039): a double division per lane,
+// some 25 vector instructions, to produce an integer that is 0 for almost every slot.  The code only needs to know on which side
+// of the steps k . 2^-frac the quotient falls, so it is first taken from x = e . (2^frac . rcp((float)total)) -- off from
+// p . 2^frac by less than x . 2^-21 <= 2^-14 (one ulp of v_rcp_f32, the rounding of total to float, the product's rounding,
+// the final rounding of p itself) -- and that answer is final unless some lane's x lies within 2^-11 of an integer >= 1: then,
+// and only then (a wavefront-uniform branch; a few launches in a thousand take it), every lane runs the exact division.
+// Bit-identical to always dividing; ~18 instructions per hop less.
+__device__ __forceinline__ int lean_weight_code(float e, double total, bool live, const SmCfg &smc, QFmt fa, int maxa)
+{
+    int kp;
+    if (smc.base == QMANN_SOFTMAX_EXP && !smc.shift) {
+        const float r2 = __builtin_ldexpf(__builtin_amdgcn_rcpf((float)total), (int)fa.frac);      // (wavefront-uniform value)
+        const float x = live ? e * r2 : 0.0f;                          // (an empty story has total = 0)
+        const float xr = __builtin_rintf(x);
+        const bool near = xr >= 1.0f && __builtin_fabsf(x - xr) <= 4.8828125e-04f;
+        if (__builtin_expect(__ballot(near) != 0, 0)) {
+            const float p = live ? (float)((double)e / total) : 0.0f;
+            kp = (int)__builtin_ldexpf(p, (int)fa.frac);
+        } else {
+            kp = (int)x;
+        }
+    } else {
+        const float p = live ? sm_quot(e, total, smc) : 0.0f;
+        kp = (int)__builtin_ldexpf(p, (int)fa.frac);
+    }
+    return kp > maxa ? maxa : kp;
+}
+
 // The end of a hop, shared by the one-wavefront kernels (this file and hops_mid.h): the read-out code `acc` of column `lane`
 // is clamped and published, the linear map H.u runs on the pre-split rows in LDS, and u' = Qa(Qa(Hu) + Qa(o)) replaces `u`.
 //   kb_code   Q_bin(u) of column `lane` (the linear map's operand)
@@ -192,8 +228,8 @@ __device__ __forceinline__ void lean_finish_hop(const HopArgs &a, uint32_t h, ui
     constexpr uint32_t LPR = 4;
     const uint32_t sub = lane >> 2, chunk = lane & 3u, D = a.D;
     const QFmt fa = a.act[h], fb = a.bin, fw = a.w[h];
-    const int maxa = (1 << (fa.iwl + fa.frac)) - 1;
-    const uint32_t wl_w = fw.iwl + fw.frac;
+    const int maxa = W7 ? 127 : (1 << (fa.iwl + fa.frac)) - 1;        // (W7: every format of the launch has word length 7)
+    const uint32_t wl_w = W7 ? 7u : fw.iwl + fw.frac;
     auto publish_o = [&]() {
         int acc = acc_of();
         acc = acc > maxa ? maxa : (acc < -maxa ? -maxa : acc);
@@ -251,19 +287,20 @@ __device__ __forceinline__ void lean_finish_hop(const HopArgs &a, uint32_t h, ui
 //                     them, four at the default Q5.2) are fetched from global memory `vg` (this story's rows of the hop's value
 //                     plane), the first four requested BEFORE before_readout() and the linear map, which hide their round trip.
 //                     At |mem| = 50 the whole-tile read doubled the kernel's HBM traffic and the kernel was bound by it.
+//   tail_key          lean_tail_rows(S): this lane's dword (piece lane & 15) of key row (S & ~15) + (lane >> 4)
 template <int MODE, int NB, bool W7, bool SPARSE, typename KeyOf, typename BeforeReadout>
 __device__ __forceinline__ void lean_hop(const HopArgs &a, const LeanArgs &la, uint32_t h, uint32_t S, uint32_t lane, const uint8_t *vt,
                                          uint8_t *lw, const uint8_t *lmap, const float *etab, float &u, KeyOf key_of,
-                                         BeforeReadout before_readout, const uint8_t *vg = nullptr)
+                                         BeforeReadout before_readout, const uint8_t *vg = nullptr, int tail_key = 0)
 {
     constexpr uint32_t Dp = 64, LPR = 4;
     const uint32_t sub = lane >> 2, chunk = lane & 3u, D = a.D;
     const QFmt fa = a.act[h], fm = a.att[h], fb = a.bin, fw = a.w[h];
-    const int maxa = (1 << (fa.iwl + fa.frac)) - 1;
+    const int maxa = W7 ? 127 : (1 << (fa.iwl + fa.frac)) - 1;
     const bool relu = hop_relu(a, h);
     // ---- column c: operand codes -----------------------------------------------------------------
     const int kb_code = (lane < D) ? qm_code_or_sign(u, fb.iwl, fb.frac) : 0;        // Q_bin(u): linear map (and fixed scores)
-    const uint32_t wl_m = fm.iwl + fm.frac, wl_w = fw.iwl + fw.frac;
+    const uint32_t wl_m = (W7 && MODE == kModeFixed) ? 7u : fm.iwl + fm.frac, wl_w = W7 ? 7u : fw.iwl + fw.frac;
     if (MODE == kModeFixed) {
         int ka = kb_code;
         if (relu && ka < 0) ka = (fb.iwl + fb.frac == 0) ? 1 : 0;                    // see make_scan_const
@@ -278,10 +315,14 @@ __device__ __forceinline__ void lean_hop(const HopArgs &a, const LeanArgs &la, u
     ScanConst csc;
     uint32_t csh = 0;
     float unit = 1.0f;
+    // A story's last 1 .. 4 rows (S mod 16 <= 4) do not get a whole pass of 16 rows x 4 lanes: they take the narrow pass below,
+    // 4 rows x 16 lanes x one dword (lean_tail_rows(): fixed-point scores at word length 7, the stock configuration).  At the
+    // bAbI cap of 50 rows that is 3 passes + a quarter instead of 4; a 1 .. 4-row story needs no full pass at all.
+    const uint32_t S_reg = lean_tail_rows<MODE, W7>(S) ? (S & ~15u) : S;       // rows the regular passes cover
     auto scan = [&](auto lane_sum, int lim, bool wrap = false) {         // wrap: mode 3's final quantiser (appx_clamp, ham_common.h)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            if (j * 16 < (int)S) {                                // wavefront-uniform
+            if (j * 16 < (int)S_reg) {                            // wavefront-uniform
                 const int v = row_lanes_sum<LPR>(lane_sum(key_of(j)));
                 if (chunk == 0) *(int16_t *)(lw + kLwSc + (j * 16 + sub) * 2) = (int16_t)(v > lim ? lim : (v < -lim ? -lim : ((wrap && v == -lim) ? 0 : v)));
             }
@@ -291,6 +332,13 @@ __device__ __forceinline__ void lean_hop(const HopArgs &a, const LeanArgs &la, u
         unit = qm_scale_down(1.0f, fm.frac);
         csh = fetch_scan_const(csc, lw, chunk, wl_m);
         scan([&](const i32x4 x) { return lane_sum_w<W7>(x, csc, csh); }, (1 << wl_m) - 1);
+        if (lean_tail_rows<MODE, W7>(S)) {                        // wavefront-uniform
+            const uint32_t c16 = lane & 15u, row = S_reg + (lane >> 4);
+            const int v = row_lanes_sum<16>(dword_sum7((uint32_t)tail_key, *(const uint32_t *)(lw + kLwE + c16 * 4),
+                                                       *(const uint32_t *)(lw + kLwO + c16 * 4), *(const uint32_t *)(lw + kLwS + c16 * 4), 0));
+            const int lim = (1 << wl_m) - 1;
+            if (c16 == 0 && row < S) *(int16_t *)(lw + kLwSc + row * 2) = (int16_t)(v > lim ? lim : (v < -lim ? -lim : v));
+        }
     } else if (mode_is_appx(MODE)) {
         unit = 1.0f / 1024.0f;
         AppxConst c;
@@ -324,10 +372,8 @@ __device__ __forceinline__ void lean_hop(const HopArgs &a, const LeanArgs &la, u
     }
     total = smc.base == QMANN_SOFTMAX_EXP ? wave_sum_f64((double)e)            // the CUDA kernel's double total
                                           : (double)wave_serial_sum_f32(e, S);     // the CPU softmax's float total, in slot order
-    const float p = live ? sm_quot(e, total, smc) : 0.0f;
     // Q(p) for 0 <= p <= 1: trunc(p . 2^frac), saturated (qm_code without the cases a probability cannot reach)
-    int kp = (int)__builtin_ldexpf(p, (int)fa.frac);
-    kp = kp > maxa ? maxa : kp;
+    int kp = lean_weight_code(e, total, live, smc, fa, maxa);
 
     // ---- read-out over the rows whose weight code is non-zero (lane c owns column c) -----------------
     uint64_t m = __ballot(kp != 0);
@@ -377,7 +423,7 @@ __device__ __forceinline__ void lean_hop(const HopArgs &a, const LeanArgs &la, u
 }
 
 template <int MODE, int NB, bool W7, bool SPARSE>
-__global__ void __launch_bounds__(kLeanBlock)
+__global__ void __launch_bounds__(kLeanBlock, 4)          // four wavefronts per SIMD (two workgroups per CU): at most 128 registers
 k_hops_lean(const HopArgs a, const LeanArgs la)
 {
     constexpr uint32_t Dp = 64;
@@ -394,10 +440,10 @@ k_hops_lean(const HopArgs a, const LeanArgs la)
     lean_stage_tables(a, la, etab, lmap, tid, kLeanBlock);
     __syncthreads();
 
-    const size_t q_stride = (size_t)gridDim.x * kLeanWaves, n_query = a.rows_total;   // (rows_total carries the query count, see launcher)
+    const uint32_t q_stride = gridDim.x * kLeanWaves, n_query = a.rows_total;   // (rows_total carries the query count, < 2^24: qmann_hops_i8)
     // The next query's first key tile and its u0 are requested during the current query's last hop (its row offsets
     // a query earlier still), so a wavefront does not sit through a cold HBM round trip at every query start.
-    size_t q = (size_t)blockIdx.x * kLeanWaves + wave;
+    uint32_t q = blockIdx.x * kLeanWaves + wave;
     if (q >= n_query) return;
     uint32_t r0 = a.row_off[q], S;
     {
@@ -407,21 +453,30 @@ k_hops_lean(const HopArgs a, const LeanArgs la)
         S = S_in < a.max_slots ? S_in : a.max_slots;
     }
     i32x4 kq[4];
+    int kt = 0;                                                         // the narrow tail pass's dword (lean_hop)
     float u_next;
     // keys of hop h of the query whose rows start at `base` (S_ rows)
     auto load_keys_of = [&](uint32_t h, uint32_t base, uint32_t S_) {
-        const uint8_t *kb = (const uint8_t *)a.keys + (size_t)h * a.key_hop_stride + (size_t)base * Dp + chunk * 16;
+        const uint8_t *k0 = (const uint8_t *)a.keys + (size_t)h * a.key_hop_stride + (size_t)base * Dp;
+        const uint8_t *kb = k0 + chunk * 16;
+        const bool tail = lean_tail_rows<MODE, W7>(S_);
+        const uint32_t S_reg = tail ? (S_ & ~15u) : S_;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const uint32_t r = j * 16 + sub;
             kq[j] = i32x4{0, 0, 0, 0};
-            if (r < S_) kq[j] = __builtin_nontemporal_load((const i32x4 *)(kb + (size_t)r * Dp));   // (streamed once: keep it out of the caches' way)
+            if (r < S_reg) kq[j] = __builtin_nontemporal_load((const i32x4 *)(kb + (size_t)r * Dp));   // (streamed once: keep it out of the caches' way)
+        }
+        if (MODE == kModeFixed && W7) {
+            const uint32_t rt = S_reg + (lane >> 4);
+            kt = 0;
+            if (tail && rt < S_) kt = __builtin_nontemporal_load((const int *)(k0 + (size_t)rt * Dp + (lane & 15u) * 4));
         }
     };
     load_keys_of(0, r0, S);
     u_next = (lane < D) ? a.u0[q * D + lane] : 0.0f;
     for (; q < n_query; q += q_stride) {
-        const size_t qn = q + q_stride;
+        const uint32_t qn = q + q_stride;
         uint32_t r0n = 0, Sn = 0;
         if (qn < n_query) {
             r0n = a.row_off[qn];
@@ -453,7 +508,7 @@ k_hops_lean(const HopArgs a, const LeanArgs la)
                     load_keys_of(0, r0n, Sn);
                     u_next = (lane < D) ? a.u0[qn * D + lane] : 0.0f;
                 }
-            }, vg);
+            }, vg, kt);
         }
         if (lane < D) a.u_out[q * D + lane] = relu_if(u, a.en_non_lin != 0);
         r0 = r0n; S = Sn;
@@ -489,7 +544,8 @@ inline void launch_lean(const HopArgs &a, uint32_t max_slots, uint32_t n_query, 
 {
     bool w7 = true;
     for (uint32_t h = 0; h < a.n_hop; h++)
-        w7 = w7 && (MODE != kModeFixed || a.att[h].iwl + a.att[h].frac == 7) && (!a.en_lin_map || a.w[h].iwl + a.w[h].frac == 7);
+        w7 = w7 && (MODE != kModeFixed || a.att[h].iwl + a.att[h].frac == 7) && (!a.en_lin_map || a.w[h].iwl + a.w[h].frac == 7) &&
+             a.act[h].iwl + a.act[h].frac == 7;
     // Sparse read-out (only the value rows that survive Q(p) are fetched, lean_hop) where those rows -- at most 2^frac_act per
     // hop -- are a small part of the longest story; otherwise the whole value tile is copied to LDS at the start of the hop.
     // QMANN_LEAN_SPARSE=0 / 1 forces the choice (A/B).

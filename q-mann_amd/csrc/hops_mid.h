@@ -9,13 +9,18 @@
 //   * the scan streams the key plane in groups of 64 rows (4 x 16-byte loads per lane), two groups in flight, the next hop's
 //     (or the next query's) first two groups requested before the softmax / read-out / linear map of the current hop;
 //   * scores are 8-bit codes in a per-wavefront LDS array (1 KB); the softmax is one table look-up per slot -- exp(x - max)
-//     takes at most 255 values on the score grid -- and a double total (lib/layer_cuda.cu:2024-2042);
+//     takes at most 255 values on the score grid -- and a double total (lib/layer_cuda.cu:2024-2042); the CPU softmax's bases
+//     (2^x, exp_plan: lib/layer.c:1196-1243) take their tables and the serial float total of hops_common.h;
 //   * a slot can carry a non-zero read-out weight Q(p) only if e >= total . 2^-frac (up to float rounding): only those few
 //     slots get the exact quotient (float)((double)e / total) of the reference, and only their value rows are read (the others
 //     contribute exact zeros, :562);
 //   * the hop's tail (linear map on the LDS images, u' = Qa(Qa(Hu) + Qa(o))) is hops_lean.h's.
-// Same arithmetic, stage by stage, as k_hops_fixed; tests/test_gpu_mid.py holds the two against each other bit for bit and
-// this kernel against the oracle.  Taken by qmann_hops_i8 for 64 < max_slots <= 1 024 when mid_supported() holds.
+// Same arithmetic, stage by stage, as k_hops_fixed; tests/test_gpu_mid.py holds the two against each other and this kernel
+// against the oracle.  One stage is NOT order-identical between the two: the e^x base's double total is a per-slot tree here and
+// a histogram sum (count . e per score code) there -- equal to the last bit or two of a double, which shows only where a weight
+// sits exactly on a truncation step of Q(p) (two tied top scores at one or two fraction bits: 1 in ~240 random-format soak
+// cases; tools/soak.py reports the count).  Neither order is the reference's serial one (lib/layer_cuda.cu:2024); the oracle
+// sums serially and such cases are the ones the tests excuse with the oracle's evidence that a p lies on a step.  Taken by qmann_hops_i8 for 64 < max_slots <= 1 024 when mid_supported() holds.
 #pragma once
 #include "hops_lean.h"
 
@@ -168,16 +173,21 @@ k_hops_mid(const HopArgs a, const LeanArgs la)
             if (S > 0) {
                 const int mxc = wave_max_i32(mx);
                 const float *et = etab + h * 256u;
-                double part = 0.0;
-                for (uint32_t g = 0; g < n_g; g++) {
-                    const uint32_t s = g * 64u + lane;
-                    if (s < S) part += (double)et[(uint32_t)(mxc - (int)sc[s])];
+                const SmCfg smc = sm_cfg(a, h);
+                double total;
+                if (smc.base == QMANN_SOFTMAX_EXP) {                  // the CUDA kernel's double total (lib/layer_cuda.cu:2024-2042)
+                    double part = 0.0;
+                    for (uint32_t g = 0; g < n_g; g++) {
+                        const uint32_t s = g * 64u + lane;
+                        if (s < S) part += (double)et[(uint32_t)(mxc - (int)sc[s])];
+                    }
+                    total = wave_sum_f64(part);
+                } else {                                              // 2^x, exp_plan: the CPU softmax's float total, slot by slot (lib/layer.c:1236)
+                    total = (double)wave_serial_total_f32(S, lane, [&](uint32_t s) { return et[(uint32_t)(mxc - (int)sc[s])]; });
                 }
-                const double total = wave_sum_f64(part);
                 // Q(p) != 0 needs p >= 2^-frac; p = (float)(e / total) rounds by at most 2^-24 relative, so a slot with
                 // e < total . 2^-frac . (1 - 2^-20) cannot reach it.  Only the others get the exact quotient.
                 const float thr = (float)(total * (double)qm_scale_down(1.0f, fa.frac) * (1.0 - 9.5367431640625e-07));
-                const SmCfg smc = sm_cfg(a, h);
                 const uint8_t *vb = (const uint8_t *)a.vals + (size_t)h * a.hop_stride + (size_t)r0 * Dp + lane;
                 for (uint32_t g = 0; g < n_g; g++) {
                     const uint32_t s = g * 64u + lane;
@@ -218,11 +228,12 @@ k_hops_mid(const HopArgs a, const LeanArgs la)
     }
 }
 
-// what this kernel covers: fixed-point attention with the e^x softmax from a table (no shift-based form, no scale layer),
+// what this kernel covers: fixed-point attention with the softmax's exponential from a table -- e^x, or the CPU softmax's 2^x /
+// exp_plan with its serial float total (no shift-based form, no scale layer),
 // 64-byte rows, 65 .. 1 024 slots, no taps; everything else keeps the streaming kernel
 inline bool mid_supported(const HopArgs &a, uint32_t max_slots)
 {
-    return a.Dp == 64 && max_slots > (uint32_t)kWave && max_slots <= kMidMaxSlots && a.softmax_base == QMANN_SOFTMAX_EXP &&
+    return a.Dp == 64 && max_slots > (uint32_t)kWave && max_slots <= kMidMaxSlots && a.softmax_base <= QMANN_SOFTMAX_EXP_PLAN &&
            !a.softmax_shift && !a.en_att_scale && !a.tap_codes && !a.tap_scores && !a.tap_probs && !a.tap_o && !a.tap_u &&
            !qm_tuning().no_mid;
 }
@@ -248,7 +259,8 @@ inline void launch_mid(const HopArgs &a, uint32_t max_slots, uint32_t n_query, h
 {
     bool w7 = true;
     for (uint32_t h = 0; h < a.n_hop; h++)
-        w7 = w7 && a.att[h].iwl + a.att[h].frac == 7 && (!a.en_lin_map || a.w[h].iwl + a.w[h].frac == 7);
+        w7 = w7 && a.att[h].iwl + a.att[h].frac == 7 && (!a.en_lin_map || a.w[h].iwl + a.w[h].frac == 7) &&
+             a.act[h].iwl + a.act[h].frac == 7;                       // (lean_finish_hop<true> folds every word length to 7)
     if (w7) launch_mid_w<true>(a, max_slots, n_query, st);
     else launch_mid_w<false>(a, max_slots, n_query, st);
 }

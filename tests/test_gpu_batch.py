@@ -737,14 +737,20 @@ def test_hops_softmax_variants(env, oracle, path, variant):
 @pytest.mark.parametrize("base", [1, 2])
 def test_cpu_softmax_bases_on_long_memories(env, oracle, base):
     """The 2^x and exp_plan bases come from the reference's CPU softmax, whose total is a FLOAT added slot by slot
-    (lib/layer.c:1161, :1236).  The kernels for up to 64 slots reproduce that sum as it is; the streaming kernels (65 slots
-    and more) add the terms of a score histogram in double -- an order-free sum of thousands of float terms cannot be the
-    serial float one.  The probabilities then agree within the 1e-5 tolerance, and a hop output may differ from the oracle's
-    (which sums serially in float) ONLY where a softmax weight lies within 1e-5 of a truncation step of Q(p); how often that
-    happens is bounded here: observed 0 of 40 queries per base + 1."""
-    cfg = cfg_synth(60, 40, 5, base=base)
-    n = run_case(env, oracle, cfg, B=40, S_list=[65, 200, 1000, 5000, 10000], seed=4200 + base, max_excused=1)
-    print(f"base {base}: {n} of 40 long-memory queries excused")
+    (lib/layer.c:1161, :1236).  Every kernel reproduces that sum as it is -- the short-memory kernels lane by lane, the
+    65 .. 1 024-slot and streaming kernels by one wavefront walking the slots (csrc/hops_common.h: wave_serial_total_f32) -- so
+    the hop outputs equal the oracle's (which sums the same way) with nothing excused, at 65 .. 10 000 slots, on the 64-byte
+    rows of the mid kernel (D = 60) and on wider rows (D = 128: the streaming kernel)."""
+    for D, B in ((60, 40), (128, 15)):
+        cfg = cfg_synth(D, 40, 5, base=base)
+        run_case(env, oracle, cfg, B=B, S_list=[65, 200, 1000, 5000, 10000], seed=4200 + base + D, max_excused=0)
+    run_case(env, oracle, cfg_synth(60, 40, 2, base=base), B=20, S_list=[70, 300, 4000], seed=4300 + base, sigma_k=6.0, max_excused=0)
+
+
+@pytest.mark.parametrize("mode,nb", [(3, 8), (10, 8), (11, 4)])
+def test_cpu_softmax_bases_in_the_hamming_kernels(env, oracle, mode, nb):
+    """the same serial float total behind the Hamming-family scores (csrc/batch_hops_ham.hip), 2^x base, long memories"""
+    run_hamming_case(env, oracle, mode, 128, [65, 300, 5000], B=6, seed=4400 + mode, num_bit=nb, extra=dict(softmax_variant=1))
 
 
 # ---------------------------------------------------------------------------------------------

@@ -89,17 +89,18 @@ def test_fixed_add_and_mul_verbs_equal_the_reference_macros(env, gold):
 
 
 def _ham_inputs(g):
-    """the 4 096 word pairs as 64 one-slot stories of 64 columns: keys = top bytes of one word, u = the other's as grid
-    values of Q5.2.  hamming_similarity{,_w} are symmetric in their operands, so where the u side would need the
-    minus-zero byte (0x80: no float on the grid produces it) the pair is fed the other way round."""
+    """the 4 096 word pairs as 32 one-slot stories of 128 columns (packed planes need rows of at least 16 bytes: 128 columns
+    at one bit per column): keys = top bytes of one word, u = the other's as values of
+    the Q5.2 grid.  A top byte of 0x80 ("minus zero": sign set, the seven magnitude bits clear) on the u side is a negative
+    value too small for the grid -- the reference's operand word FLOAT2FIXED(u, iwl, 31 - iwl) keeps its sign bit and its top
+    seven magnitude bits are zero (lib/common.h:210), which is what the kernels' byte rule reproduces."""
     a = (g["a"].astype(np.int64) & 0xFFFFFFFF) >> 24
     b = (g["b"].astype(np.int64) & 0xFFFFFFFF) >> 24
-    swap = b == 0x80
-    assert not (swap & (a == 0x80)).any()
-    kb = np.where(swap, b, a).astype(np.uint8).reshape(64, 64)
-    ub = np.where(swap, a, b).astype(np.int16).reshape(64, 64)
+    kb = a.astype(np.uint8).reshape(32, 128)
+    ub = b.astype(np.int16).reshape(32, 128)
     u = np.where(ub & 0x80, -(ub & 0x7F), ub & 0x7F).astype(np.float32) / np.float32(4.0)
-    assert (kb == 0x80).any()
+    u[ub == 0x80] = -np.float32(2.0 ** -10)
+    assert (kb == 0x80).any() and (ub == 0x80).any() and ((kb == 0x80) & (ub == 0x80)).any()
     return kb, u
 
 
@@ -115,29 +116,29 @@ def test_popcount_scores_equal_the_reference_hamming_similarity(env, gold, mode,
     ni = int(np.flatnonzero(g["num_bit"] == num_bit)[0])
     kb, u = _ham_inputs(g)
     if mode == 10:
-        want = g["sim"][ni].astype(np.int64).reshape(64, 64).sum(1)
+        want = g["sim"][ni].astype(np.int64).reshape(32, 128).sum(1)
         unit = 1.0
     else:
         w = g["sim_w"][ni].astype(np.float64) * (1 << num_bit)
         assert np.array_equal(w, np.rint(w))                      # weights are multiples of 2^-n
-        want = np.rint(w).astype(np.int64).reshape(64, 64).sum(1)
+        want = np.rint(w).astype(np.int64).reshape(32, 128).sum(1)
         unit = 1.0 / (1 << num_bit)
-    H, D, V = 1, 64, 40
+    H, D, V = 1, 128, 40
     cfg = dict(n_hop=H, dim_emb=D, dim_input=V, attention_mode=mode, softmax_variant=0, f_fixed=True, en_lin_map=True,
                fmt=[(5, 2)], fmt_w=[(5, 2)], fmt_att=[(5, 2)], fmt_bin=(5, 2), num_bit=num_bit)
     rng = np.random.default_rng(1)
     wts = {"w_h": [rng.normal(0, 1, (D, D)).astype(np.float32)], "w_ans": rng.normal(0, 0.1, (V, D)).astype(np.float32)}
     net = model.QNet(cfg, wts, device="cuda:0")
-    assert net.Dp == 64
-    dk = torch.from_numpy(kb.view(np.int8).reshape(1, 64, 64)).to(env.dev)
+    assert net.Dp == 128
+    dk = torch.from_numpy(kb.view(np.int8).reshape(1, 32, 128)).to(env.dev)
     dv = torch.zeros_like(dk)
-    ro = torch.arange(65, dtype=torch.int32, device=env.dev)                        # 64 stories of one slot
+    ro = torch.arange(33, dtype=torch.int32, device=env.dev)                        # 32 stories of one slot
     du = torch.from_numpy(u).to(env.dev)
     if packed:
         planes = net.pack_planes(dk, num_bit)
         pl = planes.cpu().numpy().view(np.uint64)                                   # the planes themselves: bit i of every byte
         for i in range(num_bit):
-            bits = ((kb >> (7 - i)) & 1).reshape(64, 1, 64)
+            bits = ((kb >> (7 - i)) & 1).reshape(32, 2, 64)
             np.testing.assert_array_equal(pl[0, :, :, i], np.packbits(bits, axis=-1, bitorder="little").view(np.uint64)[..., 0])
         _, taps = net.hops_packed(planes, dv, ro, 1, du, taps=True)
     else:

@@ -187,12 +187,23 @@ def test_mid_random_formats(env, seed):
     both_paths(env, cfg, B=50, S_list=[1, 65, 100, 400, 1024], seed=7100 + seed, sigma_k=25.0)
 
 
+@pytest.mark.parametrize("base", [1, 2])
+@pytest.mark.parametrize("iwl", [5, 2])
+def test_mid_cpu_softmax_bases_equal_streaming_kernel_and_oracle(env, oracle, base, iwl):
+    """2^x and exp_plan (the reference's CPU softmax, lib/layer.c:1196-1243): tables of those exponentials and the CPU
+    softmax's FLOAT total added slot by slot (csrc/hops_common.h: wave_serial_total_f32) in this kernel and in the streaming
+    kernel alike -- identical to each other and to the oracle, which sums the same way: nothing to excuse"""
+    both_paths(env, cfg_of(iwl=iwl, softmax_variant=base), B=len(SLOTS) * 3, S_list=SLOTS, seed=1400 + base + iwl, oracle=oracle,
+               n_oracle=len(SLOTS) * 3, max_excused=0)
+    both_paths(env, cfg_of(iwl=iwl, softmax_variant=base), B=64, S_list=[200, 1000, 65, 1024], seed=1410 + base, oracle=oracle,
+               n_oracle=24, sigma_k=6.0, max_excused=0)          # flat scores: thousands of comparable terms in the total
+
+
 def test_other_softmax_forms_keep_the_streaming_kernel(env):
-    """the 2^x / exp_plan bases, the shift-based form and the scale layer are not this kernel's: the request must still be
-    served (by the streaming kernel), with and without taps alike"""
+    """the shift-based form and the scale layer are not this kernel's: the request must still be served (by the streaming
+    kernel), with and without taps alike"""
     torch, model = env.torch, env.model
-    for extra in (dict(softmax_variant=1), dict(softmax_variant=2), dict(att_scale=[-0.5, 0.25, -0.125]),
-                  dict(softmax_variant=1, softmax_shift_based=True)):
+    for extra in (dict(att_scale=[-0.5, 0.25, -0.125]), dict(softmax_variant=1, softmax_shift_based=True)):
         cfg = cfg_of(); cfg.update(extra)
         wts, keys, vals, u0, n_slots, row_off = make_batch(env, cfg, 30, [70, 200], 1300)
         net = model.QNet(cfg, wts, device="cuda:0")
