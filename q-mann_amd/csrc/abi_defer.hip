@@ -485,10 +485,9 @@ bool submit(const Op &op)
 void sync_point(bool writes)
 {
     std::lock_guard<std::recursive_mutex> hold(g_lock);
-    if (g_mode == kOff) return;
     init_mode();
-    drain();
-    if (writes && g_model_valid) drop_model();
+    if (g_mode != kOff) drain();
+    if (writes && g_model_valid) drop_model();      // (also while the queue is switched off: the cache outlives the switch)
 }
 
 }  // namespace qmdefer

@@ -1007,8 +1007,11 @@ k_embed_story_idx(const EmbedIdxArgs a)
 constexpr uint32_t kEmRows = 16;                        // story rows per tile
 constexpr uint32_t kEmDupCap = 128;                     // repeated (row, word) pairs a tile can hold: 16 rows x 16 slots / 2
 
+// wavefronts per SIMD each instantiation is compiled for (its register budget; the launcher sizes the persistent grid by it)
+constexpr int em_waves_per_simd(int KS) { return KS == 1 ? 5 : 4; }
+
 template <int KS, int NW>                               // K / 64: 1, 2 or 4; wavefronts per workgroup (they share T^T)
-__global__ void __launch_bounds__(NW * kWave)
+__global__ void __launch_bounds__(NW * kWave, em_waves_per_simd(KS))
 k_embed_story_mfma(const EmbedIdxArgs a)
 {
     constexpr uint32_t kBlockEm = NW * kWave;
@@ -1349,7 +1352,8 @@ int qmann_answer_f32(const qmann_net *net, const float *w_ans, const float *u, c
     const size_t lds_small = ((size_t)D * lpq * vpt + (size_t)kAnsWaves * qpw * D) * sizeof(float);
     if (V <= 256u && lds_small <= 78 * 1024) {              // W^T fits LDS twice per CU
         const uint32_t need = (n_query + kAnsWaves * qpw - 1) / (kAnsWaves * qpw);
-        const uint32_t blocks = need < 512u ? need : 512u;  // persistent: two 16-wavefront workgroups per CU
+        const uint32_t cap = qm_resident_groups(kAnsWaves, 8, lds_small);      // persistent: two 16-wavefront workgroups per CU
+        const uint32_t blocks = need < cap ? need : cap;
         hipStream_t st = (hipStream_t)stream;
 #define QM_ANS_SMALL(L, N, Q)                                                                                                    \
     do {                                                                                                                         \
@@ -1579,9 +1583,10 @@ int qmann_embed_story_idx(const qmann_net *net, const uint16_t *words, uint32_t 
         const uint32_t nwv = K == 64 ? 8u : 16u;
         const size_t lds = 2u * (size_t)Dp * (K + 16u) + (size_t)nwv * (kEmRows * (K + 16u) + kEmRows * (Dp + 16u) + kEmDupCap * 4u + 16u);
         const size_t tiles = ((size_t)rows_total + kEmRows - 1) / kEmRows;
-        const uint32_t per_cu_l = (uint32_t)(160u * 1024u / (lds + 256u)), per_cu_w = 32u / nwv;
-        const uint32_t per_cu = per_cu_l < per_cu_w ? (per_cu_l ? per_cu_l : 1u) : per_cu_w;
-        const uint32_t cap = 256u * per_cu / net->n_hop + 1u;
+        // persistent in x: never more workgroups than are resident at once (rt.h: through round 3 the cap was LDS-only and
+        // rounded UP -- 86 x 3 = 258 workgroups for 256 one-per-CU slots on the joint dictionaries, 1 026 for 512 on task 1)
+        const uint32_t resident = qm_resident_groups(nwv, (uint32_t)em_waves_per_simd(K == 64 ? 1 : (K == 128 ? 2 : 4)), lds);
+        const uint32_t cap = resident / net->n_hop ? resident / net->n_hop : 1u;
         const uint32_t nx = (uint32_t)((tiles + nwv - 1) / nwv < cap ? (tiles + nwv - 1) / nwv : cap);
         const dim3 grid(nx, net->n_hop);
         hipStream_t st = (hipStream_t)stream;
@@ -1603,12 +1608,12 @@ int qmann_embed_story_idx(const qmann_net *net, const uint16_t *words, uint32_t 
     const size_t wave_lds = (size_t)kWaves * kEwWaveBytes;
     if (tab_lds + wave_lds <= 64 * 1024) {
         const size_t lds = tab_lds + wave_lds;
-        const uint32_t per_cu = (uint32_t)(160u * 1024u / (lds + 256u));
-        const uint32_t cap = 256u * (per_cu < 8u ? per_cu : 8u);
+        const uint32_t cap = qm_resident_groups(kWaves, 4, lds);          // (118 registers: four wavefronts per SIMD)
         if (lds > 48 * 1024) QM_HIP(hipFuncSetAttribute((const void *)k_embed_story_idx<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         k_embed_story_idx<true><<<need < cap ? need : cap, kBlock, lds, (hipStream_t)stream>>>(a);
     } else {
-        k_embed_story_idx<false><<<need < 2048u ? need : 2048u, kBlock, wave_lds, (hipStream_t)stream>>>(a);
+        const uint32_t cap = qm_resident_groups(kWaves, 4, wave_lds);
+        k_embed_story_idx<false><<<need < cap ? need : cap, kBlock, wave_lds, (hipStream_t)stream>>>(a);
     }
     QM_LAUNCH_CHECK();
     return qm_scope.rc();

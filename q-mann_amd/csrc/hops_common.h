@@ -64,6 +64,10 @@ constexpr uint32_t kOffScores = kOffRed + 64;                      // i8    [slo
 static_assert(kOffScores % 16 == 0, "score bytes must start 16-byte aligned");
 
 
+// raw buffer resources (bounds-checked loads: hops_mid.h)
+constexpr int kRawBufferFlags = 0x00020000;         // dword 3 of a raw buffer resource on gfx9 / CDNA: 32-bit data format, no swizzle
+constexpr int kBufferNt = 2;                        // cache policy of a buffer load: nt (streamed once)
+
 template <int CTRL>
 __device__ __forceinline__ int dpp_add(int v)
 {

@@ -55,7 +55,6 @@ k_hops_mid(const HopArgs a, const LeanArgs la)
     const uint32_t q_stride = gridDim.x * kMidWaves, n_query = a.rows_total;   // (rows_total carries the query count, see launcher)
     uint32_t q = blockIdx.x * kMidWaves + wave;
     if (q >= n_query) return;
-    const uint32_t R_end = a.row_off[n_query];                          // rows of a plane that belong to this batch
     auto slots_of = [&](uint32_t qq, uint32_t &r0_, uint32_t &S_) {
         r0_ = a.row_off[qq];
         const uint32_t S_in = a.row_off[qq + 1] - r0_;
@@ -64,43 +63,36 @@ k_hops_mid(const HopArgs a, const LeanArgs la)
     uint32_t r0, S;
     slots_of(q, r0, S);
 
-    // Group g of a query = its rows 64 g .. 64 g + 63: four 16-byte loads per lane (rows gs + 16 j + sub, piece `chunk`), one
-    // lane offset and immediate row offsets.  A group that would run past the END OF THE STORY is moved back to end there
-    // (gs = S - 64 < 64 g: the rows it repeats were requested a moment ago by the group before it -- the two are in flight
-    // together, so the repeat is served by the cache, not by HBM -- and only the passes that hold new rows are summed).  Round 3's
-    // first version let such a group run into the next story's rows: 1.26 x the algorithmic bytes at 200 slots, and at 0.62 of
-    // the peak in USEFUL bytes the kernel was in fact moving 0.78 of it.  A story shorter than one group still reads into the
-    // next story (moved back only at the plane's end).  A query with fewer than 64 rows left in the plane (the batch's last
-    // ones: "irregular") takes a plain loop with per-row clamping instead, without prefetch.
-    // The steady-state loop holds no branch around a load: the compiler then counts its outstanding loads exactly
-    // (s_waitcnt vmcnt(4) before a group's sums, the other group still in flight).
+    // Group g of a query = its rows 64 g .. 64 g + 63: four 16-byte BUFFER loads per lane (rows 64 g + 16 j + sub, piece
+    // `chunk`) through a raw buffer resource that spans exactly the story's key bytes of the hop: a row past the story's end
+    // reads as zeros and costs no memory traffic, whatever the group.  Round 3 used plain global loads and had to keep them
+    // inside the plane by hand -- a short last group was moved back to end at the story's end (its repeated rows re-read: 1.10 x
+    // the algorithmic bytes at 200 slots), a story shorter than a group read into its neighbour, the batch's last stories took
+    // a separate clamped loop.  All of that is gone: one loop, algorithmic traffic, and the compiler still counts the loads
+    // exactly (no branch around a load: s_waitcnt vmcnt(4) before a group's sums, the other group still in flight).
     const uint32_t lane_off = sub * Dp + chunk * 16u;
     i32x4 xa[4], xb[4];
-    auto key_plane = [&](uint32_t h, uint32_t r0_) { return (const uint8_t *)a.keys + (size_t)h * a.key_hop_stride + (size_t)r0_ * Dp; };
-    // the passes of 16 rows a group at its own place really has (4 for a full group; a short story's only group has fewer: the
-    // arithmetic of the passes it lacks is skipped, their loads still run, branch-free)
-    auto passes_of = [&](uint32_t g, uint32_t S_) { const uint32_t left = S_ > g * 64u ? S_ - g * 64u : 0u; return left >= 64u ? 4u : (left + 15u) / 16u; };
-    // where a story's groups may start at the latest, relative to its first row: its own end - 64, or the plane's for a short story
-    auto lim_of = [&](uint32_t r0_, uint32_t S_) { return S_ >= 64u ? S_ - 64u : R_end - r0_ - 64u; };
-    auto issue = [&](i32x4 (&x)[4], const uint8_t *plane, uint32_t lim, uint32_t g) {      // regular queries only
-        const uint32_t gs = g * 64u < lim ? g * 64u : lim;
-        const uint8_t *p = plane + (size_t)gs * Dp + lane_off;
-#pragma unroll
-        for (int j = 0; j < 4; j++) x[j] = __builtin_nontemporal_load((const i32x4 *)(p + j * 16 * Dp));
+    auto key_rsrc = [&](uint32_t h, uint32_t r0_, uint32_t S_) {
+        return __builtin_amdgcn_make_buffer_rsrc((void *)((const uint8_t *)a.keys + (size_t)h * a.key_hop_stride + (size_t)r0_ * Dp), 0,
+                                                 (int)(S_ * Dp), kRawBufferFlags);
     };
-    auto is_regular = [&](uint32_t r0_, uint32_t S_) { return S_ > 0u && R_end - r0_ >= 64u; };
-    bool regular = is_regular(r0, S);
-    if (regular) { issue(xa, key_plane(0, r0), lim_of(r0, S), 0); issue(xb, key_plane(0, r0), lim_of(r0, S), 1); }
+    auto issue = [&](i32x4 (&x)[4], __amdgpu_buffer_rsrc_t rs, uint32_t g) {
+        const uint32_t off = lane_off + g * (64u * Dp);
+#pragma unroll
+        for (int j = 0; j < 4; j++) x[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off + (uint32_t)j * 16u * Dp), 0, kBufferNt);
+    };
+    // the passes of 16 rows group g really has (4 for a full group, fewer for a story's last one, none past its end): the
+    // arithmetic of the passes it lacks is skipped (their loads ran, branch-free, and brought zeros)
+    auto passes_of = [&](uint32_t g, uint32_t S_) { const uint32_t left = S_ > g * 64u ? S_ - g * 64u : 0u; return left >= 64u ? 4u : (left + 15u) / 16u; };
+    { const __amdgpu_buffer_rsrc_t rs = key_rsrc(0, r0, S); issue(xa, rs, 0); issue(xb, rs, 1); }
     float u_next = (lane < D) ? a.u0[(size_t)q * D + lane] : 0.0f;
 
     for (; q < n_query; q += q_stride) {
         const uint32_t qn = q + q_stride;
         uint32_t r0n = 0, Sn = 0;
         if (qn < n_query) slots_of(qn, r0n, Sn);
-        const bool regular_n = qn < n_query && is_regular(r0n, Sn);
         float u = u_next;
         const uint32_t n_g = (S + 63u) / 64u;
-        const uint32_t lim = lim_of(r0, S);                           // (meaningful for regular queries)
         for (uint32_t h = 0; h < H; h++) {
             const QFmt fa = a.act[h], fm = a.att[h], fb = a.bin, fw = a.w[h];
             const int maxa = (1 << (fa.iwl + fa.frac)) - 1;
@@ -117,53 +109,36 @@ k_hops_mid(const HopArgs a, const LeanArgs la)
             uint32_t csh = fetch_scan_const(csc, lw, chunk, wl_m);
 
             // ---- scan: scores of all rows, 64 rows per step ---------------------------------------------------------
-            const uint8_t *kp = key_plane(h, r0);
+            const __amdgpu_buffer_rsrc_t rs = key_rsrc(h, r0, S);
             int mx = -128;
-            auto consume = [&](const i32x4 (&x)[4], uint32_t g, uint32_t gs, uint32_t p_lo, uint32_t p_hi) {
+            auto consume = [&](const i32x4 (&x)[4], uint32_t g, uint32_t p_hi) {
                 int s[4] = {0, 0, 0, 0};
 #pragma unroll
                 for (uint32_t j = 0; j < 4; j++)
-                    if (j >= p_lo && j < p_hi) s[j] = row_lanes_sum<4>(lane_sum_w<W7>(x[j], csc, csh));      // wavefront-uniform
-                // every lane of a row group holds its row's sum: lane (sub, chunk) keeps row gs + 16 chunk + sub
+                    if (j < p_hi) s[j] = row_lanes_sum<4>(lane_sum_w<W7>(x[j], csc, csh));      // wavefront-uniform
+                // every lane of a row group holds its row's sum: lane (sub, chunk) keeps row 64 g + 16 chunk + sub
                 int v = s[0];
                 v = chunk == 1u ? s[1] : v; v = chunk == 2u ? s[2] : v; v = chunk == 3u ? s[3] : v;
                 const int code = v > maxm ? maxm : (v < -maxm ? -maxm : v);     // Qm of the row sum (lib/layer_cuda.cu:135)
-                const uint32_t r = gs + chunk * 16u + sub;
-                if (r >= g * 64u && r < S) { sc[r] = (int8_t)code; mx = code > mx ? code : mx; }
+                const uint32_t r = g * 64u + chunk * 16u + sub;
+                if (r < S) { sc[r] = (int8_t)code; mx = code > mx ? code : mx; }
             };
-            auto gstart = [&](uint32_t g) { return g * 64u < lim ? g * 64u : lim; };
-            // passes with NEW rows in group g: a group at its own place has them in its first passes_of() passes; a group moved
-            // back (gstart(g) < 64 g) holds them in its LAST passes -- pass j covers rows gstart + 16 j .. + 15 and is new from
-            // (64 g - gstart) / 16 on (the row test in consume() drops the repeated rows of a half-new pass); a group wholly past
-            // the story's end has none
-            auto pass_lo = [&](uint32_t g) { return gstart(g) == g * 64u ? 0u : (g * 64u < S ? (g * 64u - gstart(g)) / 16u : 4u); };
-            auto pass_hi = [&](uint32_t g) { return gstart(g) == g * 64u ? passes_of(g, S) : 4u; };
-            if (regular) {
+            {
                 __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): groups 0 and 1, requested a hop ago, have landed
                 uint32_t g = 0;
                 for (; g + 2 < n_g; g += 2) {                         // steady state: two groups in flight, no branch around a load
-                    consume(xa, g, gstart(g), 0, 4);
-                    issue(xa, kp, lim, g + 2);
-                    consume(xb, g + 1, gstart(g + 1), 0, 4);
-                    issue(xb, kp, lim, g + 3);
+                    consume(xa, g, 4);
+                    issue(xa, rs, g + 2);
+                    consume(xb, g + 1, 4);
+                    issue(xb, rs, g + 3);
                 }
-                consume(xa, g, gstart(g), pass_lo(g), pass_hi(g));
-                consume(xb, g + 1, gstart(g + 1), pass_lo(g + 1), pass_hi(g + 1));       // (a group past the story's end: no pass, nothing stored)
+                consume(xa, g, passes_of(g, S));
+                consume(xb, g + 1, passes_of(g + 1, S));              // (a group past the story's end: no pass, nothing stored)
                 // in flight during the rest of the hop: the next hop's first two groups, or the next query's
-                if (h + 1 < H) { issue(xa, key_plane(h + 1, r0), lim, 0); issue(xb, key_plane(h + 1, r0), lim, 1); }
-            } else if (S > 0) {
-                for (uint32_t g = 0; g < n_g; g++) {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        uint32_t r = g * 64u + (uint32_t)j * 16u + sub;
-                        r = r < S ? r : S - 1u;
-                        xa[j] = *(const i32x4 *)(kp + (size_t)r * Dp + chunk * 16u);
-                    }
-                    consume(xa, g, g * 64u, 0, 4);
-                }
-            }
-            if (h + 1 == H && regular_n) {
-                issue(xa, key_plane(0, r0n), lim_of(r0n, Sn), 0); issue(xb, key_plane(0, r0n), lim_of(r0n, Sn), 1);
+                // (unconditionally: with nothing to come the resource is empty -- r0n = Sn = 0 -- and the loads bring zeros for free)
+                const bool more = h + 1 < H;
+                const __amdgpu_buffer_rsrc_t rn = key_rsrc(more ? h + 1 : 0u, more ? r0 : r0n, more ? S : Sn);
+                issue(xa, rn, 0); issue(xb, rn, 1);
             }
             if (h + 1 == H && qn < n_query) u_next = (lane < D) ? a.u0[(size_t)qn * D + lane] : 0.0f;
             wave_sync();                                              // the score bytes are visible to every lane
@@ -224,7 +199,7 @@ k_hops_mid(const HopArgs a, const LeanArgs la)
             lean_finish_hop<W7>(a, h, lane, lw, lmap, u, [&]() { return acc; }, kb_code, csc, csh, wl_w == wl_m && !relu);
         }
         if (lane < D) a.u_out[(size_t)q * D + lane] = relu_if(u, a.en_non_lin != 0);
-        r0 = r0n; S = Sn; regular = regular_n;
+        r0 = r0n; S = Sn;
     }
 }
 
@@ -250,8 +225,7 @@ inline void launch_mid_w(HopArgs a, uint32_t max_slots, uint32_t n_query, hipStr
     if (lds > kLdsDefaultLimit)
         QM_HIP(hipFuncSetAttribute((const void *)k_hops_mid<W7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint32_t need = (n_query + kMidWaves - 1) / kMidWaves;
-    const uint32_t per_cu = (uint32_t)(160u * 1024u / (lds + 256u));
-    const uint32_t resident = 256u * (per_cu > 2u ? 2u : (per_cu ? per_cu : 1u));
+    const uint32_t resident = qm_resident_groups(kMidWaves, (2 * kMidWaves + 3) / 4, lds);   // (the kernel's __launch_bounds__)
     k_hops_mid<W7><<<need < resident ? need : resident, kMidBlock, lds, st>>>(a, la);
 }
 

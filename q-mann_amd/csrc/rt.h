@@ -60,4 +60,19 @@ struct QmTuning {
 };
 const QmTuning &qm_tuning();                          // (tuning.hip)
 
+// compute units of the current device (256 on an MI355X in SPX mode; fewer in a partitioned mode), asked once
+unsigned qm_cu_count();                               // (tuning.hip)
+
+// Persistent kernels: how many workgroups of `waves` wavefronts are resident AT ONCE on the device, for a kernel compiled for
+// `waves_per_simd` wavefronts per SIMD (its __launch_bounds__) that takes `lds` bytes of LDS per workgroup.  A persistent grid
+// must not exceed this: a workgroup that has to wait for a slot runs after the others, alone on a mostly idle chip -- two extra
+// workgroups on a one-per-CU kernel double its run time (round 4 found three launchers sized by LDS alone).
+static inline unsigned qm_resident_groups(unsigned waves, unsigned waves_per_simd, size_t lds)
+{
+    const unsigned by_regs = waves_per_simd * 4u / waves, by_lds = (unsigned)(160u * 1024u / (lds + 256u)), by_hw = 32u / waves;
+    unsigned per_cu = by_regs < by_lds ? by_regs : by_lds;
+    per_cu = per_cu < by_hw ? per_cu : by_hw;
+    return qm_cu_count() * (per_cu ? per_cu : 1u);
+}
+
 static inline unsigned qm_cdiv(unsigned a, unsigned b) { return (a + b - 1) / b; }

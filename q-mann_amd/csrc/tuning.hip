@@ -30,6 +30,19 @@ const QmTuning &qm_tuning()
     return g_tuning;
 }
 
+unsigned qm_cu_count()
+{
+    static const unsigned n = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+            (void)hipGetLastError();
+            cus = 256;
+        }
+        return (unsigned)cus;
+    }();
+    return n;
+}
+
 extern "C" void qmann_tuning_reload(void)
 {
     (void)qm_tuning();

@@ -59,6 +59,9 @@ def make_batch(env, cfg, B, S_list, seed, sigma_k=30.0, sigma_u=20.0, sigma_h=1.
     return wts, keys, vals, u0, n_slots, row_off
 
 
+EXCUSED = {"queries": 0, "cases": 0}     # running count of excused queries (tools/soak.py reports it; every test of this file demands 0)
+
+
 def both_paths(env, cfg, B, S_list, seed, max_slots=None, oracle=None, n_oracle=0, nonzero=True, max_excused=0, **kw):
     torch, model = env.torch, env.model
     wts, keys, vals, u0, n_slots, row_off = make_batch(env, cfg, B, S_list, seed, **kw)
@@ -106,6 +109,7 @@ def both_paths(env, cfg, B, S_list, seed, max_slots=None, oracle=None, n_oracle=
                     near |= bool(((np.abs(x - k) <= 1e-5 * np.maximum(1.0, np.abs(x))) & (k > 0)).any())
                 assert near, f"query {q} ({n_slots[q]} slots) differs from the oracle with no softmax weight on a truncation step"
                 excused += 1
+        EXCUSED["queries"] += excused; EXCUSED["cases"] += 1 if excused else 0
         assert excused <= max_excused, f"{excused} queries needed the p-on-a-step excuse"
     return net
 
