@@ -770,7 +770,9 @@ def main(argv=None):
             cfgs = {}
             for key, wname, sus in SECONDARY:
                 torch.cuda.empty_cache()
-                a2 = argparse.Namespace(**{**vars(args), "queries": 0, "no_sustained": args.no_sustained or not sus, "sustain_s": 1.0})
+                # (--queries, when given, caps every workload of the line: small rehearsals of the whole line)
+                a2 = argparse.Namespace(**{**vars(args), "queries": min(args.queries, WORKLOADS[wname]["B"]) if args.queries else 0,
+                                           "no_sustained": args.no_sustained or not sus, "sustain_s": 1.0})
                 sec = run_workload(a2, wname, dev, rank, world)
                 if rank == 0:
                     cfgs[key] = compact(sec)
@@ -871,7 +873,8 @@ def run_workload(args, name, dev, rank, world):
     H = 3
     iwl = int(wl.get("iwl", 5))
     frac = 7 - iwl
-    cfg = model.babi_cfg(V, attention_mode=mode, softmax_base=0, iwl=iwl, n_hop=H, D=D, en_mq=bool(wl.get("bow") or wl.get("mq")))
+    sm_base = int(os.environ.get("QMANN_BENCH_SOFTMAX_BASE", "0"))          # (experiments: 1 = 2^x, 2 = exp_plan -- the CPU softmax's bases)
+    cfg = model.babi_cfg(V, attention_mode=mode, softmax_base=sm_base, iwl=iwl, n_hop=H, D=D, en_mq=bool(wl.get("bow") or wl.get("mq")))
     cfg["num_bit"] = nb
     if os.environ.get("QMANN_BENCH_NO_LINMAP"):            # experiment: what the in-kernel linear map costs
         cfg["en_lin_map"] = False

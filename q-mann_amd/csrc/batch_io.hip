@@ -1008,7 +1008,9 @@ constexpr uint32_t kEmRows = 16;                        // story rows per tile
 constexpr uint32_t kEmDupCap = 128;                     // repeated (row, word) pairs a tile can hold: 16 rows x 16 slots / 2
 
 // wavefronts per SIMD each instantiation is compiled for (its register budget; the launcher sizes the persistent grid by it)
-constexpr int em_waves_per_simd(int KS) { return KS == 1 ? 5 : 4; }
+// (KS = 1, task-1 dictionaries: 80 registers buy a third 8-wavefront workgroup per CU -- the kernel is latency-bound: +4.5 % on the task-1 forward
+// in an interleaved A/B against five per SIMD; the 16-wavefront forms are held to one workgroup per CU by their LDS tiles)
+constexpr int em_waves_per_simd(int KS) { return KS == 1 ? 6 : 4; }
 
 template <int KS, int NW>                               // K / 64: 1, 2 or 4; wavefronts per workgroup (they share T^T)
 __global__ void __launch_bounds__(NW * kWave, em_waves_per_simd(KS))

@@ -360,3 +360,16 @@ def test_bench_two_ranks_rehearsal_equals_the_single_rank_runs(workload, queries
         assert two["ranks"]["queries_per_s"]["min"] > 0
     # weak scaling: the whole-job figure counts both ranks' queries
     assert abs(two["value"] - 2 * B * 3 / (two["ms_per_step"] * 3e-3)) / two["value"] < 1e-6
+
+
+def test_bench_default_line_with_two_ranks_rehearsal():
+    """the WHOLE default line (headline + every BASELINE config under `configs`) with two ranks on this box's one GPU
+    (QMANN_BENCH_REHEARSE=1, small batches): every workload builds its model on rank 0, broadcasts the quantised blob and runs on
+    both ranks; the line keeps its shape -- what the driver's N > 1 runs will print"""
+    two = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--queries", "2048", "--no-sustained"], QMANN_BENCH_REHEARSE="1")
+    assert two["n_gpus"] == 2 and two["config"]["workload"] == "synth10k_d128"
+    assert sorted(two["configs"]) == ["cfg2", "cfg3", "cfg4", "cfg5", "mem50"]
+    for k, c in two["configs"].items():
+        assert c["value"] > 0 and c["roofline"]["frac"] > 0, k
+    assert two["mem50_queries_per_s"] == two["configs"]["mem50"]["value"]
+    assert two["param_broadcast"]["bytes"] > 0 and len(two["shards"]) == 2

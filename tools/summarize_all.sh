@@ -3,8 +3,9 @@
 # Remove gpurun_out/prof before collecting anew: summarize_profiles.py takes the first file it finds per pass.
 set -e
 cd "$(dirname "$0")/.."
-T=${1:-r03}
+T=${1:-r04}
 python tools/summarize_profiles.py ${T} synth10k_d128 31457280000
+python tools/summarize_profiles.py ${T}_q25 synth10k_d128_q25 31457280000
 python tools/summarize_profiles.py ${T}_ham synth10k_d256_ham 7864320000
 python tools/summarize_profiles.py ${T}_v4096 synth10k_d256_ham_v4096 7864320000
 python tools/summarize_profiles.py ${T}_appx synth10k_d128_appx 31457280000
