@@ -44,6 +44,11 @@ if ms:
     out.append(f"mean resident waves per SIMD = 4 x SQ_WAVE_CYCLES / SIMD-cycles = {4 * wc / simd_cycles:.2f}")
     out.append(f"VALU issue occupancy  = 4 x SQ_ACTIVE_INST_VALU / SIMD-cycles = {4 * g('SQ_ACTIVE_INST_VALU') / simd_cycles:.3f}   (1.0 = the SIMD's vector issue port never idle)")
     out.append(f"VALU instructions x 4 cycles / SIMD-cycles                  = {4 * g('SQ_INSTS_VALU') / simd_cycles:.3f}")
+    if g("SQ_WAVES") <= 4 * 1024 * 2:           # a persistent grid: its waves live (nearly) as long as the kernel, so their mean lifetime is a second clock
+        life = 4 * wc / g("SQ_WAVES")
+        out.append(f"  cross-check without GRBM_GUI_ACTIVE (it reads high on sub-millisecond dispatches): a wave lives {life:.3e} cycles on average = "
+                   f"{life / (clk * ms * 1e-3):.2f} of the kernel's cycles as counted above; with the wave lifetime as the kernel's length the VALU issue "
+                   f"occupancy is SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES x waves per SIMD = {g('SQ_ACTIVE_INST_VALU') / wc * g('SQ_WAVES') / 1024:.3f}")
     out.append(f"LDS issue occupancy   = 4 x SQ_ACTIVE_INST_LDS / SIMD-cycles  = {4 * g('SQ_ACTIVE_INST_LDS') / simd_cycles:.3f}")
     out.append(f"VMEM issue occupancy  = 4 x SQ_ACTIVE_INST_VMEM / SIMD-cycles = {4 * g('SQ_ACTIVE_INST_VMEM') / simd_cycles:.3f}")
     out.append(f"scalar issue occupancy= 4 x SQ_ACTIVE_INST_SCA / SIMD-cycles  = {4 * g('SQ_ACTIVE_INST_SCA') / simd_cycles:.3f}")
