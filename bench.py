@@ -192,9 +192,11 @@ def compact(res, primary=False):
     if "sustained" in res:
         su = res["sustained"]
         out["sustained"] = {k: su[k] for k in ("steps", "seconds", "queries_per_s", "kernel_ms", "frac") if k in su}
-    for k in ("param_broadcast_ms", "param_broadcast", "ranks", "shards", "pred_crc32", "accuracy"):
-        if k in res and (primary or k in ("accuracy",)):
+    for k in ("param_broadcast_ms", "param_broadcast", "ranks", "shards", "pred_crc32", "accuracy", "small_batch"):
+        if k in res and (primary or k in ("accuracy", "small_batch")):
             out[k] = res[k]
+    if "small_batch" in out:
+        out["small_batch"] = {k: v for k, v in out["small_batch"].items() if k != "note"}
     if "accuracy" in out:
         out["accuracy"] = {k: out["accuracy"][k] for k in ("test_error_from_labels", "reference_program_err_test", "equals_reference_program")
                            if k in out["accuracy"]}
@@ -483,6 +485,36 @@ def run_bow(args, name, wl, net, cfg, wts, hm, dev, rank, world, model):
             dt = time.perf_counter() - t1
             res["host_inputs"]["overlapped_queries_per_s"] = B * args.steps / dt
             res["host_inputs"]["overlapped_pred_equal"] = bool(torch.equal(o2[0], out["pred"]))
+            # SERVING-sized batches: 64 stories per call.  The forward is 6 kernel launches + 3 memsets and never synchronises or
+            # allocates once its workspace has its size, so a host can capture it in a HIP graph and replay it per batch
+            # (tests/test_gpu_graph.py): per-batch latency, launches one by one against one graph launch
+            nb = 64
+            rows_s = int(row_off[nb].item())
+            s_sw, s_qw, s_ro, s_an = sw[:rows_s].clone(), qw[:nb].clone(), row_off[:nb + 1].clone(), ans[:nb].clone()
+            with torch.cuda.stream(ks):
+                hm2.forward_words(s_sw, s_qw, s_ro, max_slots, s_an)          # (workspace is large enough already: no reallocation)
+            ks.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=ks):
+                gp = hm2.forward_words(s_sw, s_qw, s_ro, max_slots, s_an)
+            n_it = 300
+
+            def timed(fn):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(n_it):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t1) / n_it * 1e6
+
+            def direct():
+                with torch.cuda.stream(ks):
+                    hm2.forward_words(s_sw, s_qw, s_ro, max_slots, s_an)
+            timed(direct); timed(g.replay)
+            us_d, us_g = timed(direct), timed(g.replay)
+            res["small_batch"] = {"queries": nb, "us_per_batch_direct": us_d, "us_per_batch_graph": us_g,
+                                  "pred_equal": bool(torch.equal(gp[0], out["pred"][:nb])),
+                                  "note": "back-to-back batches of 64 stories, host clock; graph = one hipGraphLaunch per batch"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         st, qu = g["story"].astype(np.float32), g["question"].astype(np.float32)
         offs = np.concatenate([[0], np.cumsum(n_sen)]).astype(np.int64)
