@@ -537,8 +537,9 @@ inline void launch_lean_w(HopArgs a, uint32_t max_slots, uint32_t n_query, hipSt
     // Persistent workgroups: exactly as many as are resident AT ONCE.  The kernel is compiled for four wavefronts per SIMD
     // (__launch_bounds__: <= 128 registers), i.e. 16 per CU = two of these 8-wavefront workgroups, whatever LDS would allow.
     // Through round 3 the grid was sized by LDS alone (three per CU at bAbI sizes): a third of the workgroups waited for a
-    // slot and then ran alone on half-empty CUs -- mean residency 3.0 wavefronts per SIMD instead of 4
-    // (profiles/r04_units_m50.txt) and a kernel 8 % longer than its work.
+    // slot and then ran alone on half-empty CUs.  For THIS kernel that cost nothing measurable (it is bound by vector issue:
+    // the late workgroups, alone on their CUs, run twice as fast) -- for the latency-bound embedding kernel the same mistake
+    // doubled the run time (rt.h::qm_resident_groups).
     const uint32_t need = (n_query + kLeanWaves - 1) / kLeanWaves;
     const uint32_t resident = qm_resident_groups(kLeanWaves, 4, lds);
     k_hops_lean<MODE, NB, W7, SPARSE><<<need < resident ? need : resident, kLeanBlock, lds, st>>>(a, la);

@@ -56,7 +56,6 @@ static inline void qm_alloc(T **p, size_t n)
 struct QmTuning {
     bool no_w7, no_mid, no_lean, no_tied, embed_general_epilogue, embed_valu, answer_two_pass;
     int lean_sparse;                                  // -1 = the launcher chooses, 0 / 1 forced
-    int lean_pair;                                    // -1 = default
 };
 const QmTuning &qm_tuning();                          // (tuning.hip)
 

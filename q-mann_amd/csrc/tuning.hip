@@ -18,7 +18,6 @@ void read_env(QmTuning &t)
     t.embed_valu = on("QMANN_EMBED_VALU");
     t.answer_two_pass = on("QMANN_ANSWER_TWO_PASS");
     t.lean_sparse = tri("QMANN_LEAN_SPARSE");
-    t.lean_pair = tri("QMANN_LEAN_PAIR");
 }
 
 }  // namespace
