@@ -24,6 +24,12 @@ namespace {
 
 constexpr int kLeanWaves = 8;                       // wavefronts (= queries in flight) per workgroup
 constexpr int kLeanBlock = kLeanWaves * kWave;
+// Wavefronts per SIMD a lean kernel is compiled for (its register budget: 128 at four, 80 at six) and its persistent grid is sized
+// by.  With the buffer loads the fixed-point kernel needs 80-83 registers, so a THIRD 8-wavefront workgroup per CU fits wherever
+// LDS has room for it (up to ~16 value-tile rows: bAbI task 1, the sparse variant at any length): 0.705 -> 0.652-0.665 ms at
+// |mem| = 50 and +7.5 % on the task-1 forward (interleaved A/B).  Where LDS holds two workgroups anyway (the joint set's 64-row
+// tiles) the tighter budget only costs (-2.3 % on the mode-3 joint forward): those launches take the four-wave build.
+constexpr int kLeanWpsWide = 4, kLeanWpsTight = 6;
 
 // per-workgroup LDS: exp tables [n_hop][256] float, linear maps [n_hop][64][64] sign-magnitude bytes
 // per-wavefront LDS slice: value tile [rows_pad][64], then the small arrays below
@@ -422,13 +428,14 @@ __device__ __forceinline__ void lean_hop(const HopArgs &a, const LeanArgs &la, u
     lean_finish_hop<W7>(a, h, lane, lw, lmap, u, [&]() { return acc; }, kb_code, csc, csh, reuse);
 }
 
-template <int MODE, int NB, bool W7, bool SPARSE>
-__global__ void __launch_bounds__(kLeanBlock, 4)          // four wavefronts per SIMD (two workgroups per CU): at most 128 registers
+template <int MODE, int NB, bool W7, bool SPARSE, int WPS>
+__global__ void __launch_bounds__(kLeanBlock, WPS)
 k_hops_lean(const HopArgs a, const LeanArgs la)
 {
     constexpr uint32_t Dp = 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1);
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid / kWave));   // uniform: the query's row range lives in SGPRs, which a buffer resource needs
     const uint32_t sub = lane >> 2, chunk = lane & 3u;
     const uint32_t D = a.D, H = a.n_hop;
     float *etab = (float *)smem;                                        // [H][256]
@@ -455,23 +462,30 @@ k_hops_lean(const HopArgs a, const LeanArgs la)
     i32x4 kq[4];
     int kt = 0;                                                         // the narrow tail pass's dword (lean_hop)
     float u_next;
-    // keys of hop h of the query whose rows start at `base` (S_ rows)
+    // Keys of hop h of the query whose rows start at `base` (S_ rows): BUFFER loads bounded by the story's own bytes (a raw
+    // buffer resource per story and hop: base, size).  A row past the story's end reads as zeros without touching memory, so
+    // the loads carry no lane predicate, no saved exec mask and no zero-initialised destination -- round 3's predicated global
+    // loads kept five 64-bit lane masks per hop in scalar registers the kernel does not have (spilled to vector lanes and read
+    // back, two vector-issue slots each) and cleared 17 registers per hop.  1 368 -> 1 214 vector instructions in the kernel,
+    // 125 -> 83 registers, -5 % run time at |mem| = 50.  Two things this needs: (1) the resource must be wavefront-UNIFORM in
+    // the compiler's eyes (hence the readfirstlane on the wavefront index above) -- otherwise every load becomes a
+    // readfirstlane "waterfall" loop with a vmcnt(0) in front, which is what made the first attempt of the round 2.5 % slower
+    // than the global loads; (2) a scheduling barrier behind the requests, so that they stay where they are issued (a hop ahead)
+    // instead of sinking towards their first use.
+    const uint32_t lane_off = sub * Dp + chunk * 16u;
     auto load_keys_of = [&](uint32_t h, uint32_t base, uint32_t S_) {
         const uint8_t *k0 = (const uint8_t *)a.keys + (size_t)h * a.key_hop_stride + (size_t)base * Dp;
-        const uint8_t *kb = k0 + chunk * 16;
         const bool tail = lean_tail_rows<MODE, W7>(S_);
         const uint32_t S_reg = tail ? (S_ & ~15u) : S_;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)k0, 0, (int)(S_reg * Dp), kRawBufferFlags);
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint32_t r = j * 16 + sub;
-            kq[j] = i32x4{0, 0, 0, 0};
-            if (r < S_reg) kq[j] = __builtin_nontemporal_load((const i32x4 *)(kb + (size_t)r * Dp));   // (streamed once: keep it out of the caches' way)
-        }
+        for (int j = 0; j < 4; j++)
+            kq[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(lane_off + (uint32_t)j * 16u * Dp), 0, kBufferNt);
         if (MODE == kModeFixed && W7) {
-            const uint32_t rt = S_reg + (lane >> 4);
-            kt = 0;
-            if (tail && rt < S_) kt = __builtin_nontemporal_load((const int *)(k0 + (size_t)rt * Dp + (lane & 15u) * 4));
+            const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void *)k0, 0, (int)(tail ? S_ * Dp : 0u), kRawBufferFlags);
+            kt = __builtin_amdgcn_raw_buffer_load_b32(rt, (int)(S_reg * Dp + lane * 4u), 0, kBufferNt);
         }
+        __builtin_amdgcn_sched_barrier(0);
     };
     load_keys_of(0, r0, S);
     u_next = (lane < D) ? a.u0[q * D + lane] : 0.0f;
@@ -487,15 +501,17 @@ k_hops_lean(const HopArgs a, const LeanArgs la)
         for (uint32_t h = 0; h < H; h++) {
             // this hop's value rows: global memory -> this wavefront's LDS tile, 1 KiB (16 rows) per instruction
             const uint8_t *vg = (const uint8_t *)a.vals + (size_t)h * a.hop_stride + (size_t)r0 * Dp;
-            const uint8_t *vb = vg + chunk * 16;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t r = j * 16 + sub;
-                if (!SPARSE && j * 16 < (int)S) {                         // wavefront-uniform (SPARSE: no tile, see lean_hop)
-                    if (r < S)
-                        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(vb + (size_t)r * Dp),
-                                                         (void __attribute__((address_space(3))) *)(vt + j * 1024), 16, 0, 0);   // (the nt policy on this DMA measured no different)
-                }
+            if (!SPARSE) {                                                // (SPARSE: no tile, see lean_hop)
+                // this hop's value rows: global memory -> this wavefront's LDS tile, 1 KiB (16 rows) per instruction, through a
+                // buffer resource as the keys (rows past the story's end arrive as zeros).  The instruction's immediate offset
+                // would move the LDS address as well as the global one: the piece's 1 KiB goes into the lane offset.
+                const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)vg, 0, (int)(S * Dp), kRawBufferFlags);
+#define QM_TILE_PIECE(J)                                                                                                   \
+                if ((J) * 16 < (int)S)                                    /* wavefront-uniform */                          \
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (void __attribute__((address_space(3))) *)(vt + (J) * 1024), 16, \
+                                                             (int)(lane_off + (J) * 1024u), 0, 0, 0)
+                QM_TILE_PIECE(0); QM_TILE_PIECE(1); QM_TILE_PIECE(2); QM_TILE_PIECE(3);
+#undef QM_TILE_PIECE
             }
             lean_hop<MODE, NB, W7, SPARSE>(a, la, h, S, lane, vt, lw, lmap, etab, u, [&](int j) { return kq[j]; }, [&]() {
                 if (!SPARSE) {
@@ -503,11 +519,10 @@ k_hops_lean(const HopArgs a, const LeanArgs la)
                     wave_sync();
                 }
                 // in flight during the read-out and the linear map: the next hop's keys, or the next query's first keys
-                if (h + 1 < H) load_keys_of(h + 1, r0, S);
-                else if (qn < n_query) {
-                    load_keys_of(0, r0n, Sn);
-                    u_next = (lane < D) ? a.u0[qn * D + lane] : 0.0f;
-                }
+                // (unconditionally: with nothing to come the resource is empty -- r0n = Sn = 0 -- and the loads bring zeros for free)
+                const bool more = h + 1 < H;
+                load_keys_of(more ? h + 1 : 0u, more ? r0 : r0n, more ? S : Sn);
+                if (!more && qn < n_query) u_next = (lane < D) ? a.u0[(size_t)qn * D + lane] : 0.0f;
             }, vg, kt);
         }
         if (lane < D) a.u_out[q * D + lane] = relu_if(u, a.en_non_lin != 0);
@@ -532,17 +547,21 @@ inline void launch_lean_w(HopArgs a, uint32_t max_slots, uint32_t n_query, hipSt
     a.rows_total = n_query;                                               // (the kernel has no taps: the field carries the query count)
     const size_t lds = (la.exp_table ? a.n_hop * 1024u : 0u) + (la.lm_in_lds ? a.n_hop * kLmHopBytes : 0u) +
                        (size_t)kLeanWaves * (la.rows_pad * 64u + kLwBytes);
-    if (lds > kLdsDefaultLimit)
-        QM_HIP(hipFuncSetAttribute((const void *)k_hops_lean<MODE, NB, W7, SPARSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    // Persistent workgroups: exactly as many as are resident AT ONCE.  The kernel is compiled for four wavefronts per SIMD
-    // (__launch_bounds__: <= 128 registers), i.e. 16 per CU = two of these 8-wavefront workgroups, whatever LDS would allow.
-    // Through round 3 the grid was sized by LDS alone (three per CU at bAbI sizes): a third of the workgroups waited for a
-    // slot and then ran alone on half-empty CUs.  For THIS kernel that cost nothing measurable (it is bound by vector issue:
-    // the late workgroups, alone on their CUs, run twice as fast) -- for the latency-bound embedding kernel the same mistake
-    // doubled the run time (rt.h::qm_resident_groups).
+    // Persistent workgroups: exactly as many as are resident AT ONCE (rt.h::qm_resident_groups: registers by the build's
+    // __launch_bounds__, LDS, the 32-wavefront limit).  Through round 3 the grid was sized by LDS alone (three per CU at bAbI sizes
+    // where registers allowed two): the late third ran alone on half-empty CUs.  For THIS kernel that cost nothing measurable (it is
+    // bound by vector issue: the late workgroups run twice as fast) -- for the latency-bound embedding kernel the same mistake
+    // doubled the run time.
     const uint32_t need = (n_query + kLeanWaves - 1) / kLeanWaves;
-    const uint32_t resident = qm_resident_groups(kLeanWaves, 4, lds);
-    k_hops_lean<MODE, NB, W7, SPARSE><<<need < resident ? need : resident, kLeanBlock, lds, st>>>(a, la);
+    auto go = [&](auto kernel, int wps) {
+        if (lds > kLdsDefaultLimit) QM_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const uint32_t resident = qm_resident_groups(kLeanWaves, (unsigned)wps, lds);
+        kernel<<<need < resident ? need : resident, kLeanBlock, lds, st>>>(a, la);
+    };
+    // the six-wave build where it buys a third workgroup per CU (fixed-point attention only: the Hamming forms need more registers)
+    const bool tight = MODE == kModeFixed && qm_resident_groups(kLeanWaves, kLeanWpsTight, lds) > qm_resident_groups(kLeanWaves, kLeanWpsWide, lds);
+    if (MODE == kModeFixed && tight) go(k_hops_lean<MODE, NB, W7, SPARSE, (MODE == kModeFixed ? kLeanWpsTight : kLeanWpsWide)>, kLeanWpsTight);
+    else go(k_hops_lean<MODE, NB, W7, SPARSE, kLeanWpsWide>, kLeanWpsWide);
 }
 
 template <int MODE, int NB>
