@@ -27,8 +27,9 @@ constexpr int kLeanBlock = kLeanWaves * kWave;
 // Wavefronts per SIMD a lean kernel is compiled for (its register budget: 128 at four, 80 at six) and its persistent grid is sized
 // by.  With the buffer loads the fixed-point kernel needs 80-83 registers, so a THIRD 8-wavefront workgroup per CU fits wherever
 // LDS has room for it (up to ~16 value-tile rows: bAbI task 1, the sparse variant at any length): 0.705 -> 0.652-0.665 ms at
-// |mem| = 50 and +7.5 % on the task-1 forward (interleaved A/B).  Where LDS holds two workgroups anyway (the joint set's 64-row
-// tiles) the tighter budget only costs (-2.3 % on the mode-3 joint forward): those launches take the four-wave build.
+// |mem| = 50 and +7.5 % on the task-1 forward (interleaved A/B); the Hamming forms gain 7-8 % the same way.  Where LDS holds two
+// workgroups anyway (the joint set's 64-row tiles) the tighter budget only costs (-2.3 % on the mode-3 joint forward): those
+// launches take the four-wave build.
 constexpr int kLeanWpsWide = 4, kLeanWpsTight = 6;
 
 // per-workgroup LDS: exp tables [n_hop][256] float, linear maps [n_hop][64][64] sign-magnitude bytes
@@ -558,9 +559,11 @@ inline void launch_lean_w(HopArgs a, uint32_t max_slots, uint32_t n_query, hipSt
         const uint32_t resident = qm_resident_groups(kLeanWaves, (unsigned)wps, lds);
         kernel<<<need < resident ? need : resident, kLeanBlock, lds, st>>>(a, la);
     };
-    // the six-wave build where it buys a third workgroup per CU (fixed-point attention only: the Hamming forms need more registers)
-    const bool tight = MODE == kModeFixed && qm_resident_groups(kLeanWaves, kLeanWpsTight, lds) > qm_resident_groups(kLeanWaves, kLeanWpsWide, lds);
-    if (MODE == kModeFixed && tight) go(k_hops_lean<MODE, NB, W7, SPARSE, (MODE == kModeFixed ? kLeanWpsTight : kLeanWpsWide)>, kLeanWpsTight);
+    // the six-wave build where it buys a third workgroup per CU (every attention mode: the Hamming forms need 81-91 registers in
+    // the four-wave build and all but the EN_MQ mode-3 form fit 80 without a spill; 50-slot synthetic memories in an interleaved
+    // A/B: mode 3 0.91 -> 0.84 ms, weighted Hamming 0.70 -> 0.65 ms)
+    const bool tight = qm_resident_groups(kLeanWaves, kLeanWpsTight, lds) > qm_resident_groups(kLeanWaves, kLeanWpsWide, lds);
+    if (tight) go(k_hops_lean<MODE, NB, W7, SPARSE, kLeanWpsTight>, kLeanWpsTight);
     else go(k_hops_lean<MODE, NB, W7, SPARSE, kLeanWpsWide>, kLeanWpsWide);
 }
 
