@@ -158,7 +158,8 @@ k_answer_small(const float *__restrict__ w_ans, const float *__restrict__ u, con
     constexpr uint32_t QPW = (kWave / LPQ) * QB;        // queries per wavefront: QB per lane group, sharing each weight read
     typedef float fq __attribute__((ext_vector_type(QB)));
     float *wt = (float *)smem;                          // [D][VP]: W transposed
-    float *us = wt + (size_t)D * VP + (threadIdx.x / kWave) * QPW * D;   // [kAnsWaves][D][QPW]: this wavefront's queries, interleaved
+    const uint32_t wave_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));      // uniform: query bookkeeping in SGPRs (no spill at 64 registers)
+    float *us = wt + (size_t)D * VP + wave_u * QPW * D;   // [kAnsWaves][D][QPW]: this wavefront's queries, interleaved
     const uint32_t lane = threadIdx.x & (kWave - 1), grp = lane / LPQ, sub = lane % LPQ;
     const size_t stride = (size_t)gridDim.x * kAnsWaves * QPW;
     for (uint32_t i = threadIdx.x; i < D * VP; i += kAnsBlock) {
@@ -175,7 +176,7 @@ k_answer_small(const float *__restrict__ w_ans, const float *__restrict__ u, con
     // single word would serialise the whole batch (~12 ns each)
     float cost_acc = 0.0f;
     uint32_t match_acc = 0;
-    for (size_t qb = ((size_t)blockIdx.x * kAnsWaves + threadIdx.x / kWave) * QPW; qb < n_query; qb += stride) {
+    for (size_t qb = ((size_t)blockIdx.x * kAnsWaves + wave_u) * QPW; qb < n_query; qb += stride) {
         const uint32_t nq = n_query - qb < QPW ? (uint32_t)(n_query - qb) : QPW;
         for (uint32_t i = lane; i < nq * D; i += kWave) us[(i % D) * QPW + i / D] = u[qb * D + i];   // consecutive queries: one contiguous block
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1020,7 +1021,8 @@ k_embed_story_mfma(const EmbedIdxArgs a)
     constexpr uint32_t K = 64u * KS;
     constexpr uint32_t KP = K + 16u;                    // row pitch of T^T and X in LDS: 16 rows 4 banks apart, no conflicts on the fragment loads
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    // (readfirstlane: the compiler treats threadIdx.x / 64 as divergent and would keep every per-wavefront address in vector registers)
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid / kWave));
     constexpr uint32_t Dp = 64;                         // bAbI width (wider embeddings take the gather-sum kernel): the product loops
                                                         // unroll, so a tile's fragment loads and MFMAs are in flight together
     const uint32_t h = blockIdx.y, V = a.V, nw = a.max_words;
