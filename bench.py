@@ -488,33 +488,34 @@ def run_bow(args, name, wl, net, cfg, wts, hm, dev, rank, world, model):
             # SERVING-sized batches: 64 stories per call.  The forward is 6 kernel launches + 3 memsets and never synchronises or
             # allocates once its workspace has its size, so a host can capture it in a HIP graph and replay it per batch
             # (tests/test_gpu_graph.py): per-batch latency, launches one by one against one graph launch
-            nb = 64
-            rows_s = int(row_off[nb].item())
-            s_sw, s_qw, s_ro, s_an = sw[:rows_s].clone(), qw[:nb].clone(), row_off[:nb + 1].clone(), ans[:nb].clone()
-            with torch.cuda.stream(ks):
-                hm2.forward_words(s_sw, s_qw, s_ro, max_slots, s_an)          # (workspace is large enough already: no reallocation)
-            ks.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=ks):
-                gp = hm2.forward_words(s_sw, s_qw, s_ro, max_slots, s_an)
-            n_it = 300
-
-            def timed(fn):
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(n_it):
-                    fn()
-                torch.cuda.synchronize()
-                return (time.perf_counter() - t1) / n_it * 1e6
-
-            def direct():
+            if not os.environ.get("QMANN_BENCH_NO_SMALL_BATCH"):       # (profile passes: keep the kernel averages those of the full batches)
+                nb = 64
+                rows_s = int(row_off[nb].item())
+                s_sw, s_qw, s_ro, s_an = sw[:rows_s].clone(), qw[:nb].clone(), row_off[:nb + 1].clone(), ans[:nb].clone()
                 with torch.cuda.stream(ks):
-                    hm2.forward_words(s_sw, s_qw, s_ro, max_slots, s_an)
-            timed(direct); timed(g.replay)
-            us_d, us_g = timed(direct), timed(g.replay)
-            res["small_batch"] = {"queries": nb, "us_per_batch_direct": us_d, "us_per_batch_graph": us_g,
-                                  "pred_equal": bool(torch.equal(gp[0], out["pred"][:nb])),
-                                  "note": "back-to-back batches of 64 stories, host clock; graph = one hipGraphLaunch per batch"}
+                    hm2.forward_words(s_sw, s_qw, s_ro, max_slots, s_an)          # (workspace is large enough already: no reallocation)
+                ks.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=ks):
+                    gp = hm2.forward_words(s_sw, s_qw, s_ro, max_slots, s_an)
+                n_it = 300
+
+                def timed(fn):
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(n_it):
+                        fn()
+                    torch.cuda.synchronize()
+                    return (time.perf_counter() - t1) / n_it * 1e6
+
+                def direct():
+                    with torch.cuda.stream(ks):
+                        hm2.forward_words(s_sw, s_qw, s_ro, max_slots, s_an)
+                timed(direct); timed(graph.replay)
+                us_d, us_g = timed(direct), timed(graph.replay)
+                res["small_batch"] = {"queries": nb, "us_per_batch_direct": us_d, "us_per_batch_graph": us_g,
+                                      "pred_equal": bool(torch.equal(gp[0], out["pred"][:nb])),
+                                      "note": "back-to-back batches of 64 stories, host clock; graph = one hipGraphLaunch per batch"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         st, qu = g["story"].astype(np.float32), g["question"].astype(np.float32)
         offs = np.concatenate([[0], np.cumsum(n_sen)]).astype(np.int64)

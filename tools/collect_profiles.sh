@@ -9,6 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 P=$R/gpurun_out/prof
 mkdir -p $P
 cd /tmp && export TMPDIR=/tmp
+export QMANN_BENCH_NO_SMALL_BATCH=1     # (the 64-story serving leg of babi_task1_idx would mix 1 200 tiny launches into the kernel averages)
 # only the small summaries travel back (gpurun merges at most 64 MiB): per-dispatch traces are dropped and
 # counter files are cut down to our kernels' rows
 prune() { find "$1" -type f ! -name '*kernel_stats.csv' ! -name '*counter_collection.csv' -delete; 
