@@ -584,6 +584,15 @@ inline void launch_lean(const HopArgs &a, uint32_t max_slots, uint32_t n_query, 
     for (uint32_t h = 0; h < a.n_hop; h++) surv = surv > (1u << a.act[h].frac) ? surv : (1u << a.act[h].frac);
     const uint32_t mean_slots = (a.rows_total && n_query) ? a.rows_total / n_query : max_slots / 8u;     // (tied hops: no plane size; real stories are short next to their cap)
     bool sparse = surv * 4u <= mean_slots;
+    // ... and wherever the value tiles would cost a workgroup per CU: 8 wavefronts x 64 rows x 64 bytes = 32 KB of tiles leave
+    // room for two workgroups, the sparse variant (no tile) for three at the six-wave register budget.  The real 20-task set
+    // (max 64 rows, mean 9.3): +4 % on the mode-3 forward, +5 % on the weighted-Hamming one (A/B, QMANN_LEAN_SPARSE=0 / 1);
+    // task 1 (max 10 rows: 8 KB of tiles, three workgroups either way) keeps the tile.
+    {
+        const size_t fixed_lds = (a.en_lin_map ? a.n_hop * kLmHopBytes : 0u) + (size_t)kLeanWaves * kLwBytes + a.n_hop * 1024u;
+        const size_t tile_lds = fixed_lds + (size_t)kLeanWaves * ((((max_slots ? max_slots : 1u) + 15u) & ~15u) * 64u);
+        if (qm_resident_groups(kLeanWaves, kLeanWpsTight, tile_lds) < qm_resident_groups(kLeanWaves, kLeanWpsTight, fixed_lds)) sparse = true;
+    }
     if (qm_tuning().lean_sparse >= 0) sparse = qm_tuning().lean_sparse == 1;
     if (w7) { if (sparse) launch_lean_w<MODE, NB, true, true>(a, max_slots, n_query, st); else launch_lean_w<MODE, NB, true, false>(a, max_slots, n_query, st); }
     else { if (sparse) launch_lean_w<MODE, NB, false, true>(a, max_slots, n_query, st); else launch_lean_w<MODE, NB, false, false>(a, max_slots, n_query, st); }
