@@ -228,7 +228,7 @@ int qmann_check_slots(const uint32_t *row_off, uint32_t n_query, uint32_t max_sl
 /* bytes of LDS one workgroup of qmann_hops_i8 needs for `max_slots` slots (for sizing checks) */
 size_t qmann_hops_lds_bytes(uint32_t max_slots);
 
-/* The library's A/B switches (environment variables QMANN_NO_LEAN, QMANN_NO_MID, QMANN_NO_W7, QMANN_NO_TIED,
+/* The library's A/B switches (environment variables QMANN_NO_LEAN, QMANN_NO_MID, QMANN_NO_W7, QMANN_NO_TIED, QMANN_NO_TIGHT,
  * QMANN_LEAN_SPARSE, QMANN_EMBED_VALU, QMANN_EMBED_GENERAL_EPILOGUE, QMANN_ANSWER_TWO_PASS: INTEGRATION.md) are read ONCE,
  * at the first call that needs one; no launch touches the environment afterwards.  A host that changes one later calls
  * this to have them read again -- from one thread, while no other thread is inside the library. */

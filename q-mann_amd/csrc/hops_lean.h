@@ -562,7 +562,8 @@ inline void launch_lean_w(HopArgs a, uint32_t max_slots, uint32_t n_query, hipSt
     // the six-wave build where it buys a third workgroup per CU (every attention mode: the Hamming forms need 81-91 registers in
     // the four-wave build and all but the EN_MQ mode-3 form fit 80 without a spill; 50-slot synthetic memories in an interleaved
     // A/B: mode 3 0.91 -> 0.84 ms, weighted Hamming 0.70 -> 0.65 ms)
-    const bool tight = qm_resident_groups(kLeanWaves, kLeanWpsTight, lds) > qm_resident_groups(kLeanWaves, kLeanWpsWide, lds);
+    const bool tight = !qm_tuning().no_tight &&
+                       qm_resident_groups(kLeanWaves, kLeanWpsTight, lds) > qm_resident_groups(kLeanWaves, kLeanWpsWide, lds);
     if (tight) go(k_hops_lean<MODE, NB, W7, SPARSE, kLeanWpsTight>, kLeanWpsTight);
     else go(k_hops_lean<MODE, NB, W7, SPARSE, kLeanWpsWide>, kLeanWpsWide);
 }
@@ -591,7 +592,8 @@ inline void launch_lean(const HopArgs &a, uint32_t max_slots, uint32_t n_query, 
     {
         const size_t fixed_lds = (a.en_lin_map ? a.n_hop * kLmHopBytes : 0u) + (size_t)kLeanWaves * kLwBytes + a.n_hop * 1024u;
         const size_t tile_lds = fixed_lds + (size_t)kLeanWaves * ((((max_slots ? max_slots : 1u) + 15u) & ~15u) * 64u);
-        if (qm_resident_groups(kLeanWaves, kLeanWpsTight, tile_lds) < qm_resident_groups(kLeanWaves, kLeanWpsTight, fixed_lds)) sparse = true;
+        if (!qm_tuning().no_tight && qm_resident_groups(kLeanWaves, kLeanWpsTight, tile_lds) < qm_resident_groups(kLeanWaves, kLeanWpsTight, fixed_lds))
+            sparse = true;
     }
     if (qm_tuning().lean_sparse >= 0) sparse = qm_tuning().lean_sparse == 1;
     if (w7) { if (sparse) launch_lean_w<MODE, NB, true, true>(a, max_slots, n_query, st); else launch_lean_w<MODE, NB, true, false>(a, max_slots, n_query, st); }

@@ -18,6 +18,7 @@ void read_env(QmTuning &t)
     t.embed_valu = on("QMANN_EMBED_VALU");
     t.answer_two_pass = on("QMANN_ANSWER_TWO_PASS");
     t.lean_sparse = tri("QMANN_LEAN_SPARSE");
+    t.no_tight = tri("QMANN_NO_TIGHT") == 1;
 }
 
 }  // namespace
