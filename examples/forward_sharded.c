@@ -84,6 +84,9 @@ static void *shard_main(void *p)
         if (ok) TRY(qmann_model_params(m, &sh->root_blob, &sh->blob_bytes), "qmann_model_params");
         if (ok && sh->use_rccl) TRY(qmann_comm_get_id(sh->comm_id), "qmann_comm_get_id");
     }
+    /* every rank that will join the communicator checks -- locally, without blocking -- that it CAN (librccl loads, the GPU exists);
+     * the verdicts are agreed on at barrier A, before anybody enters the blocking qmann_comm_init_rank (qmann_dist.h) */
+    if (ok && leader && sh->use_rccl > 0) TRY(qmann_comm_probe(dev), "qmann_comm_probe");
     sh->rc[s] = ok ? 0 : 1;
     pthread_barrier_wait(&sh->bar);                          /* A: root model and communicator id are there */
     for (uint32_t i = 0; i < sh->n_shards; i++) if (sh->rc[i]) ok = 0;   /* (nobody enters a rendezvous that cannot complete) */
