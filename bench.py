@@ -7,18 +7,20 @@ One "step" = one pass of the hot path (all hops of every query, then the answer 
 one resident batch of synthetic queries.  Prints ONE JSON line (rank 0).
 
 Workloads (config.workload; `--workload NAME` runs one alone):
-  synth10k_d128   BASELINE.json configs[3], one GPU's shard: |memory| = 10 000 slots, D = 128,
-                  int8 Q5.2 (run.sh default iwl = 5), 3 hops, fixed-point dot attention
-                  (ATTENTION_MODE 2), 8 192 queries per GPU, per-query memories (62.9 GB).  Default:
-                  this is the configuration the north-star roofline target is quoted on.
+  synth10k_d128_q25  BASELINE.json configs[3] EXACTLY as SURVEY.md 8(d) words it, one GPU's shard: |memory| = 10 000 slots,
+                  D = 128, int8 Q2.5, key / value / query codes clip(round(N(0, 6)), +-127), linear-map codes sigma 6, int8
+                  answer matrix [256][128] (the MFMA projection), 3 hops, fixed-point dot attention (ATTENTION_MODE 2),
+                  8 192 queries per GPU, per-query memories (62.9 GB).  Default: this is the configuration the north-star
+                  roofline target is quoted on.
 The DEFAULT line (no --workload) carries, beside that headline, one object per BASELINE.json config under `configs`
 (each: value, ms_per_step, roofline or "QPS only" as SURVEY.md 8(d) says, cpu_baseline) -- all under the driver's clock:
-  mem50  babi_mem50             |memory| = 50 (MAX_SEN_LEN cap), D = 60: the size BASELINE.json's metric string names
-                                (also promoted to top-level keys mem50_queries_per_s / mem50_roofline_frac)
-  cfg2   babi_task1_idx         configs[1]: bAbI task 1, 3 hops, int8, dot attention, whole forward from word indices
-  cfg3   babi_joint20_appx_mq   configs[2] as the stock define.h builds it: 20-task joint, ATTENTION_MODE 3, EN_MQ
-  cfg4   synth10k_d128_q25      configs[3] as SURVEY.md 8(d) specifies it: Q2.5, codes N(0, 6), int8 answer matrix
-  cfg5   synth10k_d256_ham      configs[4]: D = 256, binary-code Hamming attention + int8 MFMA output GEMM
+  mem50     babi_mem50             |memory| = 50 (MAX_SEN_LEN cap), D = 60: the size BASELINE.json's metric string names
+                                   (also promoted to top-level keys mem50_queries_per_s / mem50_roofline_frac)
+  cfg2      babi_task1_idx         configs[1]: bAbI task 1 (all 1 000 test stories, replicated), 3 hops, int8, dot attention,
+                                   whole forward from word indices
+  cfg3      babi_joint20_appx_mq   configs[2] as the stock define.h builds it: 20-task joint, ATTENTION_MODE 3, EN_MQ
+  cfg4_q52  synth10k_d128          configs[3] at run.sh's default format Q5.2 (codes sigma 3.5, float answer layer)
+  cfg5      synth10k_d256_ham      configs[4]: D = 256, binary-code Hamming attention + int8 MFMA output GEMM
 
 N > 1: one rank per GPU.  Either the caller starts the ranks (torch.distributed.run sets WORLD_SIZE /
 RANK / LOCAL_RANK) or, when `--gpus N` is given with no WORLD_SIZE in the environment, this script
@@ -102,8 +104,9 @@ WORKLOADS["babi_joint20_v1_tied"] = dict(S=64, D=60, V=238, B=262000, mode=11, n
 # program itself printed for these weights
 WORKLOADS["babi_task1_trained"] = dict(S=10, D=60, V=0, B=262000, mode=2, nb=8, ans="f32", trained=True)
 # the default line's secondary configs: (key under `configs`, workload, with the >= 1 s sustained window)
+HEADLINE = "synth10k_d128_q25"      # BASELINE.json configs[3] exactly as SURVEY.md 8(d) words it
 SECONDARY = [("mem50", "babi_mem50", True), ("cfg2", "babi_task1_idx", False), ("cfg3", "babi_joint20_appx_mq", False),
-             ("cfg4", "synth10k_d128_q25", False), ("cfg5", "synth10k_d256_ham", False)]
+             ("cfg4_q52", "synth10k_d128", False), ("cfg5", "synth10k_d256_ham", False)]
 KERNEL_OF_MODE = {1: "k_hops_float", 2: "k_hops_fixed", 3: "k_hops_ham", 10: "k_hops_ham", 11: "k_hops_ham"}
 
 
@@ -158,7 +161,7 @@ def compact(res, primary=False):
     digits, no prose beyond short labels.  `--workload NAME` alone prints the full record."""
     keep_cfg = ("workload", "slots", "dim_emb", "hops", "queries_per_gpu", "format", "attention_mode", "key_row_bytes",
                 "answer_layer", "dim_answer", "num_bit", "input", "parallelism")
-    keep_roof = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "bytes_per_query",
+    keep_roof = ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_padded_rows", "traffic", "algorithmic_bytes_per_launch", "bytes_per_query",
                  "kernel_ms", "frac_sustained", "frac_by_survey_formula")
     out = {k: res[k] for k in (("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                                 "vs_baseline", "dtype", "data") if primary else ("value", "unit", "ms_per_step", "data")) if k in res}
@@ -169,7 +172,7 @@ def compact(res, primary=False):
         if out.get("data") == "synthetic":
             out.pop("data")
         elif "data" in out:
-            out["data"] = out["data"][:60]
+            out["data"] = out["data"][:80]
     out["config"] = {k: v for k, v in res["config"].items() if k in keep_cfg}
     r = res["roofline"]
     out["roofline"] = {k: r[k] for k in keep_roof if k in r}
@@ -362,31 +365,31 @@ def cpu_baseline(cfg, wts, pool, what, gpu_preds=None):
 
 def run_bow(args, name, wl, net, cfg, wts, hm, dev, rank, world, model):
     """configs[1]: the full forward from bag-of-words stories (embedding + hops + answer)."""
-    g = np.load(ROOT / "tests" / "golden" / "babi_qa1_test64.npz")
+    use_idx = bool(wl.get("idx"))
+    # word indices: ALL 1 000 test stories of qa1 (SURVEY.md 8(d) config 2: "real qa1 test set (1 000 queries) + replication"),
+    # as the reference's sample.c vectorised them (tests/golden/babi_qa1_test1000_words.npz, oracle/gen_golden.py);
+    # float bag-of-words rows: the 64-story fixture of the same set
+    g = np.load(ROOT / "tests" / "golden" / ("babi_qa1_test1000_words.npz" if use_idx else "babi_qa1_test64.npz"))
     n_sen = g["n_sen"].astype(np.int64)
     B = args.queries or wl["B"]
     rep = (B + len(n_sen) - 1) // len(n_sen)
     B = rep * len(n_sen)
-    story = torch.from_numpy(np.tile(g["story"].astype(np.float32), (rep, 1))).to(dev)
-    ques = torch.from_numpy(np.tile(g["question"].astype(np.float32), (rep, 1))).to(dev)
-    ans = torch.from_numpy(np.tile(g["answer"].argmax(1).astype(np.int32), rep)).to(dev)
     ns_all = np.tile(n_sen, rep)
     row_off = torch.from_numpy(np.concatenate([[0], np.cumsum(ns_all)]).astype(np.int32)).to(dev)
     max_slots = int(n_sen.max())
-    use_idx = bool(wl.get("idx"))
     if use_idx:
-        dd = int(g["dim_dict"])
-
-        def to_words(bow, nd, width, with_time):
-            out = np.full((bow.shape[0], width), 0xFFFF, np.uint16)
-            for r, row in enumerate(bow):
-                ent = [k for k in np.flatnonzero(row[:nd]) for _ in range(int(row[k]))]
-                if with_time:
-                    ent.append(nd + int(np.flatnonzero(row[nd:])[0]))
-                out[r, :len(ent)] = ent
+        def words16(a8, width=8):
+            out = np.full((a8.shape[0], width), 0xFFFF, np.uint16)
+            out[:, :a8.shape[1]] = np.where(a8 == 0xFF, 0xFFFF, a8.astype(np.uint16))
             return out
-        sw = torch.from_numpy(np.tile(to_words(g["story"], dd, 8, True), (rep, 1)).view(np.int16)).to(dev)
-        qw = torch.from_numpy(np.tile(to_words(g["question"], cfg["dim_input"], 8, False), (rep, 1)).view(np.int16)).to(dev)
+        sw_np, qw_np = words16(g["story_words"]), words16(g["question_words"])
+        sw = torch.from_numpy(np.tile(sw_np, (rep, 1)).view(np.int16)).to(dev)
+        qw = torch.from_numpy(np.tile(qw_np, (rep, 1)).view(np.int16)).to(dev)
+        ans = torch.from_numpy(np.tile(g["answer"].astype(np.int32), rep)).to(dev)
+    else:
+        story = torch.from_numpy(np.tile(g["story"].astype(np.float32), (rep, 1))).to(dev)
+        ques = torch.from_numpy(np.tile(g["question"].astype(np.float32), (rep, 1))).to(dev)
+        ans = torch.from_numpy(np.tile(g["answer"].argmax(1).astype(np.int32), rep)).to(dev)
     torch.cuda.synchronize()                                     # hm: the library's own host object, one call per batch
 
     def step():
@@ -423,8 +426,10 @@ def run_bow(args, name, wl, net, cfg, wts, hm, dev, rank, world, model):
         "metric": "queries/sec", "value": world * B * args.steps / elapsed, "unit": "queries/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int8",
-        "data": "bAbI qa1 test stories (64-story fixture from the reference's sample.c, replicated), seeded random weights",
-        "config": {"workload": name, "slots": "2..10 (mean 5.9)", "dim_emb": 60, "dim_input": cfg["dim_input"],
+        "data": ("bAbI qa1 test set, all 1 000 stories (babi_qa1_test1000_words.npz, vectorised by the reference's sample.c), replicated; seeded random weights"
+                 if use_idx else "bAbI qa1 test stories (64-story fixture from the reference's sample.c, replicated), seeded random weights"),
+        "config": {"workload": name, "slots": f"{int(n_sen.min())}..{max_slots} (mean {n_sen.mean():.1f})", "stories": len(n_sen),
+                   "dim_emb": 60, "dim_input": cfg["dim_input"],
                    "hops": 3, "queries_per_gpu": B, "format": "Q5.2 + EN_MQ weight formats", "attention_mode": 2,
                    "stages": ("one qmann_model_forward_words call: story embedding (int8 MFMA) + question embedding + hops + answer layer" if use_idx
                               else "one qmann_model_forward_bow call: rows -> word lists on the device (irregular rows redone by the float kernels) + the same stages"),
@@ -517,11 +522,19 @@ def run_bow(args, name, wl, net, cfg, wts, hm, dev, rank, world, model):
                                       "pred_equal": bool(torch.equal(gp[0], out["pred"][:nb])),
                                       "note": "back-to-back batches of 64 stories, host clock; graph = one hipGraphLaunch per batch"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        st, qu = g["story"].astype(np.float32), g["question"].astype(np.float32)
         offs = np.concatenate([[0], np.cumsum(n_sen)]).astype(np.int64)
-        pool = [(st[offs[i]:offs[i + 1]], qu[i]) for i in range(len(n_sen))]
-        res["cpu_baseline"] = cpu_baseline(cfg, wts, pool, "the 64 fixture stories (bag-of-words rows), whole forward",
-                                           gpu_preds=out["pred"][:len(n_sen)].cpu().numpy().tolist())
+        if use_idx:
+            V, dd = cfg["dim_input"], int(g["dim_dict"])
+            pick = list(range(0, len(n_sen), 5))                          # 200 stories spread over the set
+            pool = [(words_to_bow(sw_np[offs[i]:offs[i + 1]], V, dd, True), words_to_bow(qw_np[i:i + 1], V, dd, False)[0]) for i in pick]
+            what = f"{len(pick)} of the 1 000 test stories (bag-of-words rows), whole forward"
+        else:
+            st, qu = g["story"].astype(np.float32), g["question"].astype(np.float32)
+            pick = list(range(len(n_sen)))
+            pool = [(st[offs[i]:offs[i + 1]], qu[i]) for i in pick]
+            what = "the 64 fixture stories (bag-of-words rows), whole forward"
+        gp = out["pred"][:len(n_sen)].cpu().numpy()
+        res["cpu_baseline"] = cpu_baseline(cfg, wts, pool, what, gpu_preds=[int(gp[i]) for i in pick])
     return res
 
 
@@ -693,7 +706,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
-                    help="one workload alone (default: synth10k_d128 as the headline + every BASELINE config under `configs`)")
+                    help="one workload alone (default: synth10k_d128_q25 as the headline + every BASELINE config under `configs`)")
     ap.add_argument("--secondary-cpu-s", type=float, default=1.2, help="CPU-baseline seconds per leg for the secondary configs")
     ap.add_argument("--queries", type=int, default=0, help="queries per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -792,7 +805,7 @@ def main(argv=None):
                 COMM.close()
                 COMM, comm_info = None, {"error": "another rank could not join the C-level communicator"}
         default_line = args.workload is None
-        name = args.workload or "synth10k_d128"
+        name = args.workload or HEADLINE
         out = run_workload(args, name, dev, rank, world)
         # BASELINE.json quotes its metric at |mem| = 50 (the bAbI cap) and sets its target at |mem| = 10 000: the default
         # line's `value` is the 10 000-slot configuration; beside it, under `configs`, one object per BASELINE.json config
@@ -819,7 +832,7 @@ def main(argv=None):
                 out = compact(out, primary=True)
                 out["configs"] = cfgs
                 m50 = cfgs["mem50"]
-                out["config"]["value_is"] = "cfg4 shard at Q5.2 (roofline target); BASELINE metric size |mem|=50: mem50_* keys"
+                out["config"]["value_is"] = "BASELINE configs[3] as SURVEY 8(d) specifies it (Q2.5, codes N(0,6)), one GPU's shard; BASELINE metric size |mem|=50: mem50_* keys"
                 if "value" in m50:
                     out["mem50_queries_per_s"] = m50["value"]
                     out["mem50_roofline_frac"] = m50["roofline"]["frac"]
@@ -1026,9 +1039,14 @@ def run_workload(args, name, dev, rank, world):
                      "queries_per_s": world * B * n_sus / sus_elapsed, "kernel_ms": float(per.mean()),
                      "kernel_ms_first_tenth": float(per[: max(1, n_sus // 10)].mean()),
                      "kernel_ms_last_tenth": float(per[-max(1, n_sus // 10):].mean())}
-    bytes_per_query = H * S * key_row_bytes                           # key planes: the addressing scan
+    # ALGORITHMIC bytes: H . |mem| . D key bytes -- the D columns the model has, not the Dp the rows are padded to
+    # (D = 60 in 64-byte rows at the bAbI width; at D = 128 / 256 the two are equal).  The padded figure is reported beside it.
+    key_row_bytes_alg = key_row_bytes if planes is not None else D
+    bytes_per_query = H * S * key_row_bytes_alg                       # key planes: the addressing scan
+    bytes_per_query_padded = H * S * key_row_bytes
     if mode == 1:
-        bytes_per_query += H * S * Dp                                 # float read-out streams every value row too
+        bytes_per_query += H * S * D                                  # float read-out streams every value row too
+        bytes_per_query_padded += H * S * Dp
     achieved = bytes_per_query * B / (hop_ms * 1e-3) / 1e9
     # HBM traffic from the PMC counters cannot be collected inside this process (rocprofv3 wraps the run): the figure
     # is the one recorded by tools/summarize_profiles.py from a separate `rocprofv3 --pmc FETCH_SIZE` pass of this same
@@ -1048,7 +1066,7 @@ def run_workload(args, name, dev, rank, world):
                                   f"this library is built from {SRC_SHA}")
     # SURVEY.md 8(d) prices a query at keys + values; the quantised read-out touches only the <= 2^frac surviving
     # value rows (bit-identical to summing all rows), so `achieved` counts the key bytes the scan must stream
-    survey_bytes = H * S * (key_row_bytes + Dp)
+    survey_bytes = H * S * (key_row_bytes_alg + D)
     survey_gbs = survey_bytes * B / (hop_ms * 1e-3) / 1e9
 
     lean = mode != 1 and S <= 64 and Dp == 64 and planes is None
@@ -1078,6 +1096,8 @@ def run_workload(args, name, dev, rank, world):
         "roofline": {"bound": "hbm", "kernel": "k_hops_lean" if lean else KERNEL_OF_MODE[mode], "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes_per_launch": bytes_per_query * B, "bytes_per_query": bytes_per_query,
+                     "bytes_per_query_padded_rows": bytes_per_query_padded,
+                     "frac_padded_rows": bytes_per_query_padded * B / (hop_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "bytes_counted": counted,
                      "bytes_per_query_survey_formula": survey_bytes,
                      "frac_by_survey_formula": survey_gbs / HBM_PEAK_GBS,

@@ -367,8 +367,9 @@ def test_bench_default_line_with_two_ranks_rehearsal():
     (QMANN_BENCH_REHEARSE=1, small batches): every workload builds its model on rank 0, broadcasts the quantised blob and runs on
     both ranks; the line keeps its shape -- what the driver's N > 1 runs will print"""
     two = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--queries", "2048", "--no-sustained"], QMANN_BENCH_REHEARSE="1")
-    assert two["n_gpus"] == 2 and two["config"]["workload"] == "synth10k_d128"
-    assert sorted(two["configs"]) == ["cfg2", "cfg3", "cfg4", "cfg5", "mem50"]
+    assert two["n_gpus"] == 2 and two["config"]["workload"] == "synth10k_d128_q25"   # config 4 as SURVEY 8(d) words it
+    assert sorted(two["configs"]) == ["cfg2", "cfg3", "cfg4_q52", "cfg5", "mem50"]
+    assert "1 000" in two["configs"]["cfg2"]["data"]                  # config 2 on the whole qa1 test set
     for k, c in two["configs"].items():
         assert c["value"] > 0 and c["roofline"]["frac"] > 0, k
     assert two["mem50_queries_per_s"] == two["configs"]["mem50"]["value"]
