@@ -299,11 +299,12 @@ unsigned int qmann_abi_symbol_count(void);
  * the last query is replayed verb by verb so that every layer's device buffer holds what the serial loop leaves there.
  * CONTRACT: device buffers written by forward verbs are up to date after the next non-forward cuda_* verb (as for the
  * reference host, which reads only through cuda_cross_entropy_*_load / cuda_copy_dev2host) or after qmann_abi_flush();
- * a host that reads them with its own hipMemcpy must call qmann_abi_flush() first, or switch the queue off.  The same call
- * covers WRITES behind the library's back: the batched model built for a run of queries is cached, keyed on the weight
- * pointers and formats (not on the values), and dropped by every cuda_* verb that can change a weight or an input pool;
- * a host that overwrites weights or pools with its own hipMemcpy between two forward phases must call qmann_abi_flush(),
- * which drains the record and forgets the cached model (the next run rebuilds it from the device matrices).
+ * a host that reads them with its own hipMemcpy must call qmann_abi_flush() first, or switch the queue off.  That call
+ * is a pure read barrier: it keeps the cached batched model.  WRITES behind the library's back have their own call: the
+ * batched model built for a run of queries is cached, keyed on the weight pointers and formats (not on the values), and
+ * dropped by every cuda_* verb that can change a weight or an input pool; a host that overwrites weights or pools with its
+ * own hipMemcpy between two forward phases must call qmann_abi_invalidate_model(), which drains the record and forgets the
+ * cached model (the next run rebuilds it from the device matrices).
  * A forward verb called with verbose = true is a synchronisation point too: the record is drained, the verb runs at once and
  * prints its operands as the reference does (lib/layer_cuda.cu:13-47, 2450-2484).
  * THREADS: the record is process-wide; the verbs serialise on one lock around it (recording, draining, these switches).
@@ -320,7 +321,8 @@ typedef struct qmann_defer_stats {
     double ms_batched, ms_replayed, ms_model;           /* wall time (device-synchronised only with QMANN_DEFER_STATS / verify) */
 } qmann_defer_stats;
 void qmann_abi_set_defer(int mode);
-void qmann_abi_flush(void);
+void qmann_abi_flush(void);               /* drain (read barrier); the cached model stays */
+void qmann_abi_invalidate_model(void);    /* drain + forget the cached model (weights / pools rewritten behind the library) */
 void qmann_abi_defer_stats(qmann_defer_stats *out);
 
 #ifdef __cplusplus

@@ -129,6 +129,7 @@ class DeferStats(C.Structure):
 
 _proto("qmann_abi_set_defer", None, [C.c_int])
 _proto("qmann_abi_flush", None, [])
+_proto("qmann_abi_invalidate_model", None, [])
 _proto("qmann_abi_defer_stats", None, [C.POINTER(DeferStats)])
 # The tests and bench.py drive single verbs and then look at the device buffers through torch, not through a cuda_* verb:
 # for this plumbing the forward verbs launch at once (the deferred queue is the default for C hosts; tests of the queue

@@ -63,7 +63,8 @@ void exit_report()
     if (registered) return;
     registered = true;
     atexit([] {
-        const qmann_defer_stats &s = g_stats;
+        std::lock_guard<std::recursive_mutex> hold(g_lock);      // (a verb may still be running on another thread)
+        const qmann_defer_stats s = g_stats;
         fflush(stdout);
         fprintf(stderr, "\n%s", g_verify_log.c_str());
         if (!getenv("QMANN_DEFER_STATS")) return;
@@ -503,9 +504,13 @@ void qmann_abi_set_defer(int mode)
     if (mode == 2) { qmdefer::g_timing = true; qmdefer::exit_report(); }
 }
 
+// a READ barrier: drains the record and keeps the cached batched model (a host that flushes between forward phases only to read
+// layer buffers does not pay a re-quantisation of its weights per flush)
+void qmann_abi_flush(void) { qmdefer::sync_point(false); }
+
 // drains AND forgets the cached batched model: the cache is keyed on the weight POINTERS and formats, so a host that changes
-// weight values or input pools behind the library's back (its own hipMemcpy) must come through here (qmann_abi.h: CONTRACT)
-void qmann_abi_flush(void) { qmdefer::sync_point(true); }
+// weight values or input pools behind the library's back (its own hipMemcpy) comes through here (qmann_abi.h: CONTRACT)
+void qmann_abi_invalidate_model(void) { qmdefer::sync_point(true); }
 
 void qmann_abi_defer_stats(qmann_defer_stats *out)
 {

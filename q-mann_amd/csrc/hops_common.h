@@ -370,7 +370,8 @@ __device__ __forceinline__ float sm_quot(float e, double total, const SmCfg &c)
 // slot order (`float tot`, :1161).  Where a memory fits a wavefront (slot r in lane r) that sum is reproduced as it is: S
 // dependent float additions.  (It matters at the truncation steps of Q(p): with one dominant slot and a runner-up 2^-24
 // below it the float total stays 1 and p = 1 exactly, a double total gives p = 1 - 2^-23 and Q(p) one code less.)  The
-// streaming kernels sum those bases in double: an order-free sum of 10 000 float terms cannot be the serial float one.
+// streaming kernels take the same serial float total for those bases through wave_serial_total_f32 / block_serial_total_f32
+// below (one wavefront walks the slots, one dependent addition per slot; its measured cost is in DESIGN.md section 5).
 __device__ __forceinline__ float wave_serial_sum_f32(float e, uint32_t S)
 {
     float tot = 0.0f;

@@ -122,11 +122,26 @@ float *upload(const float *host, size_t n, hipStream_t st)
     return d;
 }
 
+// Everything a net must satisfy to be created -- and therefore to be replicated: qmann_model_create_on() and the blob receivers
+// (qmann_params_validate, qmann_model_create_from_params) run this SAME check, so a net the root can build is never refused on
+// a receiver after the broadcast has run, and a bad one fails on the root before any collective.
 int check_net(const qmann_net *net)
 {
     if (net->n_hop == 0 || net->n_hop > QMANN_MAX_HOP || net->dim_emb == 0 || net->dim_emb > net->dim_emb_pad || net->dim_input == 0)
         return QMANN_EINVAL;
     if (net->dim_emb_pad != 64 && net->dim_emb_pad != 128 && net->dim_emb_pad != 256) return QMANN_EUNSUPPORTED;
+    const qmann_net &n = *net;
+    switch (n.attention_mode) {
+    case QMANN_ATT_FLOAT: case QMANN_ATT_FIXED: case QMANN_ATT_APPX: case QMANN_ATT_HAMMING_V0: case QMANN_ATT_HAMMING_V1: break;
+    default: return QMANN_EINVAL;
+    }
+    if (n.softmax_base > QMANN_SOFTMAX_EXP_PLAN || n.en_lin_map > 1u || n.num_bit > 8u || n.softmax_shift_based > 1u ||
+        n.en_att_scale > 1u || n.en_non_linearity > 1u || n.en_pe > 1u)
+        return QMANN_EINVAL;
+    auto fmt_ok = [](qmann_fmt f) { return f.iwl + f.frac <= 7u && f.iwl <= 7u; };
+    for (uint32_t h = 0; h < n.n_hop; h++)
+        if (!fmt_ok(n.act[h]) || !fmt_ok(n.w[h]) || !fmt_ok(n.att[h])) return QMANN_EINVAL;
+    if (!fmt_ok(n.bin)) return QMANN_EINVAL;
     return QMANN_OK;
 }
 
@@ -137,19 +152,8 @@ int check_header(const BlobHeader &hd, size_t bytes)
     const int rc = check_net(&hd.net);
     if (rc != QMANN_OK) return rc;
     const qmann_net &n = hd.net;
-    switch (n.attention_mode) {
-    case QMANN_ATT_FLOAT: case QMANN_ATT_FIXED: case QMANN_ATT_APPX: case QMANN_ATT_HAMMING_V0: case QMANN_ATT_HAMMING_V1: break;
-    default: return QMANN_EINVAL;
-    }
-    if (n.softmax_base > QMANN_SOFTMAX_EXP_PLAN || n.en_lin_map > 1u || n.num_bit > 8u || n.softmax_shift_based > 1u ||
-        n.en_att_scale > 1u || n.en_non_linearity > 1u || n.en_pe > 1u)
-        return QMANN_EINVAL;
-    auto fmt_ok = [](qmann_fmt f) { return f.iwl + f.frac <= 7u && f.iwl <= 7u; };
-    for (uint32_t h = 0; h < n.n_hop; h++) {
-        if (!fmt_ok(n.act[h]) || !fmt_ok(n.w[h]) || !fmt_ok(n.att[h])) return QMANN_EINVAL;
+    for (uint32_t h = 0; h < n.n_hop; h++)
         if (n.lin_map[h] != nullptr) return QMANN_EINVAL;             // a blob carries offsets, never pointers
-    }
-    if (!fmt_ok(n.bin)) return QMANN_EINVAL;
     BlobHeader want = hd;
     if (blob_layout(n, &want) != bytes || memcmp(&want, &hd, sizeof hd) != 0) return QMANN_EINVAL;   // offsets must be the canonical ones
     return QMANN_OK;

@@ -55,12 +55,12 @@ static inline void qm_alloc(T **p, size_t n)
 // after the first launch; it must not run while another thread launches.
 struct QmTuning {
     bool no_w7, no_mid, no_lean, no_tied, embed_general_epilogue, embed_valu, answer_two_pass;
-    bool no_tight;                                    // QMANN_NO_TIGHT=1: the lean kernels keep their four-wave (128-register) builds
+    bool no_tight;                                    // QMANN_NO_TIGHT (set, any value): the lean kernels keep their four-wave (128-register) builds
     int lean_sparse;                                  // -1 = the launcher chooses, 0 / 1 forced
 };
 const QmTuning &qm_tuning();                          // (tuning.hip)
 
-// compute units of the current device (256 on an MI355X in SPX mode; fewer in a partitioned mode), asked once
+// compute units of the CURRENT device (256 on an MI355X in SPX mode; fewer in a partitioned mode), asked once per device ordinal
 unsigned qm_cu_count();                               // (tuning.hip)
 
 // Persistent kernels: how many workgroups of `waves` wavefronts are resident AT ONCE on the device, for a kernel compiled for

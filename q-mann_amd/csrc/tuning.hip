@@ -1,5 +1,6 @@
 // tuning.hip -- the process-wide switches of rt.h's QmTuning: read from the environment once, re-read on request.
 #include "rt.h"
+#include <atomic>
 #include "../../include/qmann_batch.h"
 
 namespace {
@@ -18,7 +19,7 @@ void read_env(QmTuning &t)
     t.embed_valu = on("QMANN_EMBED_VALU");
     t.answer_two_pass = on("QMANN_ANSWER_TWO_PASS");
     t.lean_sparse = tri("QMANN_LEAN_SPARSE");
-    t.no_tight = tri("QMANN_NO_TIGHT") == 1;
+    t.no_tight = on("QMANN_NO_TIGHT");              // presence-only, like its siblings
 }
 
 }  // namespace
@@ -32,15 +33,24 @@ const QmTuning &qm_tuning()
 
 unsigned qm_cu_count()
 {
-    static const unsigned n = [] {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
-            (void)hipGetLastError();
-            cus = 256;
-        }
-        return (unsigned)cus;
-    }();
-    return n;
+    // per device ordinal: a one-thread-per-GPU host (examples/forward_sharded.c) may drive differently partitioned devices, and
+    // a persistent grid sized with another device's count runs late workgroups alone (rt.h::qm_resident_groups)
+    constexpr int kMaxDev = 64;
+    static std::atomic<unsigned> cache[kMaxDev];                  // 0 = not asked yet
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    const bool slot = dev >= 0 && dev < kMaxDev;
+    if (slot) {
+        const unsigned c = cache[dev].load(std::memory_order_relaxed);
+        if (c) return c;
+    }
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+        (void)hipGetLastError();
+        cus = 256;
+    }
+    if (slot) cache[dev].store((unsigned)cus, std::memory_order_relaxed);
+    return (unsigned)cus;
 }
 
 extern "C" void qmann_tuning_reload(void)

@@ -80,6 +80,12 @@ def test_fixture_generator_holds_no_product_code():
         assert not [l for l in dyn.splitlines() if l.split()[-1].startswith("cuda_")], so
         needed = subprocess.run(["readelf", "-d", str(so)], capture_output=True, text=True, check=True).stdout
         assert "qmann_hip" not in needed and "amdhip" not in needed, so
+        # what `-z defs` used to guarantee at link time, now that the cuda_* imports stay undefined on purpose (`-z lazy`):
+        # every OTHER undefined symbol resolves in libc / libm / libpthread (nm prints those with their @GLIBC version) -- a
+        # misspelt or missing symbol of ref_glue.c / ref_forward.c would show up here unversioned instead of ending the process
+        # at its first call
+        stray = [u for u in _nm_undefined(so) if not u.startswith("cuda_") and "@GLIBC" not in u]
+        assert not stray, (so, stray)
         L = load_lazy(so)
         assert hasattr(L, "dense_mat_fwd") and hasattr(L, "softmax_fwd") and hasattr(L, "hamming_similarity")
 

@@ -82,7 +82,12 @@ def run_case(env, oracle, cfg, B, S_list, seed, sigma_u=20.0, sigma_k=30.0, sigm
     u_out, taps = net.hops(dk, dv, torch.from_numpy(row_off).to(env.dev), int(n_slots.max()) if B else 0,
                            torch.from_numpy(u0).to(env.dev), taps=True)
     pred, probs, _, _ = net.answer(u_out, want_probs=True)
+    # ... and once more WITHOUT taps: that call takes the production kernel of the shape (k_hops_lean up to 64 slots at 64-byte
+    # rows, k_hops_mid up to 1 024, the streaming kernels beyond; qmann_hops_i8 chooses), whose final state is compared with
+    # the oracle's directly below -- not only through the general kernels the taps route to
+    u_prod = net.hops(dk, dv, torch.from_numpy(row_off).to(env.dev), int(n_slots.max()) if B else 0, torch.from_numpy(u0).to(env.dev))
     torch.cuda.synchronize()
+    g_u_prod = u_prod.cpu().numpy()
     g_codes = taps.score_codes.cpu().numpy(); g_probs = taps.probs.cpu().numpy()
     g_o = taps.o.cpu().numpy(); g_u = taps.u.cpu().numpy(); g_pred = pred.cpu().numpy()
     g_out_probs = probs.cpu().numpy()
@@ -108,6 +113,11 @@ def run_case(env, oracle, cfg, B, S_list, seed, sigma_u=20.0, sigma_k=30.0, sigm
                 assert near_step(t["probs"][h], cfg["fmt"][h][1]).any(), f"o/u differ q{q} h{h}"
                 ok = False
         if not ok:
+            skipped += 1
+            continue
+        want_u = np.maximum(t["u"][H - 1], 0.0) if cfg.get("en_non_lin") else t["u"][H - 1]     # (u_out is what the answer layer reads)
+        if not np.array_equal(g_u_prod[q], want_u):
+            assert any(near_step(t["probs"][h], cfg["fmt"][h][1]).any() for h in range(H)), f"production kernel: final state differs q{q}"
             skipped += 1
             continue
         np.testing.assert_allclose(g_out_probs[q], t["out_probs"], rtol=1e-5, atol=1e-7)
@@ -158,6 +168,14 @@ def test_hops_en_mq_formats_and_clamp_path(env, oracle):
 def test_hops_frac_zero_vector_format(env, oracle):
     cfg = cfg_synth(64, 30, 7)        # Q7.0: the truncating shift is by zero bits
     run_case(env, oracle, cfg, B=8, S_list=[5, 40], seed=9, sigma_u=3.0, sigma_k=3.0)
+
+
+@pytest.mark.parametrize("S,B", [(50, 64), (200, 24)])
+def test_hops_production_kernels_at_the_metric_sizes(env, oracle, S, B):
+    """bench.py's babi_mem50 shape exactly -- |mem| = 50, D = 60, Q5.2, 64 queries, its code spreads -- and synth200_d64's: the
+    no-taps call inside run_case runs k_hops_lean (sparse read-out, six-wave build) / k_hops_mid against the oracle directly"""
+    run_case(env, oracle, cfg_synth(60, 80, 5), B=B, S_list=[S], seed=5000 + S, sigma_u=8.0, sigma_k=8.0)
+    run_case(env, oracle, cfg_synth(60, 80, 5), B=B, S_list=[S], seed=5100 + S, sigma_u=20.0, sigma_k=30.0)
 
 
 def test_hops_full_size_memory(env, oracle):

@@ -433,10 +433,11 @@ def test_deferred_queue_equals_the_verbs(env, gold):
         np.testing.assert_array_equal(r["last_p"], off["last_p"])
 
 
-def test_flush_forgets_the_cached_model_when_the_host_rewrites_weights(env, gold):
-    """the batched model behind the queue is cached on the weight POINTERS.  A host that overwrites the weight
-    values in place with its own copies (here: torch) between two forward phases calls qmann_abi_flush(), which drops the
-    cache: the second phase computes with the new values (= the verbs with the queue off) and a new model was built."""
+def test_invalidate_forgets_the_cached_model_when_the_host_rewrites_weights(env, gold):
+    """The batched model behind the queue is cached on the weight POINTERS.  A host that overwrites the weight values in place
+    with its own copies (here: torch) between two forward phases calls qmann_abi_invalidate_model(), which drops the cache: the
+    second phase computes with the new values (= the verbs with the queue off) and a new model was built.  qmann_abi_flush()
+    alone is a read barrier and keeps the model: a phase after a plain flush builds nothing."""
     import importlib.util
     from conftest import ROOT
     spec = importlib.util.spec_from_file_location("gen_golden", ROOT / "oracle" / "gen_golden.py")
@@ -449,11 +450,15 @@ def test_flush_forgets_the_cached_model_when_the_host_rewrites_weights(env, gold
     args = (env, cfg, None, b["story"].astype(np.float32), b["question"].astype(np.float32), b["answer"].astype(np.float32),
             b["n_sen"].astype(np.int64), nq)
     first = _host_loop(*args, defer=1, dev_wts=dev)
+    env.lib.qmann_abi_flush()                                           # drain only: the cached model survives
+    again = _host_loop(*args, defer=1, dev_wts=dev)
+    assert again["stats"]["models_built"] == first["stats"]["models_built"] and again["match"] == first["match"]
+    first = again
     for k, v in w2.items():                                             # the host's own writes: same pointers, new values
         for t, w in zip(dev[k] if isinstance(v, list) else [dev[k]], v if isinstance(v, list) else [v]):
             t.copy_(env.torch.from_numpy(np.ascontiguousarray(w, np.float32)))
     env.torch.cuda.synchronize()
-    env.lib.qmann_abi_flush()
+    env.lib.qmann_abi_invalidate_model()
     second = _host_loop(*args, defer=1, dev_wts=dev)
     plain = _host_loop(*args, defer=0, dev_wts=dev)
     assert second["stats"]["models_built"] == first["stats"]["models_built"] + 1
