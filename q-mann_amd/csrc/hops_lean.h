@@ -50,6 +50,8 @@ struct LeanArgs {
     uint32_t rows_pad;        // value-tile rows per wavefront (max_slots rounded up to 16)
     uint32_t exp_table;       // 1: fixed-point scores, e^x base, no scale layer: exp(-d . unit) comes from a table
     uint32_t lm_in_lds;       // 1: the linear maps are staged in LDS
+    const uint32_t *list;     // the queries to run, by index (the long stories of a batch whose short ones take hops_quad.h); nullptr: all
+    const uint32_t *n_list;   // device word with the list's length
 };
 
 // Wavefront reductions on the DPP network (row shifts, then the two row broadcasts; the total lands in lane 63 and is
@@ -429,7 +431,9 @@ __device__ __forceinline__ void lean_hop(const HopArgs &a, const LeanArgs &la, u
     lean_finish_hop<W7>(a, h, lane, lw, lmap, u, [&]() { return acc; }, kb_code, csc, csh, reuse);
 }
 
-template <int MODE, int NB, bool W7, bool SPARSE, int WPS>
+// LIST: the queries to run come from an index list (la.list / la.n_list) -- a separate instantiation, so that the plain kernel
+// keeps its registers (the six-wave build sits exactly at its 80-register budget)
+template <int MODE, int NB, bool W7, bool SPARSE, int WPS, bool LIST = false>
 __global__ void __launch_bounds__(kLeanBlock, WPS)
 k_hops_lean(const HopArgs a, const LeanArgs la)
 {
@@ -448,11 +452,13 @@ k_hops_lean(const HopArgs a, const LeanArgs la)
     lean_stage_tables(a, la, etab, lmap, tid, kLeanBlock);
     __syncthreads();
 
-    const uint32_t q_stride = gridDim.x * kLeanWaves, n_query = a.rows_total;   // (rows_total carries the query count, < 2^24: qmann_hops_i8)
+    // (rows_total carries the query count, < 2^24: qmann_hops_i8; with an index list the items are list[0 .. *n_list))
+    const uint32_t q_stride = gridDim.x * kLeanWaves, n_query = LIST ? *la.n_list : a.rows_total;
     // The next query's first key tile and its u0 are requested during the current query's last hop (its row offsets
     // a query earlier still), so a wavefront does not sit through a cold HBM round trip at every query start.
-    uint32_t q = blockIdx.x * kLeanWaves + wave;
-    if (q >= n_query) return;
+    uint32_t qi = blockIdx.x * kLeanWaves + wave;                       // item index; q: the query it names
+    if (qi >= n_query) return;
+    uint32_t q = LIST ? la.list[qi] : qi;
     uint32_t r0 = a.row_off[q], S;
     {
         // a story longer than the caller's bound is cut to the bound (qmann_batch.h): the value tile holds
@@ -490,10 +496,11 @@ k_hops_lean(const HopArgs a, const LeanArgs la)
     };
     load_keys_of(0, r0, S);
     u_next = (lane < D) ? a.u0[q * D + lane] : 0.0f;
-    for (; q < n_query; q += q_stride) {
-        const uint32_t qn = q + q_stride;
-        uint32_t r0n = 0, Sn = 0;
-        if (qn < n_query) {
+    for (; qi < n_query; qi += q_stride) {
+        const uint32_t qin = qi + q_stride;
+        uint32_t r0n = 0, Sn = 0, qn = 0;
+        if (qin < n_query) {
+            qn = LIST ? la.list[qin] : qin;
             r0n = a.row_off[qn];
             const uint32_t S_in = a.row_off[qn + 1] - r0n;
             Sn = S_in < a.max_slots ? S_in : a.max_slots;
@@ -523,13 +530,19 @@ k_hops_lean(const HopArgs a, const LeanArgs la)
                 // (unconditionally: with nothing to come the resource is empty -- r0n = Sn = 0 -- and the loads bring zeros for free)
                 const bool more = h + 1 < H;
                 load_keys_of(more ? h + 1 : 0u, more ? r0 : r0n, more ? S : Sn);
-                if (!more && qn < n_query) u_next = (lane < D) ? a.u0[(size_t)qn * D + lane] : 0.0f;
+                if (!more && qin < n_query) u_next = (lane < D) ? a.u0[(size_t)qn * D + lane] : 0.0f;
             }, vg, kt);
         }
         if (lane < D) a.u_out[q * D + lane] = relu_if(u, a.en_non_lin != 0);
-        r0 = r0n; S = Sn;
+        r0 = r0n; S = Sn; q = qn;
     }
 }
+
+}  // namespace
+
+#include "hops_quad.h"       // stories of <= 16 rows: four queries per wavefront (uses the helpers above)
+
+namespace {
 
 // what the lean kernel covers (everything else keeps the general kernels)
 inline bool lean_supported(const HopArgs &a, uint32_t max_slots, uint32_t key_row_bytes)
@@ -539,9 +552,11 @@ inline bool lean_supported(const HopArgs &a, uint32_t max_slots, uint32_t key_ro
 }
 
 template <int MODE, int NB, bool W7, bool SPARSE>
-inline void launch_lean_w(HopArgs a, uint32_t max_slots, uint32_t n_query, hipStream_t st)
+inline void launch_lean_w(HopArgs a, uint32_t max_slots, uint32_t n_query, hipStream_t st, const uint32_t *list = nullptr,
+                          const uint32_t *n_list = nullptr)
 {
     LeanArgs la{};
+    la.list = list; la.n_list = n_list;
     la.rows_pad = SPARSE ? 0u : ((max_slots ? max_slots : 1u) + 15u) & ~15u;       // (SPARSE: no value tile)
     la.exp_table = (MODE == kModeFixed && a.softmax_base == QMANN_SOFTMAX_EXP && !a.softmax_shift && !a.en_att_scale) ? 1u : 0u;
     la.lm_in_lds = a.en_lin_map ? 1u : 0u;
@@ -564,12 +579,39 @@ inline void launch_lean_w(HopArgs a, uint32_t max_slots, uint32_t n_query, hipSt
     // A/B: mode 3 0.91 -> 0.84 ms, weighted Hamming 0.70 -> 0.65 ms)
     const bool tight = !qm_tuning().no_tight &&
                        qm_resident_groups(kLeanWaves, kLeanWpsTight, lds) > qm_resident_groups(kLeanWaves, kLeanWpsWide, lds);
-    if (tight) go(k_hops_lean<MODE, NB, W7, SPARSE, kLeanWpsTight>, kLeanWpsTight);
+    if (list) go(k_hops_lean<MODE, NB, W7, SPARSE, kLeanWpsWide, true>, kLeanWpsWide);       // (the long stories of a split batch: few)
+    else if (tight) go(k_hops_lean<MODE, NB, W7, SPARSE, kLeanWpsTight>, kLeanWpsTight);
     else go(k_hops_lean<MODE, NB, W7, SPARSE, kLeanWpsWide>, kLeanWpsWide);
 }
 
 template <int MODE, int NB>
+inline void launch_lean_all(const HopArgs &a, uint32_t max_slots, uint32_t n_query, hipStream_t st, const uint32_t *list = nullptr,
+                            const uint32_t *n_list = nullptr);
+
+// Short-memory launches: stories of at most 16 rows take the four-queries-per-wavefront kernel (hops_quad.h), longer ones the
+// one-wavefront-per-query kernel below.  A batch whose bound allows both (the 20-task set: up to 64 rows, 91 % of the stories
+// <= 16) is split on the device into two index lists first (k_split_by_length); the two kernels then run one after the other
+// on the stream, each over its list.  QMANN_NO_QUAD keeps everything on the lean kernel (A/B).
+template <int MODE, int NB>
 inline void launch_lean(const HopArgs &a, uint32_t max_slots, uint32_t n_query, hipStream_t st)
+{
+    if (!quad_supported(a, MODE, max_slots, n_query)) { launch_lean_all<MODE, NB>(a, max_slots, n_query, st); return; }
+    if (max_slots <= kQuadSlots) {
+        launch_quad<MODE, NB>(a, QuadArgs{nullptr, nullptr, n_query}, n_query, st);
+        return;
+    }
+    // [0] short count, [1] long count, then the two lists
+    uint32_t *ws = qm_scratch_u32(2u + 2u * (size_t)n_query, st);
+    if (!ws) { launch_lean_all<MODE, NB>(a, max_slots, n_query, st); return; }
+    QM_HIP(hipMemsetAsync(ws, 0, 2 * sizeof(uint32_t), st));
+    const uint32_t blocks = (n_query + 255u) / 256u;
+    k_split_by_length<<<blocks < 2048u ? blocks : 2048u, 256, 0, st>>>(a.row_off, n_query, max_slots, ws, ws + 2, ws + 2 + n_query);
+    launch_quad<MODE, NB>(a, QuadArgs{ws + 2, ws, n_query}, n_query, st);
+    launch_lean_all<MODE, NB>(a, max_slots, n_query, st, ws + 2 + n_query, ws + 1);
+}
+
+template <int MODE, int NB>
+inline void launch_lean_all(const HopArgs &a, uint32_t max_slots, uint32_t n_query, hipStream_t st, const uint32_t *list, const uint32_t *n_list)
 {
     bool w7 = true;
     for (uint32_t h = 0; h < a.n_hop; h++)
@@ -583,7 +625,8 @@ inline void launch_lean(const HopArgs &a, uint32_t max_slots, uint32_t n_query, 
     // the linear map): the choice goes by the MEAN story length, which the launch knows from the plane size.
     uint32_t surv = 1;
     for (uint32_t h = 0; h < a.n_hop; h++) surv = surv > (1u << a.act[h].frac) ? surv : (1u << a.act[h].frac);
-    const uint32_t mean_slots = (a.rows_total && n_query) ? a.rows_total / n_query : max_slots / 8u;     // (tied hops: no plane size; real stories are short next to their cap)
+    uint32_t mean_slots = (a.rows_total && n_query) ? a.rows_total / n_query : max_slots / 8u;     // (tied hops: no plane size; real stories are short next to their cap)
+    if (list) mean_slots = mean_slots > kQuadSlots + 1u ? mean_slots : kQuadSlots + 1u;          // (the long stories of a split batch: each has > 16 rows)
     bool sparse = surv * 4u <= mean_slots;
     // ... and wherever the value tiles would cost a workgroup per CU: 8 wavefronts x 64 rows x 64 bytes = 32 KB of tiles leave
     // room for two workgroups, the sparse variant (no tile) for three at the six-wave register budget.  The real 20-task set
@@ -596,8 +639,8 @@ inline void launch_lean(const HopArgs &a, uint32_t max_slots, uint32_t n_query, 
             sparse = true;
     }
     if (qm_tuning().lean_sparse >= 0) sparse = qm_tuning().lean_sparse == 1;
-    if (w7) { if (sparse) launch_lean_w<MODE, NB, true, true>(a, max_slots, n_query, st); else launch_lean_w<MODE, NB, true, false>(a, max_slots, n_query, st); }
-    else { if (sparse) launch_lean_w<MODE, NB, false, true>(a, max_slots, n_query, st); else launch_lean_w<MODE, NB, false, false>(a, max_slots, n_query, st); }
+    if (w7) { if (sparse) launch_lean_w<MODE, NB, true, true>(a, max_slots, n_query, st, list, n_list); else launch_lean_w<MODE, NB, true, false>(a, max_slots, n_query, st, list, n_list); }
+    else { if (sparse) launch_lean_w<MODE, NB, false, true>(a, max_slots, n_query, st, list, n_list); else launch_lean_w<MODE, NB, false, false>(a, max_slots, n_query, st, list, n_list); }
 }
 
 }  // namespace

@@ -55,6 +55,7 @@ static inline void qm_alloc(T **p, size_t n)
 // after the first launch; it must not run while another thread launches.
 struct QmTuning {
     bool no_w7, no_mid, no_lean, no_tied, embed_general_epilogue, embed_valu, answer_two_pass;
+    bool no_quad;                                     // QMANN_NO_QUAD: short stories keep the one-wavefront-per-query kernel (hops_quad.h off)
     bool no_tight;                                    // QMANN_NO_TIGHT (set, any value): the lean kernels keep their four-wave (128-register) builds
     int lean_sparse;                                  // -1 = the launcher chooses, 0 / 1 forced
 };
@@ -74,5 +75,10 @@ static inline unsigned qm_resident_groups(unsigned waves, unsigned waves_per_sim
     per_cu = per_cu < by_hw ? per_cu : by_hw;
     return qm_cu_count() * (per_cu ? per_cu : 1u);
 }
+
+// Device scratch of at least `words` 32-bit words for the launch being enqueued on `stream` (index lists of a batch split by
+// story length): one buffer per (device, stream), grown when a launch needs more (the only time this allocates -- like a model's
+// workspace it reaches its size on the first batches), kept for the life of the process.  nullptr when the allocation fails.
+uint32_t *qm_scratch_u32(size_t words, hipStream_t stream);       // (tuning.hip)
 
 static inline unsigned qm_cdiv(unsigned a, unsigned b) { return (a + b - 1) / b; }

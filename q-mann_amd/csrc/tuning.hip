@@ -1,6 +1,9 @@
 // tuning.hip -- the process-wide switches of rt.h's QmTuning: read from the environment once, re-read on request.
 #include "rt.h"
 #include <atomic>
+#include <map>
+#include <mutex>
+#include <utility>
 #include "../../include/qmann_batch.h"
 
 namespace {
@@ -14,6 +17,7 @@ void read_env(QmTuning &t)
     t.no_w7 = on("QMANN_NO_W7");
     t.no_mid = on("QMANN_NO_MID");
     t.no_lean = on("QMANN_NO_LEAN");
+    t.no_quad = on("QMANN_NO_QUAD");
     t.no_tied = on("QMANN_NO_TIED");
     t.embed_general_epilogue = on("QMANN_EMBED_GENERAL_EPILOGUE");
     t.embed_valu = on("QMANN_EMBED_VALU");
@@ -51,6 +55,25 @@ unsigned qm_cu_count()
     }
     if (slot) cache[dev].store((unsigned)cus, std::memory_order_relaxed);
     return (unsigned)cus;
+}
+
+uint32_t *qm_scratch_u32(size_t words, hipStream_t stream)
+{
+    struct Buf { uint32_t *p = nullptr; size_t cap = 0; };
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, Buf> bufs;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    std::lock_guard<std::mutex> hold(mu);
+    Buf &b = bufs[{dev, stream}];
+    if (words > b.cap) {
+        // work enqueued earlier on this stream may still read the old buffer: let it finish before the buffer goes
+        if (b.p) { (void)hipStreamSynchronize(stream); (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+        const size_t cap = words + words / 4 + 64;
+        if (hipMalloc((void **)&b.p, cap * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); b.p = nullptr; return nullptr; }
+        b.cap = cap;
+    }
+    return b.p;
 }
 
 extern "C" void qmann_tuning_reload(void)

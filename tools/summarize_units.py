@@ -1,17 +1,27 @@
 #!/usr/bin/env python3
 """gpurun_out/units/<tag>/pass*.csv (tools/pmc_units.sh) -> profiles/<round>_units_<tag>.txt: per-dispatch means of the SQ / TCP
 counters of the k_hops_* kernel and the ratios that say which unit is saturated.
-usage: tools/summarize_units.py <round> <tag> <workload> [kernel_ms]"""
+usage: tools/summarize_units.py <round> <tag> <workload> [kernel_ms] [--kernel SUBSTR --out NAME]
+(--kernel: keep only the dispatches whose kernel name contains SUBSTR -- a pass file may hold several kernels of a whole
+forward; --out: the summary goes to profiles/<round>_units_<NAME>.txt)"""
 import csv, sys, collections
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
-rnd, tag, wl = sys.argv[1:4]
-ms = float(sys.argv[4]) if len(sys.argv) > 4 else None
+argv = sys.argv[1:]
+ksub = outname = None
+if "--kernel" in argv:
+    i = argv.index("--kernel"); ksub = argv[i + 1]; del argv[i:i + 2]
+if "--out" in argv:
+    i = argv.index("--out"); outname = argv[i + 1]; del argv[i:i + 2]
+rnd, tag, wl = argv[0:3]
+ms = float(argv[3]) if len(argv) > 3 else None
 acc, cnt, kern = collections.defaultdict(float), collections.Counter(), None
 dur = {}                                            # pass file -> durations of its dispatches (ns), from the rows' timestamps
 for f in sorted((ROOT / "gpurun_out" / "units" / tag).glob("pass*.csv")):
     for r in csv.DictReader(open(f)):
-        kern = r["Kernel_Name"][:90]
+        if ksub and ksub not in r["Kernel_Name"]:
+            continue
+        kern = r["Kernel_Name"][:110]
         acc[r["Counter_Name"]] += float(r["Counter_Value"]); cnt[r["Counter_Name"]] += 1
         dur.setdefault(f.name, {})[r["Dispatch_Id"]] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
 ms_trace = ms
@@ -57,6 +67,12 @@ out.append(f"VALU lane utilisation = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INS
 if "TCP_TCC_READ_REQ" in m:
     out.append(f"mean L2 read latency seen by the L1 = TCP_TCC_READ_REQ_LATENCY / TCP_TCC_READ_REQ = {g('TCP_TCC_READ_REQ_LATENCY') / max(g('TCP_TCC_READ_REQ'), 1):.0f} cycles")
     out.append(f"TCP_PENDING_STALL_CYCLES / TCP_GATE_EN1 = {g('TCP_PENDING_STALL_CYCLES') / max(g('TCP_GATE_EN1'), 1):.3f}")
-p = ROOT / "profiles" / f"{rnd}_units_{tag}.txt"
+if "FETCH_SIZE" in m:
+    out.append(f"HBM traffic per dispatch (rocprofv3 FETCH_SIZE / WRITE_SIZE are in KiB; x2 gfx950 correction on FETCH_SIZE as the guide prescribes): "
+               f"read {g('FETCH_SIZE') * 1024 * 2 / 1e6:.1f} MB, written {g('WRITE_SIZE') * 1024 / 1e6:.1f} MB (uncorrected)")
+if "SQ_VALU_MFMA_BUSY_CYCLES" in m and ms:
+    out.append(f"matrix-pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (dispatch time x 2.1 GHz) = {g('SQ_VALU_MFMA_BUSY_CYCLES') / 1024.0 / (ms * 1e-3 * 2.1e9):.3f}; "
+               f"MFMA instructions {g('SQ_INSTS_VALU_MFMA_I8'):.0f}")
+p = ROOT / "profiles" / f"{rnd}_units_{outname or tag}.txt"
 p.write_text("\n".join(out) + "\n")
 print(p)
