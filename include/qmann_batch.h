@@ -158,10 +158,23 @@ int qmann_hops_packed(const qmann_net *net, const uint64_t *key_planes, size_t k
  * softmax over V, arg-max with ties to the highest index, and -- when `answer` is given -- the
  * test-phase bookkeeping of cross_entropy_run mode 3 (cost += -p[answer], match += pred==answer).
  *   w_ans [V][D] float, answer [n_query] uint32 or NULL, pred [n_query] uint32,
- *   probs [n_query][V] float or NULL, cost/match: single device words (accumulated) or NULL. */
+ *   probs [n_query][V] float or NULL, cost/match: single device words (accumulated) or NULL.
+ * Arithmetic.  qmann_answer_f32_serial sums every logit over the embedding axis serially in float, separate multiply and add:
+ * the reference's own order (lib/layer_cuda.cu:70-80), bit-equal logits; e^x through expf, a double total, the quotient of the
+ * double division (:2006-2042).  qmann_answer_f32 takes, at the bAbI shapes (dim_emb <= 64, dim_input <= 256, e^x / 2^x base),
+ * the FUSED form on the bf16 matrix cores instead (csrc/batch_io.hip::k_answer_mfma): u -- which must lie on an 8-bit grid, as
+ * the hop kernels write it -- times W split exactly into three bf16 parts, float accumulation, hardware 2^x; closer to the
+ * exact sum than the serial float loop, and within north_star's 1e-5 of it on the probabilities (absolute; relative 1e-5 while
+ * |logit| <= 16, where a unit in the last place of a logit is still below 1e-6); predictions agree wherever the two best
+ * probabilities differ by more than 1e-6, exact ties go to the highest index in both.  Nine times fewer vector instructions
+ * per query at the joint dictionary.  QMANN_ANSWER_EXACT (environment) makes qmann_answer_f32 the serial form everywhere;
+ * the drop-in queue behind the cuda_* verbs always runs the serial form. */
 int qmann_answer_f32(const qmann_net *net, const float *w_ans, const float *u, const uint32_t *answer,
                      uint32_t *pred, float *probs, float *cost, uint32_t *match, uint32_t n_query,
                      void *stream);
+int qmann_answer_f32_serial(const qmann_net *net, const float *w_ans, const float *u, const uint32_t *answer,
+                            uint32_t *pred, float *probs, float *cost, uint32_t *match, uint32_t n_query,
+                            void *stream);
 
 /* The same answer layer when the answer matrix is on an int8 grid: w_ans_i8 [V][Dp] two's-complement
  * codes of Q(w_fmt); the projection runs on the int8 matrix cores (v_mfma_i32_16x16x64_i8).
@@ -170,7 +183,7 @@ int qmann_answer_f32(const qmann_net *net, const float *w_ans, const float *u, c
  *       count equal the float path exactly (logits are exact integers); the cost -p[answer] agrees within the 1e-5 softmax
  *       tolerance (normaliser accumulated against the running maximum, hardware exp as the reference's __expf).
  *   probs != NULL: two kernels -- logits to the workspace, then the float path's softmax on them: probabilities bit-identical
- *       to qmann_answer_f32 on the same grid values.
+ *       to qmann_answer_f32_serial on the same grid values.
  * logits_ws: caller-provided workspace, float [n_query][V] (the one-pass form keeps its per-slice records there). */
 int qmann_answer_i8(const qmann_net *net, const int8_t *w_ans_i8, qmann_fmt w_fmt, const float *u,
                     float *logits_ws, const uint32_t *answer, uint32_t *pred, float *probs, float *cost,

@@ -153,6 +153,7 @@ _proto("qmann_pack_bitplanes", C.c_int, [_vp, _vp, C.c_size_t, C.c_uint32, C.c_u
 _proto("qmann_hops_packed", C.c_int, [C.POINTER(Net), _vp, C.c_size_t, _vp, C.c_size_t, _vp, C.c_uint32, _vp, _vp,
                                       C.POINTER(Taps), C.c_uint32, _vp])
 _proto("qmann_answer_f32", C.c_int, [C.POINTER(Net), _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_uint32, _vp])
+_proto("qmann_answer_f32_serial", C.c_int, [C.POINTER(Net), _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_uint32, _vp])
 _proto("qmann_answer_i8", C.c_int, [C.POINTER(Net), _vp, Fmt, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_uint32, _vp])
 _proto("qmann_embed_story", C.c_int, [C.POINTER(Net), _vp, C.c_uint32, C.POINTER(_vp), C.POINTER(_vp), _vp, _vp,
                                       C.c_size_t, _vp])

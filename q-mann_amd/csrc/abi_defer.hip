@@ -368,6 +368,7 @@ bool run_batched(const std::vector<Op> &ops, const Sig &s, const std::vector<Que
     ok = ok && hipMemcpy(&irregular, g_scr.counters, 4, hipMemcpyDeviceToHost) == hipSuccess;      // (also waits for the row_off copy)
     if (!ok) { (void)hipGetLastError(); return false; }
     if (irregular) return false;
+    QmAnswerExact exact_answer_layer;                 // the queue promises the verb-by-verb loop's results: serial-order float sums
     const int rc = qmann_model_forward_bow(g_model, qs[a].m, ro[n], qs[a].q, g_scr.row_off, max_slots, (uint32_t)n, g_scr.label, g_scr.pred,
                                            cost, cnt, nullptr);
     if (rc != QMANN_OK) {

@@ -278,6 +278,188 @@ k_answer_small(const float *__restrict__ w_ans, const float *__restrict__ u, con
 #undef QM_ROW_STEPS
 
 // ---------------------------------------------------------------------------
+// The FLOAT answer layer on the bf16 matrix cores (bAbI widths: 64-byte rows, dictionaries up to 256), within north_star's 1e-5
+// on the float softmax instead of bit-equal to the reference's serial sum.  The kernels above reproduce
+// lib/layer_cuda.cu:70-80's order of additions exactly and pay for it: 545 vector instructions per query at the joint
+// dictionary (profiles/r05_units_j20_k_answer_small.txt), a fifth of that forward.  Here:
+//   * u, the last hop's output, lies on an 8-bit grid (|code| <= 127): every component is exactly a bf16;
+//   * W (arbitrary float32) is split once per workgroup into three bf16 images W1 + W2 + W3 = W exactly (each takes the top 8
+//     significant bits of what the one before left), 144-byte rows in LDS (16 B of padding: fragment reads without bank conflicts);
+//   * logits = u . W3 + u . W2 + u . W1 on v_mfma_f32_16x16x32_bf16, rows = 16 answers, columns = 16 queries: every product is
+//     exact (15 significant bits), only the float accumulation rounds -- the result sits closer to the exact sum than the serial
+//     float loop does; against that loop: a few units in the last place of the logit (measured: probabilities within 5e-6
+//     relative at the tests' and the bench's magnitudes, tools/answer_fused_error.py);
+//   * a lane ends with its query's logits of answers 16t + 4(lane >> 4) + r in registers: maximum, 2^((l - max) log2 e) through
+//     v_exp_f32, float total, arg-max on the LOGITS (equal logits <=> equal probabilities; ties to the highest index as
+//     lib/layer_cuda.cu:1918-1939) and the label's probability never leave them; two cross-lane steps join the four lane groups.
+// 36 vector instructions per query instead of 545 at V = 238.  QMANN_ANSWER_EXACT (or the drop-in queue, which promises the
+// serial loop's results) keeps the serial-order kernels.
+// ---------------------------------------------------------------------------
+typedef short bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+constexpr int kAmWaves = 16, kAmBlock = kAmWaves * kWave;
+constexpr uint32_t kAmPitch = 144;                  // bytes per row of a W image: 64 bf16 + 16 B (rows 16 B apart modulo 256)
+
+template <int T>                                     // tiles of 16 answers: V <= 16 T
+__global__ void __launch_bounds__(kAmBlock, 4)
+k_answer_mfma(const float *__restrict__ w_ans, const float *__restrict__ u, const uint32_t *__restrict__ answer,
+              uint32_t *__restrict__ pred, float *__restrict__ probs, float *cost, uint32_t *match, uint32_t D, uint32_t V,
+              uint32_t softmax_base, uint32_t n_query)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr uint32_t kImg = T * 16u * kAmPitch;        // one bf16 image of W
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1);
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid / kWave));
+    for (uint32_t i = tid; i < T * 16u * 64u; i += kAmBlock) {
+        const uint32_t v = i >> 6, c = i & 63u;
+        const float w = (v < V && c < D) ? w_ans[(size_t)v * D + c] : 0.0f;
+        const uint32_t b1 = __builtin_bit_cast(uint32_t, w) & 0xFFFF0000u;
+        const float r1 = w - __builtin_bit_cast(float, b1);                 // exact
+        const uint32_t b2 = __builtin_bit_cast(uint32_t, r1) & 0xFFFF0000u;
+        const float r2 = r1 - __builtin_bit_cast(float, b2);                // exact; at most 8 significant bits are left
+        const uint32_t b3 = __builtin_bit_cast(uint32_t, r2) & 0xFFFF0000u;
+        uint8_t *dst = smem + v * kAmPitch + c * 2u;
+        *(uint16_t *)dst = (uint16_t)(b1 >> 16);
+        *(uint16_t *)(dst + kImg) = (uint16_t)(b2 >> 16);
+        *(uint16_t *)(dst + 2u * kImg) = (uint16_t)(b3 >> 16);
+    }
+    __syncthreads();
+    const uint32_t qi = lane & 15u, grp = lane >> 4;
+    const bool vec4 = (D & 3u) == 0u;
+    const uint8_t *arow = smem + qi * kAmPitch + grp * 16u;          // this lane's piece of an answer row: k = 8 grp .. + 7 of a K step
+    float cost_acc = 0.0f;
+    uint32_t match_acc = 0;
+    const uint32_t n_task = (n_query + 15u) / 16u;
+    for (uint32_t task = blockIdx.x * kAmWaves + wave; task < n_task; task += gridDim.x * kAmWaves) {
+        asm volatile("" ::: "memory");                                   // (the W fragments are read per task: hoisted out of this loop they would take 24 T registers)
+        const uint32_t q = task * 16u + qi;
+        const bool q_ok = q < n_query;
+        // B fragments: u[q][32 ks + 8 grp + j], j = 0 .. 7, as bf16 (exact: u lies on an 8-bit grid)
+        bf16x8_t bf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            const uint32_t k0 = 32u * ks + 8u * grp;
+            uint32_t w[8];
+            if (vec4) {
+                const float *src = u + (size_t)q * D + k0;
+                // (plain ifs: `cond ? *(const f32x4_t *)p : zero` compiles to ONE dword load splatted over the vector with hipcc 7.2)
+                float4 lo = {0.0f, 0.0f, 0.0f, 0.0f}, hi = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (q_ok && k0 + 3u < D) lo = *(const float4 *)src;
+                if (q_ok && k0 + 7u < D) hi = *(const float4 *)(src + 4);
+#pragma unroll
+                for (int j = 0; j < 4; j++) { w[j] = __builtin_bit_cast(uint32_t, (&lo.x)[j]); w[4 + j] = __builtin_bit_cast(uint32_t, (&hi.x)[j]); }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) w[j] = (q_ok && k0 + j < D) ? __builtin_bit_cast(uint32_t, u[(size_t)q * D + k0 + j]) : 0u;
+            }
+            i32x4 pk;
+#pragma unroll
+            for (int j = 0; j < 4; j++) pk[j] = (int)__builtin_amdgcn_perm(w[2 * j + 1], w[2 * j], 0x07060302u);    // the two high halves
+            bf[ks] = __builtin_bit_cast(bf16x8_t, pk);
+        }
+        f32x4_t acc[T];
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            acc[t] = f32x4_t{0, 0, 0, 0};
+#pragma unroll
+            for (int s_ = 2; s_ >= 0; s_--)                              // the smallest terms first
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) {
+                    const bf16x8_t af = *(const bf16x8_t *)(arow + s_ * kImg + t * 16u * kAmPitch + ks * 64u);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[ks], acc[t], 0, 0, 0);
+                }
+        }
+        // ---- softmax statistics of this lane's T x 4 logits (answer 16 t + 4 grp + r), then across the four lane groups ----
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+            if ((uint32_t)t * 16u + 16u > V) {                           // (wavefront-uniform) the dictionary ends inside this tile
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[t][r] = ((uint32_t)t * 16u + grp * 4u + r < V) ? acc[t][r] : -INFINITY;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) mx = fmaxf(mx, acc[t][r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        // arg-max on the logits: the highest position of this lane that holds the maximum (positions ascend with the answer index)
+        int bpos = -1;
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) bpos = acc[t][r] == mx ? 4 * t + r : bpos;
+            __builtin_amdgcn_sched_barrier(0);                           // (a tile's compares next to its selects: all 4 T lane masks at once do not fit the scalar file)
+        }
+        uint32_t bi = bpos >= 0 ? (uint32_t)(bpos >> 2) * 16u + grp * 4u + (uint32_t)(bpos & 3) : 0u;
+        { const uint32_t o = (uint32_t)__shfl_xor((int)bi, 16); const int ob = __shfl_xor(bpos, 16); if (ob >= 0 && (bpos < 0 || o > bi)) { bi = o; bpos = ob; } }
+        { const uint32_t o = (uint32_t)__shfl_xor((int)bi, 32); const int ob = __shfl_xor(bpos, 32); if (ob >= 0 && (bpos < 0 || o > bi)) { bi = o; bpos = ob; } }
+        // the label's logit, if this lane holds it (a binary tree of selects over the lane's positions)
+        const uint32_t y = (answer && q_ok) ? answer[q] : 0xFFFFFFFFu;
+        float ly = -INFINITY;
+        if (answer) {                                                    // (wavefront-uniform)
+            const bool mine = y < V && ((y >> 2) & 3u) == grp;
+            const uint32_t ty = y >> 4, ry = y & 3u;
+            f32x4_t sel = acc[0];
+#pragma unroll
+            for (int t = 1; t < T; t++) {
+                const bool pick = ty == (uint32_t)t;
+#pragma unroll
+                for (int r = 0; r < 4; r++) sel[r] = pick ? acc[t][r] : sel[r];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            float l1 = (ry & 1u) ? sel[1] : sel[0], l2 = (ry & 1u) ? sel[3] : sel[2];
+            ly = mine ? ((ry & 2u) ? l2 : l1) : -INFINITY;
+            ly = fmaxf(ly, __shfl_xor(ly, 16));
+            ly = fmaxf(ly, __shfl_xor(ly, 32));
+        }
+        // e = base^(l - max); the 2^x base needs no scaling (lib/layer.c:1225), e^x goes through 2^(x log2 e)
+        const float sc = softmax_base == QMANN_SOFTMAX_EXP ? 1.44269504088896341f : 1.0f;
+        float tot = 0.0f;
+#pragma unroll
+        for (int t = 0; t < T; t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                acc[t][r] = __builtin_amdgcn_exp2f((acc[t][r] - mx) * sc);
+                tot += acc[t][r];
+            }
+        tot += __shfl_xor(tot, 16);
+        tot += __shfl_xor(tot, 32);
+        const float inv = __builtin_amdgcn_rcpf(tot);
+        if (probs && q_ok) {
+#pragma unroll
+            for (int t = 0; t < T; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const uint32_t v = (uint32_t)t * 16u + grp * 4u + r;
+                    if (v < V) probs[(size_t)q * V + v] = acc[t][r] * inv;
+                }
+        }
+        if (grp == 0 && q_ok) {
+            pred[q] = bi;
+            if (y < V) {
+                cost_acc += -(__builtin_amdgcn_exp2f((ly - mx) * sc) * inv);
+                match_acc += (y == bi) ? 1u : 0u;
+            }
+        }
+    }
+    if (answer) {
+        // cost / match: summed per workgroup, one atomic each
+        __shared__ float red_c[kAmWaves];
+        __shared__ uint32_t red_m[kAmWaves];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { cost_acc += __shfl_xor(cost_acc, o); match_acc += __shfl_xor(match_acc, o); }   // lanes 0 .. 15 hold the figures
+        if (lane == 0) { red_c[wave] = cost_acc; red_m[wave] = match_acc; }
+        __syncthreads();
+        if (tid == 0) {
+            float c = 0.0f; uint32_t m = 0;
+            for (int i = 0; i < kAmWaves; i++) { c += red_c[i]; m += red_m[i]; }
+            if (cost) atomicAdd(cost, c);
+            if (match && m) atomicAdd(match, m);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Answer projection on the matrix cores, for an answer matrix that lives on an int8 grid:
 // logits[q][v] = sum_c U[q][c] . W[v][c] with both operands small integers (codes), so the
 // reference's float serial sum (lib/layer_cuda.cu:70-80) is an exact integer times
@@ -1332,8 +1514,8 @@ static void fill_qkinds(EmbedIdxArgs &a)
 
 extern "C" {
 
-int qmann_answer_f32(const qmann_net *net, const float *w_ans, const float *u, const uint32_t *answer,
-                     uint32_t *pred, float *probs, float *cost, uint32_t *match, uint32_t n_query, void *stream)
+static int answer_f32_impl(const qmann_net *net, const float *w_ans, const float *u, const uint32_t *answer, uint32_t *pred,
+                           float *probs, float *cost, uint32_t *match, uint32_t n_query, void *stream, bool allow_fused)
 {
     QmBatched qm_scope;
     if (!net || !w_ans || !u || !pred) return QMANN_EINVAL;
@@ -1343,6 +1525,27 @@ int qmann_answer_f32(const qmann_net *net, const float *w_ans, const float *u, c
     if (lds > 128 * 1024) return QMANN_ERANGE;
     if (n_query == 0) return QMANN_OK;
     if (n_query >= (1u << 24)) return QMANN_ERANGE;      // one workgroup per query: a launch holds < 2^32 threads
+    // bAbI shapes (D <= 64, V <= 256), the e^x and 2^x bases: the fused form on the bf16 matrix cores (k_answer_mfma), within
+    // 1e-5 on the softmax; qmann_answer_exact_scope / QMANN_ANSWER_EXACT keep the serial-order kernels below
+    if (allow_fused && D <= 64u && V <= 256u && net->softmax_base != QMANN_SOFTMAX_EXP_PLAN && !qm_tuning().answer_exact && qm_answer_exact_depth == 0) {
+        const uint32_t tiles = (V + 15u) / 16u;
+        hipStream_t st = (hipStream_t)stream;
+        const uint32_t n_task = (n_query + 15u) / 16u, need = (n_task + kAmWaves - 1) / kAmWaves;
+#define QM_ANS_MFMA(TT)                                                                                                          \
+    do {                                                                                                                         \
+        const size_t l_ = 3u * (size_t)(TT) * 16u * kAmPitch;                                                                    \
+        if (l_ > 48 * 1024)                                                                                                      \
+            QM_HIP(hipFuncSetAttribute((const void *)k_answer_mfma<TT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l_));   \
+        const uint32_t cap = qm_resident_groups(kAmWaves, 4, l_ + 256);                                                          \
+        k_answer_mfma<TT><<<need < cap ? need : cap, kAmBlock, l_, st>>>(w_ans, u, answer, pred, probs, cost, match, D, V, net->softmax_base, n_query); \
+    } while (0)
+        if (tiles <= 2) QM_ANS_MFMA(2); else if (tiles <= 3) QM_ANS_MFMA(3); else if (tiles <= 4) QM_ANS_MFMA(4);
+        else if (tiles <= 5) QM_ANS_MFMA(5); else if (tiles <= 8) QM_ANS_MFMA(8); else if (tiles <= 12) QM_ANS_MFMA(12);
+        else if (tiles <= 15) QM_ANS_MFMA(15); else QM_ANS_MFMA(16);
+#undef QM_ANS_MFMA
+        QM_LAUNCH_CHECK();
+        return qm_scope.rc();
+    }
     if (lds > 48 * 1024)
         QM_HIP(hipFuncSetAttribute((const void *)k_answer<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // lanes per query / logits per lane / queries per lane group.  Short dictionaries: 16 lanes (one DPP row), four
@@ -1383,6 +1586,18 @@ int qmann_answer_f32(const qmann_net *net, const float *w_ans, const float *u, c
         w_ans, u, answer, pred, probs, cost, match, D, V, net->softmax_base, n_query);
     QM_LAUNCH_CHECK();
     return qm_scope.rc();
+}
+
+int qmann_answer_f32(const qmann_net *net, const float *w_ans, const float *u, const uint32_t *answer,
+                     uint32_t *pred, float *probs, float *cost, uint32_t *match, uint32_t n_query, void *stream)
+{
+    return answer_f32_impl(net, w_ans, u, answer, pred, probs, cost, match, n_query, stream, true);
+}
+
+int qmann_answer_f32_serial(const qmann_net *net, const float *w_ans, const float *u, const uint32_t *answer,
+                            uint32_t *pred, float *probs, float *cost, uint32_t *match, uint32_t n_query, void *stream)
+{
+    return answer_f32_impl(net, w_ans, u, answer, pred, probs, cost, match, n_query, stream, false);
 }
 
 int qmann_answer_i8(const qmann_net *net, const int8_t *w_ans_i8, qmann_fmt w_fmt, const float *u, float *logits_ws,

@@ -68,6 +68,14 @@ static_assert(kOffScores % 16 == 0, "score bytes must start 16-byte aligned");
 constexpr int kRawBufferFlags = 0x00020000;         // dword 3 of a raw buffer resource on gfx9 / CDNA: 32-bit data format, no swizzle
 constexpr int kBufferNt = 2;                        // cache policy of a buffer load: nt (streamed once)
 
+// Stage marks for tools/stage_budget.py (a build with -DQM_STAGE_MARKS, never the shipped one): a comment in the assembly plus a
+// scheduling barrier, so that the instructions between two marks are those of the stage the first one names.
+#ifdef QM_STAGE_MARKS
+#define QM_MARK(NAME) do { asm volatile("; QM_MARK " NAME ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define QM_MARK(NAME) do { } while (0)
+#endif
+
 template <int CTRL>
 __device__ __forceinline__ int dpp_add(int v)
 {

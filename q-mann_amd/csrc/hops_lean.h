@@ -595,7 +595,14 @@ inline void launch_lean_all(const HopArgs &a, uint32_t max_slots, uint32_t n_que
 template <int MODE, int NB>
 inline void launch_lean(const HopArgs &a, uint32_t max_slots, uint32_t n_query, hipStream_t st)
 {
-    if (!quad_supported(a, MODE, max_slots, n_query)) { launch_lean_all<MODE, NB>(a, max_slots, n_query, st); return; }
+    // A batch is split only where short stories can be many: mean length (known from the plane size; tied hops carry none and
+    // take the bAbI guess, stories short next to their cap) within the quad kernel's 16 rows.  The |mem| = 50 shape stays whole
+    // on the six-wave lean build.
+    const uint32_t mean_slots = (a.rows_total && n_query) ? a.rows_total / n_query : max_slots / 8u;
+    if (!quad_supported(a, MODE, max_slots, n_query) || (max_slots > kQuadSlots && mean_slots > kQuadSlots)) {
+        launch_lean_all<MODE, NB>(a, max_slots, n_query, st);
+        return;
+    }
     if (max_slots <= kQuadSlots) {
         launch_quad<MODE, NB>(a, QuadArgs{nullptr, nullptr, n_query}, n_query, st);
         return;
@@ -604,8 +611,8 @@ inline void launch_lean(const HopArgs &a, uint32_t max_slots, uint32_t n_query, 
     uint32_t *ws = qm_scratch_u32(2u + 2u * (size_t)n_query, st);
     if (!ws) { launch_lean_all<MODE, NB>(a, max_slots, n_query, st); return; }
     QM_HIP(hipMemsetAsync(ws, 0, 2 * sizeof(uint32_t), st));
-    const uint32_t blocks = (n_query + 255u) / 256u;
-    k_split_by_length<<<blocks < 2048u ? blocks : 2048u, 256, 0, st>>>(a.row_off, n_query, max_slots, ws, ws + 2, ws + 2 + n_query);
+    const uint32_t blocks = (n_query + kSplitBlock - 1u) / kSplitBlock;
+    k_split_by_length<<<blocks < 1024u ? blocks : 1024u, kSplitBlock, 0, st>>>(a.row_off, n_query, max_slots, ws, ws + 2, ws + 2 + n_query);
     launch_quad<MODE, NB>(a, QuadArgs{ws + 2, ws, n_query}, n_query, st);
     launch_lean_all<MODE, NB>(a, max_slots, n_query, st, ws + 2 + n_query, ws + 1);
 }

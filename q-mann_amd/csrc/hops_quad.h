@@ -172,6 +172,7 @@ k_hops_quad(const HopArgs a, const LeanArgs la, const QuadArgs qa)
             const int maxa = 127;
             if (h + 1 == H) item_of(i0 + stride, qn, r0n, Sn);         // the next quad (past the end: no rows, its key prefetch brings zeros for free)
             const bool relu = hop_relu(a, h);
+            QM_MARK("operand codes + publish");
             // ---- operand codes of this lane's four columns, published into the query's images -----------------------
             int kb[4];
 #pragma unroll
@@ -200,6 +201,7 @@ k_hops_quad(const HopArgs a, const LeanArgs la, const QuadArgs qa)
             }
             wave_sync();
 
+            QM_MARK("scan");
             // ---- scores: pass j covers rows 4j .. 4j+3 of every story; lanes with chunk == j keep the pass's score ----
             ScanConst csc;
             uint32_t csh = 0;
@@ -237,6 +239,7 @@ k_hops_quad(const HopArgs a, const LeanArgs la, const QuadArgs qa)
                 code = scan([&](const i32x4 x) { return hambyte_lane_sum<MODE, NB>(x, c); }, 32767, false);
             }
 
+            QM_MARK("softmax + weight codes");
             // ---- softmax over the slots of each story: one DPP row per story -------------------------------------------
             const SmCfg smc = sm_cfg(a, h);
             float e;
@@ -251,6 +254,7 @@ k_hops_quad(const HopArgs a, const LeanArgs la, const QuadArgs qa)
             const double total = quad_row_sum_f64((double)e);           // the CUDA kernel's double total (lib/layer_cuda.cu:2024-2042)
             const int kp = lean_weight_code(e, total, live, smc, fa, maxa);
 
+            QM_MARK("survivors: pick, fetch");
             // ---- survivors of Q(p): up to four per round, their value dwords requested at once -------------------------
             uint32_t m16 = (uint32_t)(__ballot(kp != 0) >> (16u * g)) & 0xFFFFu;      // this story's survivors, by lane of the row
             const uint8_t *v0 = (const uint8_t *)a.vals + (size_t)h * a.hop_stride;
@@ -288,10 +292,8 @@ k_hops_quad(const HopArgs a, const LeanArgs la, const QuadArgs qa)
                 const bool more = h + 1 < H;
                 load_keys_of(more ? h + 1 : 0u, more ? r0 : r0n, more ? S : Sn);
             };
-#ifdef QM_QUAD_KEYS_EARLY
-            prefetch_keys();
-#endif
 
+            QM_MARK("linear map");
             // ---- linear map: 16 passes of 4 rows x 4 lanes per query on the pre-split rows in LDS ------------------------
             const bool reuse = MODE == kModeFixed && !relu;             // (word length 7 everywhere: the scan's constants serve)
             int keep[4] = {0, 0, 0, 0};
@@ -310,15 +312,19 @@ k_hops_quad(const HopArgs a, const LeanArgs la, const QuadArgs qa)
                     keep[t >> 2] = chunk == (uint32_t)(t & 3) ? s : keep[t >> 2];
                 }
             }
-#ifndef QM_QUAD_KEYS_EARLY
-            prefetch_keys();                                            // (behind the linear map: its 16 registers are not live across the 16 passes)
-#endif
+            QM_MARK("key prefetch");
+            // behind the linear map: in front of it the 16 key registers are live across the 16 passes (8 spilled registers at the
+            // 80-register budget) and the forwards measured 1.5-4.5 % SLOWER (task 1 419 against 427 M q/s, joint 222 against 232;
+            // interleaved A/B, ROUND_NOTES.md)
+            prefetch_keys();
+            QM_MARK("read-out");
             // ---- read-out ---------------------------------------------------------------------------------------------------
             add();
             while (__ballot(m16 != 0u)) { pick_fetch(); add(); }        // more than four survivors: formats with frac > 2, rarely
             int oc[4];
             oc[0] = (int)(short)(acc02 & 0xFFFFu); oc[2] = (int)acc02 >> 16;
             oc[1] = (int)(short)(acc13 & 0xFFFFu); oc[3] = (int)acc13 >> 16;
+            QM_MARK("hop update");
             // ---- hop update u' = Qa(Qa(lu) + Qa(o)), this lane's four columns ------------------------------------------------
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -338,6 +344,7 @@ k_hops_quad(const HopArgs a, const LeanArgs la, const QuadArgs qa)
                 uf[i] = qm_scale_down((float)un, fa.frac);
             }
             wave_sync();                                                // the next hop rewrites the images
+            QM_MARK("end of hop");
         }
         if (q != 0xFFFFFFFFu) {
 #pragma unroll
@@ -349,29 +356,36 @@ k_hops_quad(const HopArgs a, const LeanArgs la, const QuadArgs qa)
 }
 
 // Stories of a batch by length: the indices of those with at most kQuadSlots rows (after the cut to the caller's bound) go to
-// `short_list`, the others to `long_list`; a wavefront's 64 consecutive queries are appended together (one atomic per list and
-// wavefront), in order, so the lists stay nearly sorted.  counts[0] / counts[1]: the list lengths, zeroed by the launcher.
-__global__ void __launch_bounds__(256)
+// `short_list`, the others to `long_list`.  A workgroup's 1 024 consecutive queries are appended together -- ONE atomic per list
+// and workgroup (an atomic per wavefront serialised 8 192 of them on two words: 62 us for 262 144 queries) --, in order, so the
+// lists stay nearly sorted.  counts[0] / counts[1]: the list lengths, zeroed by the launcher.
+constexpr int kSplitBlock = 1024;
+__global__ void __launch_bounds__(kSplitBlock)
 k_split_by_length(const uint32_t *__restrict__ row_off, uint32_t n_query, uint32_t max_slots, uint32_t *__restrict__ counts,
                   uint32_t *__restrict__ short_list, uint32_t *__restrict__ long_list)
 {
-    const uint32_t lane = threadIdx.x & 63u;
-    for (size_t q0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) & ~(size_t)63; q0 < n_query; q0 += (size_t)gridDim.x * blockDim.x) {
-        const size_t q = q0 + lane;
+    __shared__ uint32_t wsum[2][kSplitBlock / 64], wbase[2][kSplitBlock / 64];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (size_t q0 = (size_t)blockIdx.x * kSplitBlock; q0 < n_query; q0 += (size_t)gridDim.x * kSplitBlock) {
+        const size_t q = q0 + threadIdx.x;
         uint32_t s = 0;
         const bool ok = q < n_query;
         if (ok) { s = row_off[q + 1] - row_off[q]; s = s < max_slots ? s : max_slots; }
         const bool is_short = ok && s <= kQuadSlots, is_long = ok && s > kQuadSlots;
         const uint64_t ms = __ballot(is_short), ml = __ballot(is_long);
-        uint32_t bs = 0, bl = 0;
-        if (lane == 0) {
-            if (ms) bs = atomicAdd(&counts[0], (uint32_t)__popcll(ms));
-            if (ml) bl = atomicAdd(&counts[1], (uint32_t)__popcll(ml));
+        if (lane == 0) { wsum[0][wave] = (uint32_t)__popcll(ms); wsum[1][wave] = (uint32_t)__popcll(ml); }
+        __syncthreads();
+        if (threadIdx.x < 2) {                                          // thread k: list k's offsets of the 16 wavefronts, one atomic
+            uint32_t tot = 0;
+            for (int w = 0; w < kSplitBlock / 64; w++) { wbase[threadIdx.x][w] = tot; tot += wsum[threadIdx.x][w]; }
+            const uint32_t b = tot ? atomicAdd(&counts[threadIdx.x], tot) : 0u;
+            for (int w = 0; w < kSplitBlock / 64; w++) wbase[threadIdx.x][w] += b;
         }
-        bs = (uint32_t)__builtin_amdgcn_readfirstlane((int)bs); bl = (uint32_t)__builtin_amdgcn_readfirstlane((int)bl);
+        __syncthreads();
         const uint64_t below = (1ull << lane) - 1ull;
-        if (is_short) short_list[bs + (uint32_t)__popcll(ms & below)] = (uint32_t)q;
-        if (is_long) long_list[bl + (uint32_t)__popcll(ml & below)] = (uint32_t)q;
+        if (is_short) short_list[wbase[0][wave] + (uint32_t)__popcll(ms & below)] = (uint32_t)q;
+        if (is_long) long_list[wbase[1][wave] + (uint32_t)__popcll(ml & below)] = (uint32_t)q;
+        __syncthreads();                                                // (the next round rewrites wsum / wbase)
     }
 }
 

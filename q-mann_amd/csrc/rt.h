@@ -48,6 +48,15 @@ static inline void qm_alloc(T **p, size_t n)
     QM_HIP(hipMalloc((void **)p, (n ? n : 1) * sizeof(T)));
 }
 
+// Calls inside a QmAnswerExact scope take the serial-order float answer kernels (bit-equal to lib/layer_cuda.cu:70-80's loop):
+// the drop-in queue (abi_defer.hip), whose results are promised to be those of the verb-by-verb loop.
+inline thread_local int qm_answer_exact_depth = 0;
+struct QmAnswerExact {
+    QmAnswerExact() { ++qm_answer_exact_depth; }
+    ~QmAnswerExact() { --qm_answer_exact_depth; }
+    QmAnswerExact(const QmAnswerExact &) = delete;
+};
+
 // The library's A/B and tuning switches (INTEGRATION.md lists them) are read from the environment ONCE per process -- on
 // first use, through a thread-safe function-local static -- and then live in this struct: no launch calls getenv(), which
 // is not safe against a setenv() running in another thread of a threaded host (examples/forward_sharded.c is one).
@@ -55,6 +64,7 @@ static inline void qm_alloc(T **p, size_t n)
 // after the first launch; it must not run while another thread launches.
 struct QmTuning {
     bool no_w7, no_mid, no_lean, no_tied, embed_general_epilogue, embed_valu, answer_two_pass;
+    bool answer_exact;                                // QMANN_ANSWER_EXACT: the float answer layer keeps the reference's serial order of additions (no bf16 MFMA form)
     bool no_quad;                                     // QMANN_NO_QUAD: short stories keep the one-wavefront-per-query kernel (hops_quad.h off)
     bool no_tight;                                    // QMANN_NO_TIGHT (set, any value): the lean kernels keep their four-wave (128-register) builds
     int lean_sparse;                                  // -1 = the launcher chooses, 0 / 1 forced

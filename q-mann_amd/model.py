@@ -285,14 +285,17 @@ class QNet:
                   "qmann_hops_packed")
         return (u_out, tobj) if taps else u_out
 
-    def answer(self, u, answer=None, want_probs=False):
+    def answer(self, u, answer=None, want_probs=False, serial=False):
+        """serial=True: qmann_answer_f32_serial (the reference's order of additions, bit-equal logits); default: the library's
+        choice (the fused bf16 form at the bAbI shapes, within 1e-5 on the probabilities)"""
         B = u.shape[0]
         pred = torch.empty(B, dtype=torch.int32, device=self.dev)
         probs = torch.empty((B, self.V), dtype=torch.float32, device=self.dev) if want_probs else None
         cost = torch.zeros(1, dtype=torch.float32, device=self.dev) if answer is not None else None
         match = torch.zeros(1, dtype=torch.int32, device=self.dev) if answer is not None else None
-        abi.check(abi.lib.qmann_answer_f32(C.byref(self.net), _ptr(self.w_ans), _ptr(u), _ptr(answer), _ptr(pred),
-                                           _ptr(probs), _ptr(cost), _ptr(match), B, self._s()), "qmann_answer_f32")
+        fn = abi.lib.qmann_answer_f32_serial if serial else abi.lib.qmann_answer_f32
+        abi.check(fn(C.byref(self.net), _ptr(self.w_ans), _ptr(u), _ptr(answer), _ptr(pred),
+                     _ptr(probs), _ptr(cost), _ptr(match), B, self._s()), "qmann_answer_f32")
         return pred, probs, cost, match
 
     def answer_i8(self, u, w_ans_i8, w_fmt, answer=None, want_probs=False):

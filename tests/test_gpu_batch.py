@@ -50,6 +50,17 @@ ORACLE_SM = {0: 0, 1: 1, 2: 2}       # qmann softmax_base -> the oracle's varian
 E2E_FLOAT_EXCUSED = 2              # the whole forward in mode 1 against the oracle: observed maximum (1 of 64 stories) + 1
 
 
+def check_fused_probs(got, want, logits, what=""):
+    """The FUSED float answer layer (qmann_answer_f32's default at the bAbI shapes: bf16 matrix cores, csrc/batch_io.hip::
+    k_answer_mfma) against the oracle's probabilities `want` of one query.  north_star grants the float softmax 1e-5: absolute
+    1e-5 always; relative 1e-5 (+ 1e-7) -- the criterion of the serial form -- while a unit in the last place of the logits is
+    below 1e-6 (|logit| < 8), scaled up with that unit beyond: two correct float evaluations of sum_c w u differ by units in the
+    last place of the LOGIT, which is a relative error of the probability (at |logit| = 50 one unit is 3.8e-6)."""
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-5, err_msg=f"fused answer layer, absolute {what}")
+    scale = max(1.0, float(np.abs(logits).max()) / 8.0)
+    np.testing.assert_allclose(got, want, rtol=1e-5 * scale, atol=1e-7, err_msg=f"fused answer layer, relative (x{scale:.1f}) {what}")
+
+
 def near_step(p, frac, rel=1e-5):
     """True where the oracle's p sits within `rel` of a Q(.frac) truncation step."""
     x = p.astype(np.float64) * (1 << frac)
@@ -81,7 +92,8 @@ def run_case(env, oracle, cfg, B, S_list, seed, sigma_u=20.0, sigma_k=30.0, sigm
     dv = torch.from_numpy(model.to_signmag(vals)).to(env.dev)
     u_out, taps = net.hops(dk, dv, torch.from_numpy(row_off).to(env.dev), int(n_slots.max()) if B else 0,
                            torch.from_numpy(u0).to(env.dev), taps=True)
-    pred, probs, _, _ = net.answer(u_out, want_probs=True)
+    pred, probs, _, _ = net.answer(u_out, want_probs=True, serial=True)       # the reference's order of additions: strict criteria below
+    pred_fu, probs_fu, _, _ = net.answer(u_out, want_probs=True)              # the library's default (fused at the bAbI shapes)
     # ... and once more WITHOUT taps: that call takes the production kernel of the shape (k_hops_lean up to 64 slots at 64-byte
     # rows, k_hops_mid up to 1 024, the streaming kernels beyond; qmann_hops_i8 chooses), whose final state is compared with
     # the oracle's directly below -- not only through the general kernels the taps route to
@@ -91,6 +103,7 @@ def run_case(env, oracle, cfg, B, S_list, seed, sigma_u=20.0, sigma_k=30.0, sigm
     g_codes = taps.score_codes.cpu().numpy(); g_probs = taps.probs.cpu().numpy()
     g_o = taps.o.cpu().numpy(); g_u = taps.u.cpu().numpy(); g_pred = pred.cpu().numpy()
     g_out_probs = probs.cpu().numpy()
+    g_fused_probs, g_fused_pred = probs_fu.cpu().numpy(), pred_fu.cpu().numpy()
 
     m = oracle.make_model(cfg, wts)
     skipped = 0
@@ -121,9 +134,11 @@ def run_case(env, oracle, cfg, B, S_list, seed, sigma_u=20.0, sigma_k=30.0, sigm
             skipped += 1
             continue
         np.testing.assert_allclose(g_out_probs[q], t["out_probs"], rtol=1e-5, atol=1e-7)
+        check_fused_probs(g_fused_probs[q], t["out_probs"], t["logits"], f"q{q}")
         top2 = np.sort(t["out_probs"])[-2:]
         if top2[1] - top2[0] > 1e-6:
             assert int(g_pred[q]) == opred, f"pred q{q}"
+            assert int(g_fused_pred[q]) == opred, f"pred q{q} (fused answer layer)"
     # observed: 0 in every case of this file (the excuse exists for the float tolerance of the softmax)
     assert skipped <= max_excused, f"{skipped} of {B} queries hit the p-on-a-step exclusion (bound {max_excused})"
     return skipped
@@ -499,12 +514,12 @@ def test_answer_mfma_i8_bit_identical_to_float_path(env, oracle, D, V, B):
     w_i8 = net.quantize_i8(torch.from_numpy(w_float).to(env.dev), w_fmt, abi.CODE_TWOS)
     ans = torch.from_numpy(rng.integers(0, V, B).astype(np.int32)).to(env.dev)
     pred_i, probs_i, cost_i, match_i, logits = net.answer_i8(du, w_i8, w_fmt, answer=ans, want_probs=True)
-    pred_f, probs_f, cost_f, match_f = net.answer(du, answer=ans, want_probs=True)
+    pred_f, probs_f, cost_f, match_f = net.answer(du, answer=ans, want_probs=True, serial=True)
     torch.cuda.synchronize()
     # exact integer matmul as the ground truth for the MFMA lane maps
     want = (u_codes.astype(np.int64) @ w_codes.T.astype(np.int64)).astype(np.float64) / 256.0
     np.testing.assert_array_equal(logits.cpu().numpy().astype(np.float64), want)
-    # and the whole layer equals the float path bit for bit
+    # and the whole layer equals the serial-order float path bit for bit
     np.testing.assert_array_equal(probs_i.cpu().numpy(), probs_f.cpu().numpy())
     np.testing.assert_array_equal(pred_i.cpu().numpy(), pred_f.cpu().numpy())
     assert int(match_i.cpu()) == int(match_f.cpu())
@@ -831,7 +846,7 @@ def test_answer_layer_vs_oracle(env, oracle, V, D, base):
     u[3] = 0.0                                                    # ... and an all-equal row: the highest index wins
     ans = rng.integers(0, V, B).astype(np.int32)
     net = model.QNet(cfg, wts)
-    pred, probs, cost, match = net.answer(torch.from_numpy(u).to(env.dev), torch.from_numpy(ans).to(env.dev), want_probs=True)
+    pred, probs, cost, match = net.answer(torch.from_numpy(u).to(env.dev), torch.from_numpy(ans).to(env.dev), want_probs=True, serial=True)
     torch.cuda.synchronize()
     pred = pred.cpu().numpy(); probs = probs.cpu().numpy()
     want_cost, want_match = 0.0, 0
