@@ -1188,6 +1188,20 @@ k_embed_story_idx(const EmbedIdxArgs a)
 // Grid: x = workgroups over tiles (persistent), y = hop.
 // ---------------------------------------------------------------------------
 constexpr uint32_t kEmRows = 16;                        // story rows per tile
+// LDS images of the two MFMA operands, laid out for ds_read_b128's lane groups.  The hardware serves a wavefront's b128 read in
+// four groups of 16 lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 (MI355X_MICROARCH.md, LDS) -- and a
+// fragment's lane l reads row l & 15, K bytes 16 (l >> 4) .. + 15: every group holds each row 0 .. 15 exactly once, with a K
+// piece that depends on the row.  So a row's pieces must not share banks across K pieces: each (16 rows x 16 bytes) block of
+// one K piece is 256 contiguous bytes, row r at 16 r -- a group's 16 lanes then cover the 64 banks once whatever pieces they
+// read.  (Through round 4 these images were row-major with a 16-byte pad: rows 11 and 12 of adjacent pieces met in every
+// group, SQ_LDS_BANK_CONFLICT was half of the LDS-active cycles and the LDS array was busy 64 % of the kernel.)
+//   T^T: [table][16-column block][K / 16 pieces][16 columns][16 bytes]       em_tt_off(K, table, column, k)
+//   X  : [K / 16 pieces][16 rows][16 bytes]                                   em_x_off(row, k)
+__device__ __forceinline__ uint32_t em_tt_off(uint32_t K, uint32_t t, uint32_t col, uint32_t k)
+{
+    return ((((t * 4u + (col >> 4)) * (K >> 4) + (k >> 4)) * 16u + (col & 15u)) << 4) + (k & 15u);
+}
+__device__ __forceinline__ uint32_t em_x_off(uint32_t row, uint32_t k) { return ((((k >> 4) << 4) + row) << 4) + (k & 15u); }
 constexpr uint32_t kEmDupCap = 128;                     // repeated (row, word) pairs a tile can hold: 16 rows x 16 slots / 2
 
 // wavefronts per SIMD each instantiation is compiled for (its register budget; the launcher sizes the persistent grid by it)
@@ -1201,30 +1215,28 @@ k_embed_story_mfma(const EmbedIdxArgs a)
 {
     constexpr uint32_t kBlockEm = NW * kWave;
     constexpr uint32_t K = 64u * KS;
-    constexpr uint32_t KP = K + 16u;                    // row pitch of T^T and X in LDS: 16 rows 4 banks apart, no conflicts on the fragment loads
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // (readfirstlane: the compiler treats threadIdx.x / 64 as divergent and would keep every per-wavefront address in vector registers)
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid / kWave));
     constexpr uint32_t Dp = 64;                         // bAbI width (wider embeddings take the gather-sum kernel): the product loops
                                                         // unroll, so a tile's fragment loads and MFMAs are in flight together
     const uint32_t h = blockIdx.y, V = a.V, nw = a.max_words;
-    int8_t *tt = (int8_t *)smem;                                         // [2][Dp][KP]: A then C of this hop, transposed
+    int8_t *tt = (int8_t *)smem;                                         // [2][Dp][K]: A then C of this hop, transposed (em_tt_off)
     constexpr uint32_t SP = Dp + 16u;                                    // row pitch of the output staging tile (conflict-free dword writes)
-    uint8_t *ws = smem + 2u * Dp * KP + wave * (kEmRows * KP + kEmRows * SP + kEmDupCap * 4u + 16u);
-    uint32_t *X = (uint32_t *)ws;                                        // [16][KP] bytes
-    uint8_t *stage = ws + kEmRows * KP;                                  // [16][SP] one table's output rows
+    uint8_t *ws = smem + 2u * Dp * K + wave * (kEmRows * K + kEmRows * SP + kEmDupCap * 4u + 16u);
+    uint32_t *X = (uint32_t *)ws;                                        // [16][K] bytes (em_x_off)
+    uint8_t *stage = ws + kEmRows * K;                                   // [16][SP] one table's output rows
     uint32_t *dup = (uint32_t *)(stage + kEmRows * SP);                  // [kEmDupCap] row << 16 | word
     uint32_t *n_dup = dup + kEmDupCap;
 
     // ---- T^T of the hop's two tables ------------------------------------------------------------------------------
     for (uint32_t t = 0; t < 2; t++) {
         const uint32_t *src = (const uint32_t *)(t ? a.t_c[h] : a.t_a[h]);       // [V][Dp] two's complement
-        int8_t *dst = tt + t * Dp * KP;
         for (uint32_t i = tid; i < K * (Dp / 4); i += kBlockEm) {
             const uint32_t k = i / (Dp / 4), c4 = i % (Dp / 4);
             const uint32_t x = k < V ? src[(size_t)k * (Dp / 4) + c4] : 0u;
 #pragma unroll
-            for (uint32_t j = 0; j < 4; j++) dst[(4 * c4 + j) * KP + k] = (int8_t)(x >> (8 * j));
+            for (uint32_t j = 0; j < 4; j++) tt[em_tt_off(K, t, 4 * c4 + j, k)] = (int8_t)(x >> (8 * j));
         }
     }
     __syncthreads();
@@ -1273,13 +1285,15 @@ k_embed_story_mfma(const EmbedIdxArgs a)
     };
     for (size_t tile = (size_t)blockIdx.x * NW + wave; tile < n_tiles; tile += tile_step) {
         const size_t row0 = tile * kEmRows;
+        QM_MARK("X: zero, words of the tile");
         // ---- X: counts per (row, word) -----------------------------------------------------------------------------
-        for (uint32_t i = lane; i < kEmRows * KP / 16u; i += kWave) *(i32x4 *)((uint8_t *)X + i * 16u) = i32x4{0, 0, 0, 0};
+        for (uint32_t i = lane; i < kEmRows * K / 16u; i += kWave) *(i32x4 *)((uint8_t *)X + i * 16u) = i32x4{0, 0, 0, 0};
         if (lane == 0) *n_dup = 0u;
         uint32_t w[4];
         take_words(tile, w);
         request_words(tile + tile_step);
         flush_pending();                                                 // the previous tile's rows (see below)
+        QM_MARK("X: last slot, byte adds, time entry");
         uint32_t last = 0;                                               // 1 + this row's last non-empty slot
 #pragma unroll
         for (uint32_t i = 0; i < 4; i++) last = w[i] != 0xFFFFu ? 4 * qd + i + 1 : last;
@@ -1297,7 +1311,7 @@ k_embed_story_mfma(const EmbedIdxArgs a)
             if (w[i] >= V) continue;                                     // empty (0xFFFF) or out of range: ignored
             if (a.time_last && 4 * qd + i + 1 == last) { time_w = w[i]; continue; }
             const uint32_t sh = 8u * (w[i] & 3u);
-            const uint32_t old = atomicAdd(&X[r4 * (KP / 4) + (w[i] >> 2)], 1u << sh);
+            const uint32_t old = atomicAdd(&X[em_x_off(r4, w[i]) >> 2], 1u << sh);
             if (((old >> sh) & 0xFFu) == 1u) {                           // the second occurrence announces the repeat, once
                 const uint32_t n = atomicAdd(n_dup, 1u);
                 if (n < kEmDupCap) dup[n] = (r4 << 16) | w[i];
@@ -1305,14 +1319,15 @@ k_embed_story_mfma(const EmbedIdxArgs a)
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (time_w != 0xFFFFu) ((uint8_t *)X)[r4 * KP + time_w] = 1;      // the time entry SETS its slot (sample.c:474)
+        if (time_w != 0xFFFFu) ((uint8_t *)X)[em_x_off(r4, time_w)] = 1;  // the time entry SETS its slot (sample.c:474)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+        QM_MARK("B fragments, repeated words");
         i32x4 bx[KS];
 #pragma unroll
-        for (int ks = 0; ks < KS; ks++) bx[ks] = *(const i32x4 *)((const uint8_t *)X + nrow * KP + ks * 64 + kq * 16);
+        for (int ks = 0; ks < KS; ks++) bx[ks] = *(const i32x4 *)((const uint8_t *)X + em_x_off(nrow, ks * 64u + kq * 16u));
 
         // ---- repeated words: does any product Qw(Qw(count) . kw) differ from count . kw?  (it does only when the product
         // leaves the format: |count . kw| > max_w -- rare; lane = column) ------------------------------------------------
@@ -1320,12 +1335,13 @@ k_embed_story_mfma(const EmbedIdxArgs a)
         uint32_t fix_rows = 0;                                           // rows to be summed term by term (wavefront-uniform)
         for (uint32_t d = 0; d < nd; d++) {
             const uint32_t e = dup[d], r = e >> 16, wd = e & 0xFFFFu;
-            const int c = (int)((const uint8_t *)X)[r * KP + wd];
+            const int c = (int)((const uint8_t *)X)[em_x_off(r, wd)];
             const int cc = count_code((uint32_t)c, fw.frac, maxw);
-            const int ka = (int)tt[lane * KP + wd], kc = (int)tt[(Dp + lane) * KP + wd];
+            const int ka = (int)tt[em_tt_off(K, 0, lane, wd)], kc = (int)tt[em_tt_off(K, 1, lane, wd)];
             if (__any(qm_mul_code(cc, ka, fw.frac, maxw) != c * ka || qm_mul_code(cc, kc, fw.frac, maxw) != c * kc)) fix_rows |= 1u << r;
         }
 
+        QM_MARK("products (MFMA)");
         // ---- the products, the epilogue, the stores ---------------------------------------------------------------
         // A lane's 4 columns are one dword; the 16 rows of a tile are contiguous in memory, so the tile leaves through an
         // LDS staging tile as whole rows, 16 bytes per lane (a store of 64 scattered dwords per 16 columns ran at the
@@ -1338,10 +1354,11 @@ k_embed_story_mfma(const EmbedIdxArgs a)
                 acc[t][cb] = i32x4{0, 0, 0, 0};
 #pragma unroll
                 for (int ks = 0; ks < KS; ks++) {
-                    const i32x4 am = *(const i32x4 *)(tt + ((t * Dp + cb * 16u + nrow) * KP + ks * 64 + kq * 16));
+                    const i32x4 am = *(const i32x4 *)(tt + em_tt_off(K, t, cb * 16u + nrow, ks * 64u + kq * 16u));
                     acc[t][cb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(am, bx[ks], acc[t][cb], 0, 0, 0);
                 }
             }
+        QM_MARK("epilogue: quantise, stage, rows back");
 #pragma unroll
         for (uint32_t t = 0; t < 2; t++) {
             const QFmt dstf = t ? f_act : f_att;
@@ -1364,7 +1381,7 @@ k_embed_story_mfma(const EmbedIdxArgs a)
             // words (the non-zero bytes of its X row), lane = column; replaces the row in the staging tile
             for (uint32_t m = fix_rows; m; m &= m - 1) {
                 const uint32_t r = (uint32_t)__builtin_ctz(m);
-                const uint32_t xr = lane < K / 4 ? X[r * (KP / 4) + lane] : 0u;
+                const uint32_t xr = lane < K / 4 ? X[em_x_off(r, 4u * lane) >> 2] : 0u;       // counts of words 4 lane .. 4 lane + 3
                 int sum = 0;
                 for (uint64_t nz = __ballot(xr != 0u); nz; nz &= nz - 1) {
                     const uint32_t j = (uint32_t)__builtin_ctzll(nz);
@@ -1372,7 +1389,7 @@ k_embed_story_mfma(const EmbedIdxArgs a)
 #pragma unroll
                     for (uint32_t b = 0; b < 4; b++) {
                         const uint32_t c = (xv >> (8 * b)) & 0xFFu;
-                        if (c) sum += qm_mul_code(count_code(c, fw.frac, maxw), (int)tt[(t * Dp + lane) * KP + 4 * j + b], fw.frac, maxw);
+                        if (c) sum += qm_mul_code(count_code(c, fw.frac, maxw), (int)tt[em_tt_off(K, t, lane, 4 * j + b)], fw.frac, maxw);
                     }
                 }
                 __builtin_amdgcn_wave_barrier();                         // (every lane's dword of this row is written)
@@ -1388,8 +1405,243 @@ k_embed_story_mfma(const EmbedIdxArgs a)
         pend_row0 = row0;
         pending = true;
         __builtin_amdgcn_wave_barrier();                                 // the next tile rewrites X
+        QM_MARK("end of tile");
     }
     flush_pending();
+}
+
+// ---------------------------------------------------------------------------
+// The same for the joint-task dictionaries (129 .. 256 entries), EVERY HOP of a tile in one workgroup.  With one workgroup per
+// hop (the kernel above) a tile's count matrix X is rebuilt for every hop -- 135 of its 349 vector instructions per tile and hop
+// (tools/stage_budget.py; the kernel's vector and matrix issue together keep a SIMD 75 % busy, profiles/r05_units_j20_*) -- because
+// T^T of three hops (104 KB) and sixteen wavefronts' whole X tiles (70 KB) do not fit one CU's LDS together.  They do once X is
+// built in four CHUNKS of 64 dictionary entries: a chunk is 16 rows x 80 bytes, becomes the wavefront's B fragment of that K
+// step at once (4 registers), and its LDS bytes are reused by the next chunk and, after the products, by the staging tile.
+// Per tile: 4 short build rounds (zero 1.3 KB, byte-add the words of the chunk, set the time entry, read the fragment) for all
+// hops together instead of a 4.3 KB build per hop; then per hop 32 MFMAs, the epilogue and the stores as above.  Hops before
+// the last store their rows at once (younger than the next tile's word request, so the wait for those words does not wait for
+// them); the last hop's rows wait in registers for the start of the next tile, as above.
+// Repeated words: noticed by the byte-add as above, checked per chunk against every hop's tables; a row whose repeated word
+// leaves a hop's weight format is summed term by term from the tile's word list (kept in LDS for that, 512 bytes).
+// ---------------------------------------------------------------------------
+template <int NW>
+__global__ void __launch_bounds__(NW * kWave, 4)
+k_embed_story_mfma_hops(const EmbedIdxArgs a)
+{
+    constexpr uint32_t kBlockEm = NW * kWave;
+    constexpr uint32_t K = 256u, KS = 4u, Dp = 64u;
+    constexpr uint32_t XC = kEmRows * 64u;              // an X chunk: [4 pieces][16 rows][16 bytes] (em_x_off on k & 63)
+    constexpr uint32_t SP = Dp + 16u;                   // row pitch of the staging tile, which follows the two chunks in their bytes
+    constexpr uint32_t kWaveLds = 2u * XC + kEmDupCap * 4u + 16u + kEmRows * 16u * 2u;
+    static_assert(2u * XC >= kEmRows * SP, "the staging tile lies over the two X chunks");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1), wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid / kWave));
+    const uint32_t H = a.n_hop, V = a.V, nw = a.max_words;
+    int8_t *tt = (int8_t *)smem;                                         // [H][2][Dp][K]: A then C of every hop, transposed (em_tt_off)
+    uint8_t *ws = smem + (size_t)H * 2u * Dp * K + wave * kWaveLds;
+    uint8_t *xs = ws;                                                    // two X chunks in turn (one is zeroed while the other is filled); later one table's output rows [16][SP]
+    uint32_t *dup = (uint32_t *)(ws + 2u * XC);                          // [kEmDupCap] row << 16 | word
+    uint32_t *n_dup = dup + kEmDupCap;
+    uint16_t *wl = (uint16_t *)(n_dup + 4);                              // [16][16] the tile's words (the term-by-term path reads them)
+
+    for (uint32_t t = 0; t < 2u * H; t++) {
+        const uint32_t *src = (const uint32_t *)((t & 1u) ? a.t_c[t >> 1] : a.t_a[t >> 1]);      // [V][Dp] two's complement
+        int8_t *dst = tt + (size_t)(t >> 1) * 2u * Dp * K;
+        for (uint32_t i = tid; i < K * (Dp / 4); i += kBlockEm) {
+            const uint32_t k = i / (Dp / 4), c4 = i % (Dp / 4);
+            const uint32_t x = k < V ? src[(size_t)k * (Dp / 4) + c4] : 0u;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) dst[em_tt_off(K, t & 1u, 4 * c4 + j, k)] = (int8_t)(x >> (8 * j));
+        }
+    }
+    __syncthreads();
+
+    const uint32_t r4 = lane >> 2, qd = lane & 3u;                       // word phase: row r4 of the tile, slots 4 qd .. 4 qd + 3
+    const uint32_t nrow = lane & 15u, kq = lane >> 4;                    // matrix phase: story row nrow, K bytes 16 kq .. / columns 4 kq ..
+    const size_t n_tiles = ((size_t)a.rows + kEmRows - 1) / kEmRows;
+    const uint32_t slot0 = 4 * qd < nw ? 4 * qd : 0u;
+    uint2 raw_next = {0u, 0u};
+    auto request_words = [&](size_t tile_) {
+        size_t row = tile_ * kEmRows + r4;
+        row = row < a.rows ? row : a.rows - 1;
+        raw_next = *(const uint2 *)(a.words + row * nw + slot0);
+    };
+    auto take_words = [&](size_t tile_, uint32_t (&w_)[4]) {
+        const bool in = tile_ * kEmRows + r4 < a.rows;
+        w_[0] = raw_next.x & 0xFFFFu; w_[1] = raw_next.x >> 16; w_[2] = raw_next.y & 0xFFFFu; w_[3] = raw_next.y >> 16;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) w_[i] = (in && 4 * qd + i < nw) ? w_[i] : 0xFFFFu;
+    };
+    auto wsync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    const size_t tile_step = (size_t)gridDim.x * NW;
+    request_words((size_t)blockIdx.x * NW + wave);
+    i32x4 pend[2];                                                       // the last hop's rows of the previous tile
+    size_t pend_row0 = 0;
+    bool pending = false;
+    const uint32_t srow = lane / (Dp / 16u), spiece = lane % (Dp / 16u);  // whole rows out: lane i holds piece i % 4 of row i / 4
+    auto store_rows = [&](uint32_t h, size_t row0_, const i32x4 (&rows_)[2]) {
+        if (row0_ + srow < a.rows) {
+            *(i32x4 *)(a.keys + (size_t)h * a.hop_stride + row0_ * Dp + (size_t)lane * 16u) = rows_[0];
+            *(i32x4 *)(a.vals + (size_t)h * a.hop_stride + row0_ * Dp + (size_t)lane * 16u) = rows_[1];
+        }
+    };
+    for (size_t tile = (size_t)blockIdx.x * NW + wave; tile < n_tiles; tile += tile_step) {
+        const size_t row0 = tile * kEmRows;
+        QM_MARK("words of the tile");
+        uint32_t w[4];
+        take_words(tile, w);
+        request_words(tile + tile_step);
+        if (pending) { store_rows(H - 1u, pend_row0, pend); pending = false; }
+        *(uint2 *)(wl + r4 * 16u + 4u * qd) = uint2{w[0] | (w[1] << 16), w[2] | (w[3] << 16)};
+        if (lane == 0) *n_dup = 0u;
+        uint32_t last = 0;                                               // 1 + this row's last non-empty slot
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) last = w[i] != 0xFFFFu ? 4 * qd + i + 1 : last;
+        {   // maximum over the 4 lanes of the row
+            uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)last, 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]
+            last = o > last ? o : last;
+            o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)last, 0x4E, 0xF, 0xF, true);                // quad_perm [2,3,0,1]
+            last = o > last ? o : last;
+        }
+        // The time entry (the row's last non-empty slot, if its word is in range) SETS its byte to 1 (sample.c:474), the other
+        // slots count.  Here the time slot simply adds its 1 and every other slot of the row that holds the same word is dropped:
+        // the same byte, without a separate store (and its wait) behind the adds.
+        uint32_t time_w = 0xFFFFu;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) {
+            if (w[i] >= V) { w[i] = 0xFFFFu; continue; }                 // empty or out of range: ignored
+            if (a.time_last && 4 * qd + i + 1 == last) time_w = w[i];
+        }
+        {   // the row's time word to its four lanes (one of them holds it, the others 0xFFFF: a minimum)
+            uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)time_w, 0xB1, 0xF, 0xF, true);
+            uint32_t tw = o < time_w ? o : time_w;
+            o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tw, 0x4E, 0xF, 0xF, true);
+            tw = o < tw ? o : tw;
+#pragma unroll
+            for (uint32_t i = 0; i < 4; i++)
+                if (w[i] == tw && !(a.time_last && 4 * qd + i + 1 == last)) w[i] = 0xFFFFu;
+        }
+        // ---- X in four chunks of 64 dictionary entries: each becomes the B fragment of its K step ------------------------
+        i32x4 bx[KS];
+        uint32_t fix_rows[QMANN_MAX_HOP] = {};                           // per hop: rows to be summed term by term (wavefront-uniform)
+        uint32_t nd_seen = 0;
+#pragma unroll
+        for (uint32_t ks = 0; ks < KS; ks++) {
+            QM_MARK("X chunk: zero the next, byte adds, fragment");
+            uint8_t *xc = xs + (ks & 1u) * XC, *xn = xs + ((ks + 1u) & 1u) * XC;
+            if (ks == 0) {                                               // (the later chunks were zeroed a round ahead)
+                *(i32x4 *)(xc + lane * 16u) = i32x4{0, 0, 0, 0};
+                wsync();
+            }
+            if (ks + 1u < KS) *(i32x4 *)(xn + lane * 16u) = i32x4{0, 0, 0, 0};
+#pragma unroll
+            for (uint32_t i = 0; i < 4; i++) {
+                if (w[i] == 0xFFFFu || (w[i] >> 6) != ks) continue;
+                const uint32_t sh = 8u * (w[i] & 3u);
+                const uint32_t old = atomicAdd((uint32_t *)(xc + (em_x_off(r4, w[i] & 63u) & ~3u)), 1u << sh);
+                if (((old >> sh) & 0xFFu) == 1u) {                       // the second occurrence announces the repeat, once
+                    const uint32_t n = atomicAdd(n_dup, 1u);
+                    if (n < kEmDupCap) dup[n] = (r4 << 16) | w[i];
+                }
+            }
+            wsync();
+            bx[ks] = *(const i32x4 *)(xc + em_x_off(nrow, kq * 16u));
+            // repeated words of this chunk: does any product Qw(Qw(count) . kw) differ from count . kw in some hop?  (only when the
+            // product leaves the format: rare; lane = column)
+            const uint32_t nd = *n_dup < kEmDupCap ? *n_dup : kEmDupCap;
+            for (uint32_t d = nd_seen; d < nd; d++) {
+                const uint32_t e = dup[d], r = e >> 16, wd = e & 0xFFFFu;
+                const int c = (int)xc[em_x_off(r, wd & 63u)];
+                for (uint32_t h = 0; h < H; h++) {
+                    const QFmt fw = a.w[h];
+                    const int maxw = (1 << (fw.iwl + fw.frac)) - 1;
+                    const int cc = count_code((uint32_t)c, fw.frac, maxw);
+                    const int8_t *th = tt + (size_t)h * 2u * Dp * K;
+                    const int ka = (int)th[em_tt_off(K, 0, lane, wd)], kc = (int)th[em_tt_off(K, 1, lane, wd)];
+                    if (__any(qm_mul_code(cc, ka, fw.frac, maxw) != c * ka || qm_mul_code(cc, kc, fw.frac, maxw) != c * kc)) fix_rows[h] |= 1u << r;
+                }
+            }
+            nd_seen = nd;
+        }
+        wsync();                                                         // the staging tile rewrites chunk bytes
+        // ---- per hop: the products, the epilogue, the stores ---------------------------------------------------------------
+        for (uint32_t h = 0; h < H; h++) {
+            QM_MARK("products (MFMA)");
+            const int8_t *th = tt + (size_t)h * 2u * Dp * K;
+            const QFmt fw = a.w[h], f_att = a.att[h], f_act = a.act[h];
+            const bool kmz = (a.key_mz >> h) & 1u;
+            const int maxw = (1 << (fw.iwl + fw.frac)) - 1;
+            i32x4 acc[2][4];
+#pragma unroll
+            for (uint32_t t = 0; t < 2; t++)
+#pragma unroll
+                for (uint32_t cb = 0; cb < 4; cb++) {
+                    acc[t][cb] = i32x4{0, 0, 0, 0};
+#pragma unroll
+                    for (uint32_t ks = 0; ks < KS; ks++) {
+                        const i32x4 am = *(const i32x4 *)(th + em_tt_off(K, t, cb * 16u + nrow, ks * 64u + kq * 16u));
+                        acc[t][cb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(am, bx[ks], acc[t][cb], 0, 0, 0);
+                    }
+                }
+            QM_MARK("epilogue: quantise, stage, rows back");
+            i32x4 rows[2];
+#pragma unroll
+            for (uint32_t t = 0; t < 2; t++) {
+                const QFmt dstf = t ? f_act : f_att;
+                const uint32_t qk = (a.qkinds >> (4u * h + 2u * t)) & 3u;    // (workgroup-uniform)
+#pragma unroll
+                for (uint32_t cb = 0; cb < 4; cb++) {
+                    const i32x4 v = acc[t][cb];                              // v[r]: story row nrow, column 16 cb + 4 kq + r
+                    const s16x2 x01 = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm((uint32_t)v[1], (uint32_t)v[0], 0x05040100u));
+                    const s16x2 x23 = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm((uint32_t)v[3], (uint32_t)v[2], 0x05040100u));
+                    uint32_t out;
+                    if (qk != kQkGeneral) {
+                        out = ew_to_bytes4(x01, x23, maxw, qk);
+                    } else {
+                        const uint32_t b01 = ew_to_bytes(x01, maxw, fw, dstf, t == 0 && kmz), b23 = ew_to_bytes(x23, maxw, fw, dstf, t == 0 && kmz);
+                        out = __builtin_amdgcn_perm(b23, b01, 0x06040200u);
+                    }
+                    *(uint32_t *)(xs + nrow * SP + cb * 16u + kq * 4u) = out;
+                }
+                // a row whose repeated word leaves the format: its sums term by term, Qw(Qw(count) . kw) over the row's distinct
+                // words (from the tile's word list; the time slot sets its word's count to 1), lane = column
+                for (uint32_t m = fix_rows[h]; m; m &= m - 1) {
+                    const uint32_t r = (uint32_t)__builtin_ctz(m);
+                    uint32_t last_r = 0;
+                    for (uint32_t j = 0; j < nw; j++) last_r = wl[r * 16u + j] != 0xFFFFu ? j + 1u : last_r;
+                    int sum = 0;
+                    for (uint32_t j = 0; j < nw; j++) {
+                        const uint32_t wj = wl[r * 16u + j];
+                        if (wj >= V) continue;
+                        bool first = true, timed = false;
+                        uint32_t cnt = 0;
+                        for (uint32_t k = 0; k < nw; k++) {
+                            if (wl[r * 16u + k] != wj) continue;
+                            first = first && k >= j;
+                            if (a.time_last && k + 1u == last_r) timed = true; else cnt++;
+                        }
+                        if (!first) continue;
+                        if (timed) cnt = 1;
+                        sum += qm_mul_code(count_code(cnt, fw.frac, maxw), (int)th[em_tt_off(K, t, lane, wj)], fw.frac, maxw);
+                    }
+                    __builtin_amdgcn_wave_barrier();                     // (every lane's dword of this row is written)
+                    xs[r * SP + lane] = (uint8_t)ew_to_bytes(s16x2{(short)sum, (short)0}, maxw, fw, dstf, t == 0 && kmz);
+                }
+                wsync();
+                rows[t] = *(const i32x4 *)(xs + srow * SP + spiece * 16u);
+                __builtin_amdgcn_wave_barrier();                         // the second table reuses the staging tile
+            }
+            if (h + 1u < H) store_rows(h, row0, rows);
+            else { pend[0] = rows[0]; pend[1] = rows[1]; pend_row0 = row0; pending = true; }
+        }
+        __builtin_amdgcn_wave_barrier();                                 // the next tile rewrites the chunk bytes and the word list
+        QM_MARK("end of tile");
+    }
+    if (pending) store_rows(H - 1u, pend_row0, pend);
 }
 
 // question: word entries only (no time entry, sample.c:557-565); u0[j] = Qw0(sum_k Qw0(Qw0(W[j][k]) . Qw0(c_k))),
@@ -1798,17 +2050,29 @@ int qmann_embed_story_idx(const qmann_net *net, const uint16_t *words, uint32_t 
     for (uint32_t h = 0; h < net->n_hop; h++) mfma_ok = mfma_ok && net->w[h].iwl >= 1;
     if (mfma_ok) {
         const uint32_t K = net->dim_input <= 64 ? 64u : (net->dim_input <= 128 ? 128u : 256u), Dp = net->dim_emb_pad;
-        // T^T (2 x 64 x (K + 16) bytes) is per workgroup: large dictionaries share it among 16 wavefronts
-        const uint32_t nwv = K == 64 ? 8u : 16u;
-        const size_t lds = 2u * (size_t)Dp * (K + 16u) + (size_t)nwv * (kEmRows * (K + 16u) + kEmRows * (Dp + 16u) + kEmDupCap * 4u + 16u);
+        hipStream_t st = (hipStream_t)stream;
         const size_t tiles = ((size_t)rows_total + kEmRows - 1) / kEmRows;
+        // joint-task dictionaries, several hops: every hop of a tile in one workgroup, X built once per tile in chunks
+        // (k_embed_story_mfma_hops); QMANN_EMBED_PER_HOP keeps a workgroup per hop (A/B)
+        if (K == 256u && net->n_hop >= 2u && net->n_hop <= 3u && !qm_tuning().embed_per_hop) {
+            constexpr uint32_t nwh = 16u;
+            const size_t lds = (size_t)net->n_hop * 2u * Dp * K + (size_t)nwh * (2u * kEmRows * 64u + kEmDupCap * 4u + 16u + kEmRows * 32u);
+            const uint32_t resident = qm_resident_groups(nwh, 4u, lds);
+            const uint32_t nx = (uint32_t)((tiles + nwh - 1) / nwh < resident ? (tiles + nwh - 1) / nwh : resident);
+            QM_HIP(hipFuncSetAttribute((const void *)k_embed_story_mfma_hops<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            k_embed_story_mfma_hops<16><<<nx, nwh * kWave, lds, st>>>(a);
+            QM_LAUNCH_CHECK();
+            return qm_scope.rc();
+        }
+        // T^T (2 x 64 x K bytes) is per workgroup: large dictionaries share it among 16 wavefronts
+        const uint32_t nwv = K == 64 ? 8u : 16u;
+        const size_t lds = 2u * (size_t)Dp * K + (size_t)nwv * (kEmRows * K + kEmRows * (Dp + 16u) + kEmDupCap * 4u + 16u);
         // persistent in x: never more workgroups than are resident at once (rt.h: through round 3 the cap was LDS-only and
         // rounded UP -- 86 x 3 = 258 workgroups for 256 one-per-CU slots on the joint dictionaries, 1 026 for 512 on task 1)
         const uint32_t resident = qm_resident_groups(nwv, (uint32_t)em_waves_per_simd(K == 64 ? 1 : (K == 128 ? 2 : 4)), lds);
         const uint32_t cap = resident / net->n_hop ? resident / net->n_hop : 1u;
         const uint32_t nx = (uint32_t)((tiles + nwv - 1) / nwv < cap ? (tiles + nwv - 1) / nwv : cap);
         const dim3 grid(nx, net->n_hop);
-        hipStream_t st = (hipStream_t)stream;
 #define QM_EM_GO(KS_, NW_)                                                                                                       \
         do {                                                                                                                     \
             if (lds > 48 * 1024) QM_HIP(hipFuncSetAttribute((const void *)k_embed_story_mfma<KS_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \

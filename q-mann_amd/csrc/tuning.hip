@@ -22,6 +22,7 @@ void read_env(QmTuning &t)
     t.no_tied = on("QMANN_NO_TIED");
     t.embed_general_epilogue = on("QMANN_EMBED_GENERAL_EPILOGUE");
     t.embed_valu = on("QMANN_EMBED_VALU");
+    t.embed_per_hop = on("QMANN_EMBED_PER_HOP");
     t.answer_two_pass = on("QMANN_ANSWER_TWO_PASS");
     t.lean_sparse = tri("QMANN_LEAN_SPARSE");
     t.no_tight = on("QMANN_NO_TIGHT");              // presence-only, like its siblings
