@@ -246,6 +246,7 @@ __device__ __forceinline__ void lean_finish_hop(const HopArgs &a, uint32_t h, ui
         return acc;
     };
 
+    QM_MARK("linear map + hop update");
     // ---- linear map + hop update ---------------------------------------------------------------------
     if (a.en_lin_map) {
         if (!reuse) {
@@ -307,6 +308,7 @@ __device__ __forceinline__ void lean_hop(const HopArgs &a, const LeanArgs &la, u
     const QFmt fa = a.act[h], fm = a.att[h], fb = a.bin, fw = a.w[h];
     const int maxa = W7 ? 127 : (1 << (fa.iwl + fa.frac)) - 1;
     const bool relu = hop_relu(a, h);
+    QM_MARK("operand codes + publish");
     // ---- column c: operand codes -----------------------------------------------------------------
     const int kb_code = (lane < D) ? qm_code_or_sign(u, fb.iwl, fb.frac) : 0;        // Q_bin(u): linear map (and fixed scores)
     const uint32_t wl_m = (W7 && MODE == kModeFixed) ? 7u : fm.iwl + fm.frac, wl_w = W7 ? 7u : fw.iwl + fw.frac;
@@ -320,6 +322,7 @@ __device__ __forceinline__ void lean_hop(const HopArgs &a, const LeanArgs &la, u
     }
     wave_sync();
 
+    QM_MARK("scan");
     // ---- scores ------------------------------------------------------------------------------------
     ScanConst csc;
     uint32_t csh = 0;
@@ -365,6 +368,7 @@ __device__ __forceinline__ void lean_hop(const HopArgs &a, const LeanArgs &la, u
     }
     wave_sync();
 
+    QM_MARK("softmax + weight codes");
     // ---- softmax over slots, slot r in lane r ------------------------------------------------------
     const bool live = lane < S;
     const int code = live ? (int)*(const int16_t *)(lw + kLwSc + lane * 2) : 0;
@@ -384,6 +388,7 @@ __device__ __forceinline__ void lean_hop(const HopArgs &a, const LeanArgs &la, u
     // Q(p) for 0 <= p <= 1: trunc(p . 2^frac), saturated (qm_code without the cases a probability cannot reach)
     int kp = lean_weight_code(e, total, live, smc, fa, maxa);
 
+    QM_MARK("survivors, read-out, key prefetch");
     // ---- read-out over the rows whose weight code is non-zero (lane c owns column c) -----------------
     uint64_t m = __ballot(kp != 0);
     int rr[4], kk[4];
@@ -533,6 +538,7 @@ k_hops_lean(const HopArgs a, const LeanArgs la)
                 if (!more && qin < n_query) u_next = (lane < D) ? a.u0[(size_t)qn * D + lane] : 0.0f;
             }, vg, kt);
         }
+        QM_MARK("end of query");
         if (lane < D) a.u_out[q * D + lane] = relu_if(u, a.en_non_lin != 0);
         r0 = r0n; S = Sn; q = qn;
     }
@@ -595,16 +601,22 @@ inline void launch_lean_all(const HopArgs &a, uint32_t max_slots, uint32_t n_que
 template <int MODE, int NB>
 inline void launch_lean(const HopArgs &a, uint32_t max_slots, uint32_t n_query, hipStream_t st)
 {
-    // A batch is split only where short stories can be many: mean length (known from the plane size; tied hops carry none and
-    // take the bAbI guess, stories short next to their cap) within the quad kernel's 16 rows.  The |mem| = 50 shape stays whole
-    // on the six-wave lean build.
-    const uint32_t mean_slots = (a.rows_total && n_query) ? a.rows_total / n_query : max_slots / 8u;
-    if (!quad_supported(a, MODE, max_slots, n_query) || (max_slots > kQuadSlots && mean_slots > kQuadSlots)) {
-        launch_lean_all<MODE, NB>(a, max_slots, n_query, st);
+    if (!quad_supported(a, MODE, max_slots, n_query)) { launch_lean_all<MODE, NB>(a, max_slots, n_query, st); return; }
+    if (max_slots <= kQuadSlots) {
+        launch_quad<MODE, NB, 1>(a, QuadArgs{nullptr, nullptr, n_query}, n_query, st);
         return;
     }
-    if (max_slots <= kQuadSlots) {
-        launch_quad<MODE, NB>(a, QuadArgs{nullptr, nullptr, n_query}, n_query, st);
+    // A batch is split only where short stories can be many: mean length (known from the plane size; tied hops carry none and
+    // take the bAbI guess, stories short next to their cap) within the short form's 16 rows.  A batch of long stories -- the
+    // |mem| = 50 shape of BASELINE's metric -- goes whole through the four-chunk form (QMANN_NO_QUAD_LONG: the lean kernel).
+    const uint32_t mean_slots = (a.rows_total && n_query) ? a.rows_total / n_query : max_slots / 8u;
+    if (mean_slots > kQuadSlots) {
+        // (fixed-point scores only: the form is 2 % ahead of the lean kernel at 50 rows -- 7 % fewer vector instructions per query,
+        // four wavefronts per SIMD against six -- which does not pay for ten more instantiations in the Hamming modes)
+        if constexpr (MODE == kModeFixed) {
+            if (!qm_tuning().no_quad_long) { launch_quad<MODE, NB, 4>(a, QuadArgs{nullptr, nullptr, n_query}, n_query, st); return; }
+        }
+        launch_lean_all<MODE, NB>(a, max_slots, n_query, st);
         return;
     }
     // [0] short count, [1] long count, then the two lists
@@ -613,7 +625,8 @@ inline void launch_lean(const HopArgs &a, uint32_t max_slots, uint32_t n_query, 
     QM_HIP(hipMemsetAsync(ws, 0, 2 * sizeof(uint32_t), st));
     const uint32_t blocks = (n_query + kSplitBlock - 1u) / kSplitBlock;
     k_split_by_length<<<blocks < 1024u ? blocks : 1024u, kSplitBlock, 0, st>>>(a.row_off, n_query, max_slots, ws, ws + 2, ws + 2 + n_query);
-    launch_quad<MODE, NB>(a, QuadArgs{ws + 2, ws, n_query}, n_query, st);
+    launch_quad<MODE, NB, 1>(a, QuadArgs{ws + 2, ws, n_query}, n_query, st);
+    // (the few long stories of such a batch: the lean kernel -- the four-chunk quad form measured 3 % SLOWER on the joint forward)
     launch_lean_all<MODE, NB>(a, max_slots, n_query, st, ws + 2 + n_query, ws + 1);
 }
 

@@ -26,6 +26,7 @@ namespace {
 constexpr int kQuadWaves = 8;                       // wavefronts per workgroup: 32 queries in flight
 constexpr int kQuadBlock = kQuadWaves * kWave;
 constexpr int kQuadWps = 6;                         // wavefronts per SIMD the kernel is compiled for (80 registers): three workgroups per CU
+constexpr int kQuadWpsLong = 4;                     // ... the form for stories of up to 64 rows (two key register sets, four scores per lane): 128 registers
 constexpr uint32_t kQuadSlots = 16;                 // rows per story
 constexpr uint32_t kQwBytes = 256;                  // a query's constant images: kLwE, kLwO, kLwS, kLwUb of hops_lean.h
 constexpr uint32_t kOobOffset = 0x80000000u;        // a buffer offset no plane reaches (planes are bounded to 2 GiB here): reads zeros
@@ -37,6 +38,12 @@ struct QuadArgs {
 };
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+// a story's survivor mask: 16 bits per slot set
+template <int NC> struct QuadMask { typedef uint64_t type; };
+template <> struct QuadMask<1> { typedef uint32_t type; };
+__device__ __forceinline__ uint32_t quad_ctz(uint32_t m) { return (uint32_t)__builtin_ctz(m); }
+__device__ __forceinline__ uint32_t quad_ctz(uint64_t m) { return (uint32_t)__builtin_ctzll(m); }
 
 // butterflies over the 16 lanes of a DPP row (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror): every lane
 // ends with the row's result
@@ -102,11 +109,15 @@ __device__ __forceinline__ uint32_t quad_ubyte(float ua, QFmt fm, bool real)
     return real ? (mag | (!(ua >= 0.0f) ? 0x80u : 0u)) : 0u;
 }
 
-template <int MODE, int NB, int WPS>
+// NC: chunks of 16 rows a story may have -- 1: the short stories (every row of a hop in 16 key registers, requested a hop ahead);
+// 4: up to 64 rows (the |mem| = 50 cap of BASELINE's metric): the key chunks alternate between two register sets, the next one
+// requested before the current one is scored; a lane keeps NC scores (slot 16k + 4 (lane & 3) + ((lane >> 2) & 3) in set k)
+template <int MODE, int NB, int WPS, int NC>
 __global__ void __launch_bounds__(kQuadBlock, WPS)
 k_hops_quad(const HopArgs a, const LeanArgs la, const QuadArgs qa)
 {
     constexpr uint32_t Dp = 64;
+    constexpr uint32_t kSlots = kQuadSlots * NC;
     constexpr bool W7 = true;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1);
@@ -121,7 +132,7 @@ k_hops_quad(const HopArgs a, const LeanArgs la, const QuadArgs qa)
 
     const uint32_t n_items = qa.n_list ? *qa.n_list : qa.n_items;
     const uint32_t stride = gridDim.x * kQuadWaves * 4u;
-    const uint32_t cap = a.max_slots < kQuadSlots ? a.max_slots : kQuadSlots;
+    const uint32_t cap = a.max_slots < kSlots ? a.max_slots : kSlots;
     uint32_t i0 = (blockIdx.x * kQuadWaves + wave) * 4u;
     if (i0 >= n_items) return;
     // this lane's query of the quad that starts at item i: its index, first row and length (0 rows for a missing query)
@@ -137,19 +148,20 @@ k_hops_quad(const HopArgs a, const LeanArgs la, const QuadArgs qa)
     };
     uint32_t q, r0, S;
     item_of(i0, q, r0, S);
-    i32x4 kq[4];
-    // keys of hop h for the four stories (r0_, S_ per lane): row 4j + sub4 of the lane's story, 16 bytes per lane.  One raw
-    // buffer resource spans the hop's whole key plane (wavefront-uniform, as a buffer load needs it); a row the story does not
-    // have is asked at an offset beyond every plane and reads as zeros without touching memory.
-    auto load_keys_of = [&](uint32_t h, uint32_t r0_, uint32_t S_) {
+    i32x4 kq[NC > 1 ? 2 : 1][4];
+    // keys of hop h for the four stories (r0_, S_ per lane), chunk c_ of 16 rows: row 16 c_ + 4j + sub4 of the lane's story, 16
+    // bytes per lane.  One raw buffer resource spans the hop's whole key plane (wavefront-uniform, as a buffer load needs it); a
+    // row the story does not have is asked at an offset beyond every plane and reads as zeros without touching memory.
+    auto load_chunk = [&](i32x4 (&k_)[4], uint32_t h, uint32_t r0_, uint32_t S_, uint32_t c_) {
         const uint8_t *k0 = (const uint8_t *)a.keys + (size_t)h * a.key_hop_stride;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)k0, 0, (int)0x7FFFFFFF, kRawBufferFlags);
-        const uint32_t base = (r0_ + sub4) * Dp + chunk * 16u;
+        const uint32_t row = c_ * 16u + sub4, base = (r0_ + row) * Dp + chunk * 16u;
 #pragma unroll
         for (int j = 0; j < 4; j++)
-            kq[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((uint32_t)j * 4u + sub4 < S_ ? base + (uint32_t)j * 4u * Dp : kOobOffset), 0, kBufferNt);
+            k_[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(row + (uint32_t)j * 4u < S_ ? base + (uint32_t)j * 4u * Dp : kOobOffset), 0, kBufferNt);
         __builtin_amdgcn_sched_barrier(0);
     };
+    auto load_keys_of = [&](uint32_t h, uint32_t r0_, uint32_t S_) { load_chunk(kq[0], h, r0_, S_, 0u); };
     load_keys_of(0, r0, S);
     const QFmt fb = a.bin;
     for (; i0 < n_items; i0 += stride) {
@@ -165,8 +177,10 @@ k_hops_quad(const HopArgs a, const LeanArgs la, const QuadArgs qa)
             const uint32_t m01 = s0 > s1 ? s0 : s1, m23 = s2 > s3 ? s2 : s3;
             maxS = m01 > m23 ? m01 : m23;
         }
-        const uint32_t slot = 4u * chunk + sub4;                        // the slot whose score this lane keeps
-        const bool live = slot < S;
+        const uint32_t slot0 = 4u * chunk + sub4;                       // the slots whose scores this lane keeps: 16 k + slot0
+        bool live[NC];
+#pragma unroll
+        for (int k = 0; k < NC; k++) live[k] = 16u * k + slot0 < S;
         for (uint32_t h = 0; h < H; h++) {
             const QFmt fa = a.act[h], fm = a.att[h], fw = a.w[h];
             const int maxa = 127;
@@ -206,57 +220,99 @@ k_hops_quad(const HopArgs a, const LeanArgs la, const QuadArgs qa)
             ScanConst csc;
             uint32_t csh = 0;
             float unit = 1.0f;
+            int code[NC];
             auto scan = [&](auto lane_sum, int lim, bool wrap) {
-                int code = 0;
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    if ((uint32_t)j * 4u < maxS) {                      // wavefront-uniform
-                        const int v = row_lanes_sum<4>(lane_sum(kq[j]));
-                        const int c = v > lim ? lim : (v < -lim ? -lim : ((wrap && v == -lim) ? 0 : v));
-                        code = chunk == (uint32_t)j ? c : code;
+                for (int k = 0; k < NC; k++) {
+                    code[k] = 0;
+                    if (16u * k < maxS) {                               // wavefront-uniform
+                        // (NC > 1) the next chunk's keys into the other register set before this chunk is scored
+                        if (NC > 1 && k + 1 < NC && 16u * (k + 1) < maxS) load_chunk(kq[(k + 1) & 1], h, r0, S, (uint32_t)(k + 1));
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            if (16u * k + (uint32_t)j * 4u < maxS) {    // wavefront-uniform
+                                const int v = row_lanes_sum<4>(lane_sum(kq[k & 1][j]));
+                                const int c = v > lim ? lim : (v < -lim ? -lim : ((wrap && v == -lim) ? 0 : v));
+                                code[k] = chunk == (uint32_t)j ? c : code[k];
+                            }
+                        }
                     }
                 }
-                return code;
             };
-            int code;
             if (MODE == kModeFixed) {
                 unit = qm_scale_down(1.0f, fm.frac);
                 csh = fetch_scan_const(csc, lw, chunk, 7u);
-                code = scan([&](const i32x4 x) { return lane_row_sum7(x, csc); }, 127, false);
+                scan([&](const i32x4 x) { return lane_row_sum7(x, csc); }, 127, false);
             } else if (mode_is_appx(MODE)) {
                 unit = 1.0f / 1024.0f;
                 AppxConst c;
                 make_appx_const(c, lw + kLwUb, chunk * 16, D);
                 const int lim = 1 << (fm.iwl + 10);
                 const uint32_t kind = MODE == kModeAppxMq ? ham_kind_of(a, h) : (uint32_t)kHamSame;             // (wavefront-uniform)
-                if (kind == kHamFine) code = scan([&](const i32x4 x) { return appx_lane_sum_k<kHamFine>(x, c); }, lim, true);
-                else if (kind == kHamCoarse) code = scan([&](const i32x4 x) { return appx_lane_sum_k<kHamCoarse>(x, c); }, lim, true);
-                else code = scan([&](const i32x4 x) { return appx_lane_sum(x, c); }, lim, true);
+                if (kind == kHamFine) scan([&](const i32x4 x) { return appx_lane_sum_k<kHamFine>(x, c); }, lim, true);
+                else if (kind == kHamCoarse) scan([&](const i32x4 x) { return appx_lane_sum_k<kHamCoarse>(x, c); }, lim, true);
+                else scan([&](const i32x4 x) { return appx_lane_sum(x, c); }, lim, true);
             } else {
                 if (MODE == kModeV1Bytes) unit = qm_scale_down(1.0f, NB);
                 HamByteConst c;
                 make_hambyte_const<MODE, NB>(c, lw + kLwUb, chunk * 16, D);
-                code = scan([&](const i32x4 x) { return hambyte_lane_sum<MODE, NB>(x, c); }, 32767, false);
+                scan([&](const i32x4 x) { return hambyte_lane_sum<MODE, NB>(x, c); }, 32767, false);
             }
 
             QM_MARK("softmax + weight codes");
             // ---- softmax over the slots of each story: one DPP row per story -------------------------------------------
             const SmCfg smc = sm_cfg(a, h);
-            float e;
+            float e[NC];
             if (MODE == kModeFixed && la.exp_table) {
-                const int mxc = quad_row_max_i32(live ? code : -32768);
-                e = live ? etab[h * 256u + (uint32_t)(mxc - code)] : 0.0f;
+                int mxc = -32768;
+#pragma unroll
+                for (int k = 0; k < NC; k++) mxc = (live[k] && code[k] > mxc) ? code[k] : mxc;
+                mxc = quad_row_max_i32(mxc);
+#pragma unroll
+                for (int k = 0; k < NC; k++) e[k] = live[k] ? etab[h * 256u + (uint32_t)(mxc - code[k])] : 0.0f;
             } else {
-                const float xs = live ? sm_scaled((float)code * unit, smc) : -INFINITY;
-                const float mx = quad_row_max_f32(xs);
-                e = live ? sm_exp(xs - mx, smc) : 0.0f;
+                float xs[NC], mx = -INFINITY;
+#pragma unroll
+                for (int k = 0; k < NC; k++) { xs[k] = live[k] ? sm_scaled((float)code[k] * unit, smc) : -INFINITY; mx = fmaxf(mx, xs[k]); }
+                mx = quad_row_max_f32(mx);
+#pragma unroll
+                for (int k = 0; k < NC; k++) e[k] = live[k] ? sm_exp(xs[k] - mx, smc) : 0.0f;
             }
-            const double total = quad_row_sum_f64((double)e);           // the CUDA kernel's double total (lib/layer_cuda.cu:2024-2042)
-            const int kp = lean_weight_code(e, total, live, smc, fa, maxa);
+            double tsum = 0.0;
+#pragma unroll
+            for (int k = 0; k < NC; k++) tsum += (double)e[k];
+            const double total = quad_row_sum_f64(tsum);                // the CUDA kernel's double total (lib/layer_cuda.cu:2024-2042)
+            // weight codes Q(p) of the lane's NC slots, a byte each (lean_weight_code's arithmetic: the quotient's side of the
+            // truncation steps from e . 2^frac . rcp(total), the exact double division only when some lane sits within 2^-11 of a step)
+            uint32_t kp4 = 0;
+            {
+                const float r2 = __builtin_ldexpf(__builtin_amdgcn_rcpf((float)total), (int)fa.frac);
+                float x[NC];
+                bool near = false;
+#pragma unroll
+                for (int k = 0; k < NC; k++) {
+                    x[k] = live[k] ? e[k] * r2 : 0.0f;
+                    const float xr = __builtin_rintf(x[k]);
+                    near = near || (xr >= 1.0f && __builtin_fabsf(x[k] - xr) <= 4.8828125e-04f);
+                }
+                if (__builtin_expect(__ballot(near) != 0, 0)) {
+#pragma unroll
+                    for (int k = 0; k < NC; k++) x[k] = __builtin_ldexpf(live[k] ? (float)((double)e[k] / total) : 0.0f, (int)fa.frac);
+                }
+#pragma unroll
+                for (int k = 0; k < NC; k++) {
+                    const int kc = (int)x[k];
+                    kp4 |= (uint32_t)(kc > maxa ? maxa : kc) << (8 * k);
+                }
+            }
 
             QM_MARK("survivors: pick, fetch");
             // ---- survivors of Q(p): up to four per round, their value dwords requested at once -------------------------
-            uint32_t m16 = (uint32_t)(__ballot(kp != 0) >> (16u * g)) & 0xFFFFu;      // this story's survivors, by lane of the row
+            // this story's survivors: bit 16 k + (lane of the row) for slot set k
+            typedef typename QuadMask<NC>::type mask_t;
+            mask_t m16 = 0;
+#pragma unroll
+            for (int k = 0; k < NC; k++) m16 |= (mask_t)((uint32_t)(__ballot(((kp4 >> (8 * k)) & 0xFFu) != 0u) >> (16u * g)) & 0xFFFFu) << (16 * k);
             const uint8_t *v0 = (const uint8_t *)a.vals + (size_t)h * a.hop_stride;
             const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)v0, 0, (int)0x7FFFFFFF, kRawBufferFlags);
             uint32_t kk4, bb[4];                                        // kk4: the four weight codes, a byte each
@@ -265,11 +321,11 @@ k_hops_quad(const HopArgs a, const LeanArgs la, const QuadArgs qa)
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const bool has = m16 != 0u;
-                    const uint32_t pos = has ? (uint32_t)__builtin_ctz(m16) : 0u;
-                    m16 &= m16 - 1u;                                    // (0 stays 0)
-                    const int w = __builtin_amdgcn_ds_bpermute((int)(((lane & 48u) | pos) << 2), kp);
-                    kk4 |= (has ? (uint32_t)w : 0u) << (8 * i);
-                    const uint32_t r = ((pos & 3u) << 2) | (pos >> 2);  // the slot that lane `pos` of the row keeps
+                    const uint32_t bit = has ? quad_ctz(m16) : 0u, pos = bit & 15u, set = bit >> 4;
+                    m16 &= m16 - (mask_t)1;                             // (0 stays 0)
+                    const uint32_t w = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((lane & 48u) | pos) << 2), (int)kp4);
+                    kk4 |= (has ? (w >> (8u * set)) & 0xFFu : 0u) << (8 * i);
+                    const uint32_t r = (set << 4) | ((pos & 3u) << 2) | (pos >> 2);       // the slot that lane `pos` of the row keeps in that set
                     bb[i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rv, (int)(has ? (r0 + r) * Dp + l * 4u : kOobOffset), 0, 0);
                 }
             };
@@ -404,7 +460,7 @@ inline bool quad_supported(const HopArgs &a, int mode, uint32_t max_slots, uint3
     return (uint64_t)n_query * (max_slots ? max_slots : 1u) * 64u < 0x7FFF0000ull;
 }
 
-template <int MODE, int NB>
+template <int MODE, int NB, int NC>
 inline void launch_quad(HopArgs a, const QuadArgs &qa, uint32_t n_max, hipStream_t st)
 {
     LeanArgs la{};
@@ -413,12 +469,11 @@ inline void launch_quad(HopArgs a, const QuadArgs &qa, uint32_t n_max, hipStream
     la.lm_in_lds = a.en_lin_map ? 1u : 0u;
     const size_t lds = (la.exp_table ? a.n_hop * 1024u : 0u) + (la.lm_in_lds ? a.n_hop * kLmHopBytes : 0u) + (size_t)kQuadWaves * 4u * kQwBytes;
     const uint32_t need = (n_max + kQuadWaves * 4u - 1u) / (kQuadWaves * 4u);
-    auto go = [&](auto kernel, int wps) {
-        if (lds > kLdsDefaultLimit) QM_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        const uint32_t resident = qm_resident_groups(kQuadWaves, (unsigned)wps, lds);
-        kernel<<<need < resident ? need : resident, kQuadBlock, lds, st>>>(a, la, qa);
-    };
-    go(k_hops_quad<MODE, NB, kQuadWps>, kQuadWps);
+    constexpr int wps = NC == 1 ? kQuadWps : kQuadWpsLong;
+    auto kernel = k_hops_quad<MODE, NB, wps, NC>;
+    if (lds > kLdsDefaultLimit) QM_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const uint32_t resident = qm_resident_groups(kQuadWaves, (unsigned)wps, lds);
+    kernel<<<need < resident ? need : resident, kQuadBlock, lds, st>>>(a, la, qa);
 }
 
 }  // namespace

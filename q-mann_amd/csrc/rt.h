@@ -66,6 +66,7 @@ struct QmTuning {
     bool no_w7, no_mid, no_lean, no_tied, embed_general_epilogue, embed_valu, answer_two_pass;
     bool embed_per_hop;                               // QMANN_EMBED_PER_HOP: the joint-dictionary story embedding keeps one workgroup per hop (k_embed_story_mfma<4, 16>)
     bool answer_exact;                                // QMANN_ANSWER_EXACT: the float answer layer keeps the reference's serial order of additions (no bf16 MFMA form)
+    bool no_quad_long;                                // QMANN_NO_QUAD_LONG: stories of 17 .. 64 rows keep the one-wavefront-per-query kernel (hops_quad.h's four-chunk form off)
     bool no_quad;                                     // QMANN_NO_QUAD: short stories keep the one-wavefront-per-query kernel (hops_quad.h off)
     bool no_tight;                                    // QMANN_NO_TIGHT (set, any value): the lean kernels keep their four-wave (128-register) builds
     int lean_sparse;                                  // -1 = the launcher chooses, 0 / 1 forced

@@ -18,6 +18,7 @@ void read_env(QmTuning &t)
     t.no_mid = on("QMANN_NO_MID");
     t.no_lean = on("QMANN_NO_LEAN");
     t.no_quad = on("QMANN_NO_QUAD");
+    t.no_quad_long = on("QMANN_NO_QUAD_LONG");
     t.answer_exact = on("QMANN_ANSWER_EXACT");
     t.no_tied = on("QMANN_NO_TIED");
     t.embed_general_epilogue = on("QMANN_EMBED_GENERAL_EPILOGUE");
