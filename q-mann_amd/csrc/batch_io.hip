@@ -1668,9 +1668,21 @@ k_embed_query_idx(const uint16_t *__restrict__ words, const int8_t *__restrict__
         if (q_ok && sub < max_words) w = words[q * max_words + sub];
         const bool valid = w != 0xFFFFu && w < V;
         const uint32_t me = w | (valid ? 1u << 16 : 0u);
+        // slots past the last valid word of the wavefront's four questions add nothing: the loops below stop there (the word
+        // arrays are 8 or 16 slots wide, a bAbI question has 3 .. 5 words)
+        uint32_t n_used = 0;
+        {
+            const uint64_t vm = __ballot(valid);
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) {
+                const uint32_t m = (uint32_t)(vm >> (16 * g4)) & 0xFFFFu;
+                const uint32_t n = m ? 32u - (uint32_t)__builtin_clz(m) : 0u;
+                n_used = n > n_used ? n : n_used;
+            }
+        }
         uint32_t cnt = 0;
         bool dup = false, later = false;
-        for (uint32_t j = 0; j < max_words; j++) {
+        for (uint32_t j = 0; j < n_used; j++) {
             const uint32_t o = (uint32_t)__shfl((int)me, (int)j, 16);
             const bool same = (((o ^ me) & 0xFFFFu) == 0u) && ((o >> 16) & 1u);
             cnt += same ? 1u : 0u;
@@ -1691,7 +1703,7 @@ k_embed_query_idx(const uint16_t *__restrict__ words, const int8_t *__restrict__
             const uint32_t c4 = c0 + sub;
             const bool col_ok = c4 < dw;
             int acc[4] = {0, 0, 0, 0};
-            for (uint32_t e = 0; e < max_words; e++) {
+            for (uint32_t e = 0; e < n_used; e++) {
                 const uint32_t pe = (uint32_t)__shfl((int)pack, (int)e, 16);
                 if (!((pe >> 24) & 1u) || !col_ok) continue;
                 const uint32_t we = pe & 0xFFFFu, ce = (pe >> 16) & 0xFFu;

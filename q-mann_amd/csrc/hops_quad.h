@@ -316,10 +316,15 @@ k_hops_quad(const HopArgs a, const LeanArgs la, const QuadArgs qa)
             const uint8_t *v0 = (const uint8_t *)a.vals + (size_t)h * a.hop_stride;
             const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)v0, 0, (int)0x7FFFFFFF, kRawBufferFlags);
             uint32_t kk4, bb[4];                                        // kk4: the four weight codes, a byte each
+            uint32_t n_pick = 0;                                        // how many of the four are in use by some story (wavefront-uniform)
             auto pick_fetch = [&]() {
                 kk4 = 0;
+                n_pick = 0;
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
+                    // (a peaked softmax leaves one survivor: the later picks, their loads and their products are skipped together)
+                    if (i > 0 && __ballot(m16 != 0u) == 0) { bb[i] = 0u; continue; }
+                    n_pick = (uint32_t)i + 1u;
                     const bool has = m16 != 0u;
                     const uint32_t bit = has ? quad_ctz(m16) : 0u, pos = bit & 15u, set = bit >> 4;
                     m16 &= m16 - (mask_t)1;                             // (0 stays 0)
@@ -333,6 +338,7 @@ k_hops_quad(const HopArgs a, const LeanArgs la, const QuadArgs qa)
             auto add = [&]() {
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
+                    if ((uint32_t)i >= n_pick) continue;                // (wavefront-uniform)
                     // sign(v) . min(|v| . Q(p) >> frac, 127): the scan's packed multiply (Q(p) pre-shifted, signed 16-bit saturation)
                     const uint32_t kc = ((kk4 >> (8 * i)) & 0xFFu) << (8 - (int)fa.frac), kc2 = kc | (kc << 16);
                     const uint32_t pe = pk_mul_sat_i16(bb[i] & 0x007F007Fu, kc2), po = pk_mul_sat_i16((bb[i] >> 8) & 0x007F007Fu, kc2);
