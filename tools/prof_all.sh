@@ -4,7 +4,7 @@
 # Afterwards, here: tools/summarize_all.sh  (stamps profiles/traffic.json / mfma.json with the kernel-source hash).
 set -e
 cd $GRAFT_REPO_ROOT
-T=${1:-r04}; part=${2:-1}
+T=${1:-r05}; part=${2:-1}
 C="timeout -k 10 300 bash tools/collect_profiles.sh"
 if [ "$part" = 1 ]; then
   rm -rf gpurun_out/prof
