@@ -1274,13 +1274,17 @@ k_embed_story_mfma(const EmbedIdxArgs a)
     i32x4 pend[2];
     size_t pend_row0 = 0;
     bool pending = false;
+    // (raw BUFFER stores on a resource that spans the tile's rows: a row past the plane's last one is dropped by the bounds check and
+    // the stores stand under no lane predicate -- with one the compiler cannot count the stores in flight and waits for ALL of them,
+    // `vmcnt(0)`, wherever it waits for the next tile's words: k_embed_story_mfma_hops below has the measurement)
     auto flush_pending = [&]() {
         if (!pending) return;
-        const uint32_t r = lane / (Dp / 16u);
-        if (pend_row0 + r < a.rows) {
-            *(i32x4 *)(a.keys + (size_t)h * a.hop_stride + pend_row0 * Dp + (size_t)lane * 16u) = pend[0];
-            *(i32x4 *)(a.vals + (size_t)h * a.hop_stride + pend_row0 * Dp + (size_t)lane * 16u) = pend[1];
-        }
+        const size_t left = (size_t)a.rows - pend_row0;
+        const int bytes = (int)((left < kEmRows ? left : (size_t)kEmRows) * Dp);
+        const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)(a.keys + (size_t)h * a.hop_stride + pend_row0 * Dp), 0, bytes, kRawBufferFlags);
+        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(a.vals + (size_t)h * a.hop_stride + pend_row0 * Dp), 0, bytes, kRawBufferFlags);
+        __builtin_amdgcn_raw_buffer_store_b128(pend[0], rk, (int)(lane * 16u), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(pend[1], rv, (int)(lane * 16u), 0, 0);
         pending = false;
     };
     for (size_t tile = (size_t)blockIdx.x * NW + wave; tile < n_tiles; tile += tile_step) {
@@ -1291,6 +1295,8 @@ k_embed_story_mfma(const EmbedIdxArgs a)
         if (lane == 0) *n_dup = 0u;
         uint32_t w[4];
         take_words(tile, w);
+        asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));    // (the words are taken HERE, before the next request is issued: see k_embed_story_mfma_hops)
+        __builtin_amdgcn_sched_barrier(0);
         request_words(tile + tile_step);
         flush_pending();                                                 // the previous tile's rows (see below)
         QM_MARK("X: last slot, byte adds, time entry");
@@ -1455,6 +1461,8 @@ k_embed_story_mfma_hops(const EmbedIdxArgs a)
         }
     }
     __syncthreads();
+    QM_CLK_DECL();
+    QM_CLK(0);                                                           // 0: T^T staging
 
     const uint32_t r4 = lane >> 2, qd = lane & 3u;                       // word phase: row r4 of the tile, slots 4 qd .. 4 qd + 3
     const uint32_t nrow = lane & 15u, kq = lane >> 4;                    // matrix phase: story row nrow, K bytes 16 kq .. / columns 4 kq ..
@@ -1479,21 +1487,36 @@ k_embed_story_mfma_hops(const EmbedIdxArgs a)
     };
     const size_t tile_step = (size_t)gridDim.x * NW;
     request_words((size_t)blockIdx.x * NW + wave);
-    i32x4 pend[2];                                                       // the last hop's rows of the previous tile
+    // the last hop's rows of the previous tile (keeping the last TWO hops' rows back, so that the youngest stores in flight at the
+    // wait for a tile's words are two thirds of a tile old, measured 3 % SLOWER on the joint forwards)
+    i32x4 pend[2];
     size_t pend_row0 = 0;
     bool pending = false;
     const uint32_t srow = lane / (Dp / 16u), spiece = lane % (Dp / 16u);  // whole rows out: lane i holds piece i % 4 of row i / 4
+    // Rows leave through raw BUFFER stores on a resource that spans exactly the tile's rows inside the plane: a row past the
+    // last one (the last tile only) is dropped by the bounds check, so the stores stand under no branch.  With a lane predicate
+    // around them the compiler cannot count the stores in flight, and the wait for the NEXT tile's words -- a load older than
+    // these stores -- became `s_waitcnt vmcnt(0)`: every tile waited for its predecessor's stores to reach memory (15 % of a
+    // wavefront's time, tools/stage_clocks.py).
     auto store_rows = [&](uint32_t h, size_t row0_, const i32x4 (&rows_)[2]) {
-        if (row0_ + srow < a.rows) {
-            *(i32x4 *)(a.keys + (size_t)h * a.hop_stride + row0_ * Dp + (size_t)lane * 16u) = rows_[0];
-            *(i32x4 *)(a.vals + (size_t)h * a.hop_stride + row0_ * Dp + (size_t)lane * 16u) = rows_[1];
-        }
+        const size_t left = (size_t)a.rows - row0_;                      // (row0_ < rows for every tile that runs)
+        const int bytes = (int)((left < kEmRows ? left : (size_t)kEmRows) * Dp);
+        const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)(a.keys + (size_t)h * a.hop_stride + row0_ * Dp), 0, bytes, kRawBufferFlags);
+        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(a.vals + (size_t)h * a.hop_stride + row0_ * Dp), 0, bytes, kRawBufferFlags);
+        __builtin_amdgcn_raw_buffer_store_b128(rows_[0], rk, (int)(lane * 16u), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(rows_[1], rv, (int)(lane * 16u), 0, 0);
     };
     for (size_t tile = (size_t)blockIdx.x * NW + wave; tile < n_tiles; tile += tile_step) {
         const size_t row0 = tile * kEmRows;
         QM_MARK("words of the tile");
+        QM_CLK(1);                                                       // 1: loop overhead / end of the previous tile
         uint32_t w[4];
         take_words(tile, w);
+        // (the words are TAKEN before anything else is issued: hoisted above them, the next tile's request and the pending stores
+        // stood between the old load and its wait, and the compiler -- which cannot count the stores of the hop loop behind it --
+        // waited `vmcnt(1)`: for the request it had just issued.  15 % of a wavefront's time, tools/stage_clocks.py)
+        asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));    // (materialised HERE: the wait for the old load sits in front of the new request)
+        __builtin_amdgcn_sched_barrier(0);
         request_words(tile + tile_step);
         if (pending) { store_rows(H - 1u, pend_row0, pend); pending = false; }
         *(uint2 *)(wl + r4 * 16u + 4u * qd) = uint2{w[0] | (w[1] << 16), w[2] | (w[3] << 16)};
@@ -1525,10 +1548,12 @@ k_embed_story_mfma_hops(const EmbedIdxArgs a)
             for (uint32_t i = 0; i < 4; i++)
                 if (w[i] == tw && !(a.time_last && 4 * qd + i + 1 == last)) w[i] = 0xFFFFu;
         }
+        QM_CLK(2);                                                       // 2: words taken (waits for the prefetched load), pending stores, time word
         // ---- X in four chunks of 64 dictionary entries: each becomes the B fragment of its K step ------------------------
         i32x4 bx[KS];
         uint32_t fix_rows[QMANN_MAX_HOP] = {};                           // per hop: rows to be summed term by term (wavefront-uniform)
         uint32_t nd_seen = 0;
+        bool repeats = false;                                            // some lane's byte add met a count of 1 (wavefront-uniform once balloted)
 #pragma unroll
         for (uint32_t ks = 0; ks < KS; ks++) {
             QM_MARK("X chunk: zero the next, byte adds, fragment");
@@ -1546,13 +1571,18 @@ k_embed_story_mfma_hops(const EmbedIdxArgs a)
                 if (((old >> sh) & 0xFFu) == 1u) {                       // the second occurrence announces the repeat, once
                     const uint32_t n = atomicAdd(n_dup, 1u);
                     if (n < kEmDupCap) dup[n] = (r4 << 16) | w[i];
+                    repeats = true;
                 }
             }
+            QM_CLK(3);                                                   // 3: chunk zero + byte adds issued
             wsync();
+            QM_CLK(4);                                                   // 4: wait for the adds
             bx[ks] = *(const i32x4 *)(xc + em_x_off(nrow, kq * 16u));
             // repeated words of this chunk: does any product Qw(Qw(count) . kw) differ from count . kw in some hop?  (only when the
             // product leaves the format: rare; lane = column)
-            const uint32_t nd = *n_dup < kEmDupCap ? *n_dup : kEmDupCap;
+            // (the list's length is read only when some lane announced a repeat: otherwise an LDS round trip per chunk for nothing)
+            uint32_t nd = nd_seen;
+            if (__any(repeats)) { nd = *n_dup < kEmDupCap ? *n_dup : kEmDupCap; }
             for (uint32_t d = nd_seen; d < nd; d++) {
                 const uint32_t e = dup[d], r = e >> 16, wd = e & 0xFFFFu;
                 const int c = (int)xc[em_x_off(r, wd & 63u)];
@@ -1566,8 +1596,10 @@ k_embed_story_mfma_hops(const EmbedIdxArgs a)
                 }
             }
             nd_seen = nd;
+            QM_CLK(5);                                                   // 5: fragment read + repeated-word check
         }
         wsync();                                                         // the staging tile rewrites chunk bytes
+        QM_CLK(6);
         // ---- per hop: the products, the epilogue, the stores ---------------------------------------------------------------
         for (uint32_t h = 0; h < H; h++) {
             QM_MARK("products (MFMA)");
@@ -1587,6 +1619,7 @@ k_embed_story_mfma_hops(const EmbedIdxArgs a)
                         acc[t][cb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(am, bx[ks], acc[t][cb], 0, 0, 0);
                     }
                 }
+            QM_CLK(7);                                                   // 7: 32 fragment reads + MFMAs issued
             QM_MARK("epilogue: quantise, stage, rows back");
             i32x4 rows[2];
 #pragma unroll
@@ -1631,17 +1664,22 @@ k_embed_story_mfma_hops(const EmbedIdxArgs a)
                     __builtin_amdgcn_wave_barrier();                     // (every lane's dword of this row is written)
                     xs[r * SP + lane] = (uint8_t)ew_to_bytes(s16x2{(short)sum, (short)0}, maxw, fw, dstf, t == 0 && kmz);
                 }
+                QM_CLK(8);                                               // 8: quantise + staging writes (waits for the MFMA results)
                 wsync();
                 rows[t] = *(const i32x4 *)(xs + srow * SP + spiece * 16u);
                 __builtin_amdgcn_wave_barrier();                         // the second table reuses the staging tile
+                QM_CLK(9);                                               // 9: rows read back
             }
             if (h + 1u < H) store_rows(h, row0, rows);
             else { pend[0] = rows[0]; pend[1] = rows[1]; pend_row0 = row0; pending = true; }
+            QM_CLK(10);                                                  // 10: stores issued
         }
         __builtin_amdgcn_wave_barrier();                                 // the next tile rewrites the chunk bytes and the word list
         QM_MARK("end of tile");
     }
     if (pending) store_rows(H - 1u, pend_row0, pend);
+    QM_CLK(11);
+    QM_CLK_FLUSH();
 }
 
 // question: word entries only (no time entry, sample.c:557-565); u0[j] = Qw0(sum_k Qw0(Qw0(W[j][k]) . Qw0(c_k))),
@@ -1851,6 +1889,20 @@ static int answer_f32_impl(const qmann_net *net, const float *w_ans, const float
     QM_LAUNCH_CHECK();
     return qm_scope.rc();
 }
+
+#ifdef QM_STAGE_CLOCKS
+// debug builds only (tools/stage_clocks.py): the per-stage shader-cycle sums of the instrumented kernels of this file, then cleared
+int qmann_debug_stage_clocks(unsigned long long *out, int n)
+{
+    unsigned long long h[kQmClkStages] = {};
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(qm_stage_clk), sizeof h) != hipSuccess) return -1;
+    for (int i = 0; i < n && i < kQmClkStages; i++) out[i] = h[i];
+    unsigned long long z[kQmClkStages] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(qm_stage_clk), z, sizeof z) != hipSuccess) return -1;
+    return kQmClkStages;
+}
+#endif
 
 int qmann_answer_f32(const qmann_net *net, const float *w_ans, const float *u, const uint32_t *answer,
                      uint32_t *pred, float *probs, float *cost, uint32_t *match, uint32_t n_query, void *stream)

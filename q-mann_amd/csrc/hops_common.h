@@ -76,6 +76,22 @@ constexpr int kBufferNt = 2;                        // cache policy of a buffer 
 #define QM_MARK(NAME) do { } while (0)
 #endif
 
+// Stage CLOCKS for tools/stage_clocks.py (a build with -DQM_STAGE_CLOCKS, never the shipped one): where does a wavefront's TIME go
+// in a latency-bound kernel?  QM_CLK(i) charges the shader cycles (s_memtime) since the wavefront's previous QM_CLK to stage i --
+// wall time of that wavefront, waits and the other wavefronts' turns included --; QM_CLK_FLUSH() adds the wavefront's sums to
+// qm_stage_clk[] (one atomic per stage and wavefront at kernel end), which qmann_debug_stage_clocks() reads and clears.
+#ifdef QM_STAGE_CLOCKS
+constexpr int kQmClkStages = 16;
+__device__ unsigned long long qm_stage_clk[kQmClkStages];
+#define QM_CLK_DECL() unsigned long long qm_clk_acc_[kQmClkStages] = {}; unsigned long long qm_clk_last_ = __builtin_amdgcn_s_memtime()
+#define QM_CLK(I) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); qm_clk_acc_[I] += t_ - qm_clk_last_; qm_clk_last_ = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define QM_CLK_FLUSH() do { if ((threadIdx.x & 63u) == 0u) for (int i_ = 0; i_ < kQmClkStages; i_++) if (qm_clk_acc_[i_]) atomicAdd(&qm_stage_clk[i_], qm_clk_acc_[i_]); } while (0)
+#else
+#define QM_CLK_DECL() do { } while (0)
+#define QM_CLK(I) do { } while (0)
+#define QM_CLK_FLUSH() do { } while (0)
+#endif
+
 template <int CTRL>
 __device__ __forceinline__ int dpp_add(int v)
 {
