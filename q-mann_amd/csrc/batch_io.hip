@@ -1430,12 +1430,12 @@ k_embed_story_mfma(const EmbedIdxArgs a)
 // Repeated words: noticed by the byte-add as above, checked per chunk against every hop's tables; a row whose repeated word
 // leaves a hop's weight format is summed term by term from the tile's word list (kept in LDS for that, 512 bytes).
 // ---------------------------------------------------------------------------
-template <int NW>
-__global__ void __launch_bounds__(NW * kWave, 4)
+template <int NW, int KS_, int WPS>                     // wavefronts per workgroup; K / 64 (chunks); wavefronts per SIMD compiled for
+__global__ void __launch_bounds__(NW * kWave, WPS)
 k_embed_story_mfma_hops(const EmbedIdxArgs a)
 {
     constexpr uint32_t kBlockEm = NW * kWave;
-    constexpr uint32_t K = 256u, KS = 4u, Dp = 64u;
+    constexpr uint32_t KS = (uint32_t)KS_, K = 64u * KS, Dp = 64u;
     constexpr uint32_t XC = kEmRows * 64u;              // an X chunk: [4 pieces][16 rows][16 bytes] (em_x_off on k & 63)
     constexpr uint32_t SP = Dp + 16u;                   // row pitch of the staging tile, which follows the two chunks in their bytes
     constexpr uint32_t kWaveLds = 2u * XC + kEmDupCap * 4u + 16u + kEmRows * 16u * 2u;
@@ -2118,19 +2118,18 @@ int qmann_embed_story_idx(const qmann_net *net, const uint16_t *words, uint32_t 
         const size_t tiles = ((size_t)rows_total + kEmRows - 1) / kEmRows;
         // joint-task dictionaries, several hops: every hop of a tile in one workgroup, X built once per tile in chunks
         // (k_embed_story_mfma_hops); QMANN_EMBED_PER_HOP keeps a workgroup per hop (A/B)
+        // (64-entry dictionaries -- task 1 -- gain nothing from it: 444 against 443 M q/s in an interleaved A/B with the K = 64
+        // instantiation at six wavefronts per SIMD; they keep a workgroup per hop)
         if (K == 256u && net->n_hop >= 2u && net->n_hop <= 3u && !qm_tuning().embed_per_hop) {
             constexpr uint32_t nwh = 16u;
             const size_t lds = (size_t)net->n_hop * 2u * Dp * K + (size_t)nwh * (2u * kEmRows * 64u + kEmDupCap * 4u + 16u + kEmRows * 32u);
             const uint32_t resident = qm_resident_groups(nwh, 4u, lds);
             const uint32_t nx = (uint32_t)((tiles + nwh - 1) / nwh < resident ? (tiles + nwh - 1) / nwh : resident);
-            QM_HIP(hipFuncSetAttribute((const void *)k_embed_story_mfma_hops<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            k_embed_story_mfma_hops<16><<<nx, nwh * kWave, lds, st>>>(a);
+            QM_HIP(hipFuncSetAttribute((const void *)k_embed_story_mfma_hops<16, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            k_embed_story_mfma_hops<16, 4, 4><<<nx, nwh * kWave, lds, st>>>(a);
             QM_LAUNCH_CHECK();
             return qm_scope.rc();
         }
-        // T^T (2 x 64 x K bytes) is per workgroup: large dictionaries share it among 16 wavefronts
-        const uint32_t nwv = K == 64 ? 8u : 16u;
-        const size_t lds = 2u * (size_t)Dp * K + (size_t)nwv * (kEmRows * K + kEmRows * (Dp + 16u) + kEmDupCap * 4u + 16u);
         // persistent in x: never more workgroups than are resident at once (rt.h: through round 3 the cap was LDS-only and
         // rounded UP -- 86 x 3 = 258 workgroups for 256 one-per-CU slots on the joint dictionaries, 1 026 for 512 on task 1)
         const uint32_t resident = qm_resident_groups(nwv, (uint32_t)em_waves_per_simd(K == 64 ? 1 : (K == 128 ? 2 : 4)), lds);

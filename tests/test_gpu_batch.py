@@ -363,7 +363,14 @@ def run_hamming_case(env, oracle, mode, D, S_list, B, seed, iwl=5, num_bit=8, si
         planes = net.pack_planes(dk, num_bit)
         u_out, taps = net.hops_packed(planes, dv, dro, int(n_slots.max()), du0, taps=True)
         unit = 1.0 if mode == 10 else 1.0 / (1 << num_bit)
+    # ... and the same request WITHOUT taps: the production kernel of the shape (quad / lean / streaming; for packed planes the
+    # packed streaming kernel), whose final state is compared with the oracle's directly below
+    if mode == 3 or from_bytes:
+        u_prod = net.hops(dk, dv, dro, int(n_slots.max()), du0)
+    else:
+        u_prod = net.hops_packed(planes, dv, dro, int(n_slots.max()), du0)
     torch.cuda.synchronize()
+    g_u_prod = u_prod.cpu().numpy()
     g_codes = taps.score_codes.cpu().numpy(); g_scores = taps.scores.cpu().numpy()
     g_probs = taps.probs.cpu().numpy(); g_u = taps.u.cpu().numpy(); g_o = taps.o.cpu().numpy()
     m = oracle.make_model(cfg, wts)
@@ -384,6 +391,11 @@ def run_hamming_case(env, oracle, mode, D, S_list, B, seed, iwl=5, num_bit=8, si
             np.testing.assert_allclose(g_probs[h, a:b], t["probs"][h], rtol=1e-5, atol=1e-7)
             if not (np.array_equal(g_o[q, h], t["o"][h]) and np.array_equal(g_u[q, h], t["u"][h])):
                 assert near_step(t["probs"][h], frac).any(), f"o/u differ q{q} h{h}"
+                ok = False
+        if ok and b > a:
+            want_u = np.maximum(t["u"][H - 1], 0.0) if cfg.get("en_non_lin") else t["u"][H - 1]
+            if not np.array_equal(g_u_prod[q], want_u):
+                assert any(near_step(t["probs"][h], cfg["fmt"][h][1]).any() for h in range(H)), f"production kernel: final state differs q{q}"
                 ok = False
         excused += not ok
     assert excused == 0, f"{excused} of {B} queries needed the p-on-a-step excuse (observed: 0)"
