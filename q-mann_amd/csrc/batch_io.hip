@@ -2130,6 +2130,9 @@ int qmann_embed_story_idx(const qmann_net *net, const uint16_t *words, uint32_t 
             QM_LAUNCH_CHECK();
             return qm_scope.rc();
         }
+        // T^T (2 x 64 x K bytes) is per workgroup: large dictionaries share it among 16 wavefronts
+        const uint32_t nwv = K == 64 ? 8u : 16u;
+        const size_t lds = 2u * (size_t)Dp * K + (size_t)nwv * (kEmRows * K + kEmRows * (Dp + 16u) + kEmDupCap * 4u + 16u);
         // persistent in x: never more workgroups than are resident at once (rt.h: through round 3 the cap was LDS-only and
         // rounded UP -- 86 x 3 = 258 workgroups for 256 one-per-CU slots on the joint dictionaries, 1 026 for 512 on task 1)
         const uint32_t resident = qm_resident_groups(nwv, (uint32_t)em_waves_per_simd(K == 64 ? 1 : (K == 128 ? 2 : 4)), lds);
