@@ -271,7 +271,7 @@ int qmann_hops_i8(const qmann_net *net, const int8_t *keys, const int8_t *vals, 
         a.tap_codes = taps->score_codes; a.tap_scores = taps->scores; a.tap_probs = taps->probs;
         a.tap_o = taps->o; a.tap_u = taps->u;
     }
-    a.rows_total = (uint32_t)(hop_stride / net->dim_emb_pad);
+    a.rows_total = hop_stride ? (uint32_t)(hop_stride / net->dim_emb_pad) : (uint32_t)qm_rows_hint;      // (tied hops: the caller's hint, or 0 = unknown)
     a.max_slots = max_slots;
     a.n_hop = net->n_hop; a.D = net->dim_emb; a.Dp = net->dim_emb_pad;
     a.softmax_base = net->softmax_base; a.en_lin_map = net->en_lin_map;

@@ -309,7 +309,7 @@ int fill_args(HopArgs &a, const qmann_net *net, const void *keys, const int8_t *
         a.tap_codes = taps->score_codes; a.tap_scores = taps->scores; a.tap_probs = taps->probs;
         a.tap_o = taps->o; a.tap_u = taps->u;
     }
-    a.rows_total = (uint32_t)(val_hop_stride / net->dim_emb_pad);
+    a.rows_total = val_hop_stride ? (uint32_t)(val_hop_stride / net->dim_emb_pad) : (uint32_t)qm_rows_hint;   // (tied hops: the caller's hint, or 0 = unknown)
     a.n_hop = net->n_hop; a.D = net->dim_emb; a.Dp = net->dim_emb_pad;
     a.softmax_base = net->softmax_base; a.en_lin_map = net->en_lin_map;
     a.softmax_shift = net->softmax_shift_based; a.en_att_scale = net->en_att_scale; a.en_non_lin = net->en_non_linearity;

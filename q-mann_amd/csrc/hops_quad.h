@@ -452,7 +452,7 @@ k_split_by_length(const uint32_t *__restrict__ row_off, uint32_t n_query, uint32
 }
 
 // what the quad kernel covers: the lean kernel's shapes (lean_supported) with word length 7 in every format of the launch, the
-// e^x softmax base without the shift-based normaliser, and planes of less than 2 GiB (its buffer offsets are 32-bit)
+// e^x softmax base without the shift-based normaliser, and planes of known size below 2 GiB (its buffer offsets are 32-bit)
 inline bool quad_supported(const HopArgs &a, int mode, uint32_t max_slots, uint32_t n_query)
 {
     if (qm_tuning().no_quad || a.softmax_base != QMANN_SOFTMAX_EXP || a.softmax_shift) return false;
@@ -462,8 +462,10 @@ inline bool quad_supported(const HopArgs &a, int mode, uint32_t max_slots, uint3
         if (a.en_lin_map && a.w[h].iwl + a.w[h].frac != 7) return false;
     }
     if (a.bin.frac > 7u) return false;
-    // rows of the launch <= n_query . max_slots (the plane size is unknown for tied hops): every row offset must stay below 2^31
-    return (uint64_t)n_query * (max_slots ? max_slots : 1u) * 64u < 0x7FFF0000ull;
+    // The kernel addresses rows by 32-bit byte offsets from the start of a hop's plane (one buffer resource per hop): the plane --
+    // every row the batch's offsets can name, cut stories' unused rows included -- must stay below 2 GiB, and its size must be
+    // KNOWN: from hop_stride, or for tied hops (hop_stride = 0) from the caller's hint (rt.h::QmRowsHint, qmann_model gives it)
+    return a.rows_total != 0u && (uint64_t)a.rows_total * 64u < 0x7FFF0000ull;
 }
 
 template <int MODE, int NB, int NC>

@@ -247,6 +247,7 @@ int hops_and_answer(qmann_model *m, uint32_t rows_total, const uint32_t *row_off
                     const uint32_t *answer, uint32_t *pred, float *cost, uint32_t *match, void *stream)
 {
     const size_t hop_stride = m->tied ? 0 : (size_t)rows_total * m->Dp;
+    QmRowsHint plane_rows(rows_total);               // (a tied model passes hop_stride = 0: the hop kernels still learn the plane's size)
     int rc;
     if (use_planes(m, max_slots)) {
         const size_t key_hop_stride = m->tied ? 0 : (size_t)rows_total * (m->Dp / 64) * m->net.num_bit * 8;

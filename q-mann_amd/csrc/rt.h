@@ -57,6 +57,17 @@ struct QmAnswerExact {
     QmAnswerExact(const QmAnswerExact &) = delete;
 };
 
+// A hop-plane's size in rows, from a caller that knows it, for calls that pass hop_stride = 0 (tied hops: one plane for every
+// hop, qmann_model's hops_and_answer): hops_quad.h addresses rows by 32-bit byte offsets from the plane's start and must know that
+// the plane stays below 2 GiB; without the hint such a call keeps the one-wavefront-per-query kernel.
+inline thread_local size_t qm_rows_hint = 0;
+struct QmRowsHint {
+    size_t prev;
+    explicit QmRowsHint(size_t rows) : prev(qm_rows_hint) { qm_rows_hint = rows; }
+    ~QmRowsHint() { qm_rows_hint = prev; }
+    QmRowsHint(const QmRowsHint &) = delete;
+};
+
 // The library's A/B and tuning switches (INTEGRATION.md lists them) are read from the environment ONCE per process -- on
 // first use, through a thread-safe function-local static -- and then live in this struct: no launch calls getenv(), which
 // is not safe against a setenv() running in another thread of a threaded host (examples/forward_sharded.c is one).
