@@ -559,7 +559,7 @@ inline bool lean_supported(const HopArgs &a, uint32_t max_slots, uint32_t key_ro
 
 template <int MODE, int NB, bool W7, bool SPARSE>
 inline void launch_lean_w(HopArgs a, uint32_t max_slots, uint32_t n_query, hipStream_t st, const uint32_t *list = nullptr,
-                          const uint32_t *n_list = nullptr)
+                          const uint32_t *n_list = nullptr, uint32_t per_cu_cap = 0)
 {
     LeanArgs la{};
     la.list = list; la.n_list = n_list;
@@ -577,7 +577,8 @@ inline void launch_lean_w(HopArgs a, uint32_t max_slots, uint32_t n_query, hipSt
     const uint32_t need = (n_query + kLeanWaves - 1) / kLeanWaves;
     auto go = [&](auto kernel, int wps) {
         if (lds > kLdsDefaultLimit) QM_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        const uint32_t resident = qm_resident_groups(kLeanWaves, (unsigned)wps, lds);
+        uint32_t resident = qm_resident_groups(kLeanWaves, (unsigned)wps, lds);
+        if (per_cu_cap && resident > per_cu_cap * qm_cu_count()) resident = per_cu_cap * qm_cu_count();
         kernel<<<need < resident ? need : resident, kLeanBlock, lds, st>>>(a, la);
     };
     // the six-wave build where it buys a third workgroup per CU (every attention mode: the Hamming forms need 81-91 registers in
@@ -592,12 +593,14 @@ inline void launch_lean_w(HopArgs a, uint32_t max_slots, uint32_t n_query, hipSt
 
 template <int MODE, int NB>
 inline void launch_lean_all(const HopArgs &a, uint32_t max_slots, uint32_t n_query, hipStream_t st, const uint32_t *list = nullptr,
-                            const uint32_t *n_list = nullptr);
+                            const uint32_t *n_list = nullptr, uint32_t per_cu_cap = 0);
 
 // Short-memory launches: stories of at most 16 rows take the four-queries-per-wavefront kernel (hops_quad.h), longer ones the
 // one-wavefront-per-query kernel below.  A batch whose bound allows both (the 20-task set: up to 64 rows, 91 % of the stories
 // <= 16) is split on the device into two index lists first (k_split_by_length); the two kernels then run one after the other
 // on the stream, each over its list.  QMANN_NO_QUAD keeps everything on the lean kernel (A/B).
+constexpr uint32_t kCorunMinQueries = 32768;          // (32 768 and 65 536 queries: the two forms time the same within 0.3 %; 262 000: +4 %)
+
 template <int MODE, int NB>
 inline void launch_lean(const HopArgs &a, uint32_t max_slots, uint32_t n_query, hipStream_t st)
 {
@@ -625,13 +628,31 @@ inline void launch_lean(const HopArgs &a, uint32_t max_slots, uint32_t n_query, 
     QM_HIP(hipMemsetAsync(ws, 0, 2 * sizeof(uint32_t), st));
     const uint32_t blocks = (n_query + kSplitBlock - 1u) / kSplitBlock;
     k_split_by_length<<<blocks < 1024u ? blocks : 1024u, kSplitBlock, 0, st>>>(a.row_off, n_query, max_slots, ws, ws + 2, ws + 2 + n_query);
+    // Large batches: the two kernels SIDE BY SIDE -- the long stories' kernel on a second stream (forked and joined by events, so
+    // the caller's stream sees one ordered step and a stream capture takes both branches), one workgroup per CU, the short stories'
+    // kernel two per CU instead of three.  Both are bound by vector issue and latency, not by a shared unit: together they fill
+    // the issue slots either leaves empty alone.  Kernel trace on the 20-task set (262 000 queries, 9 % long): 433 us for both
+    // (they end within 10 us of each other) against 370 + 98 us in sequence; forward 1.033 -> 0.994 ms (interleaved A/B).
+    // Other splits measured: 3 + 1 per CU 1.012, 3 + 3 1.011, 2 + 2 1.003, 1 + 1 1.117 ms.  QMANN_NO_CORUN: in sequence.
+    if (n_query >= kCorunMinQueries && !qm_tuning().no_corun) {
+        if (QmSide *sd = qm_side_stream(st)) {
+            QM_HIP(hipEventRecord(sd->fork, st));
+            QM_HIP(hipStreamWaitEvent(sd->side, sd->fork, 0));
+            launch_lean_all<MODE, NB>(a, max_slots, n_query, sd->side, ws + 2 + n_query, ws + 1, 1u);
+            QM_HIP(hipEventRecord(sd->join, sd->side));
+            launch_quad<MODE, NB, 1>(a, QuadArgs{ws + 2, ws, n_query}, n_query, st, 2u);
+            QM_HIP(hipStreamWaitEvent(st, sd->join, 0));
+            return;
+        }
+    }
     launch_quad<MODE, NB, 1>(a, QuadArgs{ws + 2, ws, n_query}, n_query, st);
     // (the few long stories of such a batch: the lean kernel -- the four-chunk quad form measured 3 % SLOWER on the joint forward)
     launch_lean_all<MODE, NB>(a, max_slots, n_query, st, ws + 2 + n_query, ws + 1);
 }
 
 template <int MODE, int NB>
-inline void launch_lean_all(const HopArgs &a, uint32_t max_slots, uint32_t n_query, hipStream_t st, const uint32_t *list, const uint32_t *n_list)
+inline void launch_lean_all(const HopArgs &a, uint32_t max_slots, uint32_t n_query, hipStream_t st, const uint32_t *list, const uint32_t *n_list,
+                            uint32_t per_cu_cap)
 {
     bool w7 = true;
     for (uint32_t h = 0; h < a.n_hop; h++)
@@ -659,8 +680,8 @@ inline void launch_lean_all(const HopArgs &a, uint32_t max_slots, uint32_t n_que
             sparse = true;
     }
     if (qm_tuning().lean_sparse >= 0) sparse = qm_tuning().lean_sparse == 1;
-    if (w7) { if (sparse) launch_lean_w<MODE, NB, true, true>(a, max_slots, n_query, st, list, n_list); else launch_lean_w<MODE, NB, true, false>(a, max_slots, n_query, st, list, n_list); }
-    else { if (sparse) launch_lean_w<MODE, NB, false, true>(a, max_slots, n_query, st, list, n_list); else launch_lean_w<MODE, NB, false, false>(a, max_slots, n_query, st, list, n_list); }
+    if (w7) { if (sparse) launch_lean_w<MODE, NB, true, true>(a, max_slots, n_query, st, list, n_list, per_cu_cap); else launch_lean_w<MODE, NB, true, false>(a, max_slots, n_query, st, list, n_list, per_cu_cap); }
+    else { if (sparse) launch_lean_w<MODE, NB, false, true>(a, max_slots, n_query, st, list, n_list, per_cu_cap); else launch_lean_w<MODE, NB, false, false>(a, max_slots, n_query, st, list, n_list, per_cu_cap); }
 }
 
 }  // namespace

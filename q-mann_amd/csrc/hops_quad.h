@@ -469,7 +469,7 @@ inline bool quad_supported(const HopArgs &a, int mode, uint32_t max_slots, uint3
 }
 
 template <int MODE, int NB, int NC>
-inline void launch_quad(HopArgs a, const QuadArgs &qa, uint32_t n_max, hipStream_t st)
+inline void launch_quad(HopArgs a, const QuadArgs &qa, uint32_t n_max, hipStream_t st, uint32_t per_cu_cap = 0)
 {
     LeanArgs la{};
     la.rows_pad = 0;
@@ -480,7 +480,8 @@ inline void launch_quad(HopArgs a, const QuadArgs &qa, uint32_t n_max, hipStream
     constexpr int wps = NC == 1 ? kQuadWps : kQuadWpsLong;
     auto kernel = k_hops_quad<MODE, NB, wps, NC>;
     if (lds > kLdsDefaultLimit) QM_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const uint32_t resident = qm_resident_groups(kQuadWaves, (unsigned)wps, lds);
+    uint32_t resident = qm_resident_groups(kQuadWaves, (unsigned)wps, lds);
+    if (per_cu_cap && resident > per_cu_cap * qm_cu_count()) resident = per_cu_cap * qm_cu_count();
     kernel<<<need < resident ? need : resident, kQuadBlock, lds, st>>>(a, la, qa);
 }
 

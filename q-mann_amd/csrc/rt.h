@@ -78,6 +78,7 @@ struct QmTuning {
     bool embed_per_hop;                               // QMANN_EMBED_PER_HOP: the joint-dictionary story embedding keeps one workgroup per hop (k_embed_story_mfma<4, 16>)
     bool answer_exact;                                // QMANN_ANSWER_EXACT: the float answer layer keeps the reference's serial order of additions (no bf16 MFMA form)
     bool no_quad_long;                                // QMANN_NO_QUAD_LONG: stories of 17 .. 64 rows keep the one-wavefront-per-query kernel (hops_quad.h's four-chunk form off)
+    bool no_corun;                                    // QMANN_NO_CORUN: the two kernels of a split batch run one after the other (no second stream)
     bool no_quad;                                     // QMANN_NO_QUAD: short stories keep the one-wavefront-per-query kernel (hops_quad.h off)
     bool no_tight;                                    // QMANN_NO_TIGHT (set, any value): the lean kernels keep their four-wave (128-register) builds
     int lean_sparse;                                  // -1 = the launcher chooses, 0 / 1 forced
@@ -102,6 +103,10 @@ static inline unsigned qm_resident_groups(unsigned waves, unsigned waves_per_sim
 // Device scratch of at least `words` 32-bit words for the launch being enqueued on `stream` (index lists of a batch split by
 // story length): one buffer per (device, stream), grown when a launch needs more (the only time this allocates -- like a model's
 // workspace it reaches its size on the first batches), kept for the life of the process.  nullptr when the allocation fails.
-uint32_t *qm_scratch_u32(size_t words, hipStream_t stream);       // (tuning.hip)
+uint32_t *qm_scratch_u32(size_t words, hipStream_t stream);
+
+// A second stream beside `stream` with the two events that fork work onto it and join it back (cached per (device, stream)).
+struct QmSide { hipStream_t side; hipEvent_t fork, join; };
+QmSide *qm_side_stream(hipStream_t stream);       // (tuning.hip)
 
 static inline unsigned qm_cdiv(unsigned a, unsigned b) { return (a + b - 1) / b; }

@@ -18,6 +18,7 @@ void read_env(QmTuning &t)
     t.no_mid = on("QMANN_NO_MID");
     t.no_lean = on("QMANN_NO_LEAN");
     t.no_quad = on("QMANN_NO_QUAD");
+    t.no_corun = on("QMANN_NO_CORUN");
     t.no_quad_long = on("QMANN_NO_QUAD_LONG");
     t.answer_exact = on("QMANN_ANSWER_EXACT");
     t.no_tied = on("QMANN_NO_TIED");
@@ -77,6 +78,22 @@ uint32_t *qm_scratch_u32(size_t words, hipStream_t stream)
         b.cap = cap;
     }
     return b.p;
+}
+
+QmSide *qm_side_stream(hipStream_t stream)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, QmSide> sides;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    std::lock_guard<std::mutex> hold(mu);
+    auto it = sides.find({dev, stream});
+    if (it != sides.end()) return &it->second;
+    QmSide sd{};
+    if (hipStreamCreateWithFlags(&sd.side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return &(sides[{dev, stream}] = sd);
 }
 
 extern "C" void qmann_tuning_reload(void)

@@ -22,14 +22,17 @@ def _words(rng, n, V, dd, max_words, with_time, n_sen=None):
     return out
 
 
-@pytest.mark.parametrize("mode,nb", [(2, 8), (3, 8), (11, 4)])
-def test_forward_words_replays_from_a_captured_graph(mode, nb):
+@pytest.mark.parametrize("mode,nb,B,cap", [(2, 8, 96, 10), (3, 8, 96, 10), (11, 4, 96, 10),
+                                            # a batch that is split by story length, its two hop kernels side by side on two
+                                            # streams (csrc/hops_lean.h::launch_lean): the capture takes both branches
+                                            (2, 8, 40000, 40), (3, 8, 40000, 40)])
+def test_forward_words_replays_from_a_captured_graph(mode, nb, B, cap):
     import torch
     load_pkg()
     import qmann_amd.model as model
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(5 + mode)
-    V, dd, D, H, B = 40, 30, 60, 3, 96
+    V, dd, D, H = 40, 30, 60, 3
     cfg = model.babi_cfg(V, mode, 0, iwl=5, en_mq=True)
     cfg["num_bit"] = nb
     wts = {"w_q": rng.normal(0, 1.0, (D, V)).astype(np.float32), "w_ans": rng.normal(0, 0.3, (V, D)).astype(np.float32),
@@ -37,6 +40,8 @@ def test_forward_words_replays_from_a_captured_graph(mode, nb):
            "w_c": [rng.normal(0, 1.0, (D, V)).astype(np.float32) for _ in range(H)],
            "w_h": [rng.normal(0, 1.0, (D, D)).astype(np.float32) for _ in range(H)]}
     n_sen = rng.integers(1, 11, B).astype(np.int64)
+    if cap > 10:
+        n_sen[::9] = rng.integers(17, cap + 1, len(n_sen[::9]))                   # one story in nine is long (mean length stays < 16)
     rows = int(n_sen.sum())
     row_off = torch.from_numpy(np.concatenate([[0], np.cumsum(n_sen)]).astype(np.int32)).to(dev)
 
@@ -50,21 +55,21 @@ def test_forward_words_replays_from_a_captured_graph(mode, nb):
     plain = model.HostModel(cfg, wts, device="cuda:0")                           # the same model on the default stream: the check
     sw, qw, ans = batch(1)                                                       # static input buffers of the graph
     with torch.cuda.stream(s):
-        hm.forward_words(sw, qw, row_off, 10, ans)                               # warm-up: the workspace takes its size
+        hm.forward_words(sw, qw, row_off, cap, ans)                              # warm-up: the workspace takes its size
     s.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g, stream=s):
-        pred, cost, match = hm.forward_words(sw, qw, row_off, 10, ans)           # captured, not run
+        pred, cost, match = hm.forward_words(sw, qw, row_off, cap, ans)          # captured, not run
     for seed in (2, 3, 4):
         nsw, nqw, nans = batch(seed)
         sw.copy_(nsw); qw.copy_(nqw); ans.copy_(nans)                            # new batch into the graph's input buffers
         torch.cuda.synchronize()
         g.replay()
         torch.cuda.synchronize()
-        p2, c2, m2 = plain.forward_words(nsw, nqw, row_off, 10, nans)
+        p2, c2, m2 = plain.forward_words(nsw, nqw, row_off, cap, nans)
         torch.cuda.synchronize()
         # (cost / match are single words the forward ACCUMULATES into: the captured memset of _out zeroes them per replay? no --
         # they are zeroed by torch.zeros inside the capture, which is part of the graph)
         assert torch.equal(pred, p2), seed
-        assert int(match.item()) == int(m2.item()) and float(cost.item()) == pytest.approx(float(c2.item()), rel=1e-6)
+        assert int(match.item()) == int(m2.item()) and float(cost.item()) == pytest.approx(float(c2.item()), rel=1e-5)
     assert len({int(x) for x in pred.cpu().numpy()}) > 1                         # (not a degenerate constant prediction)

@@ -24,7 +24,7 @@ def env():
     return e
 
 
-def three_paths(env, monkeypatch, cfg, B, S_list, seed, sigma_k=30.0, sigma_u=20.0, sigma_h=1.0, shuffle=True, max_slots=None):
+def three_paths(env, monkeypatch, cfg, B, S_list, seed, sigma_k=30.0, sigma_u=20.0, sigma_h=1.0, shuffle=True, max_slots=None, repeat=0):
     """general kernel (taps) == production path (quad / split) == lean kernel alone (QMANN_NO_QUAD)"""
     torch, model = env.torch, env.model
     H, D, V = cfg["n_hop"], cfg["dim_emb"], cfg["dim_input"]
@@ -56,6 +56,7 @@ def three_paths(env, monkeypatch, cfg, B, S_list, seed, sigma_k=30.0, sigma_u=20
     ms = int(n_slots.max()) if max_slots is None else max_slots
     u_gen, _ = net.hops(dk, dv, dro, ms, du0, taps=True)        # taps: general kernel
     u_prod = net.hops(dk, dv, dro, ms, du0)                     # no taps: quad / split (where they apply)
+    u_again = [net.hops(dk, dv, dro, ms, du0) for _ in range(repeat)]       # back to back, no synchronisation between the calls
     monkeypatch.setenv("QMANN_NO_QUAD", "1")
     model.abi.lib.qmann_tuning_reload()
     u_lean = net.hops(dk, dv, dro, ms, du0)                     # the lean kernel alone
@@ -63,7 +64,7 @@ def three_paths(env, monkeypatch, cfg, B, S_list, seed, sigma_k=30.0, sigma_u=20
     model.abi.lib.qmann_tuning_reload()
     torch.cuda.synchronize()
     g = u_gen.cpu().numpy()
-    for name, t in (("production", u_prod), ("lean", u_lean)):
+    for name, t in [("production", u_prod), ("lean", u_lean)] + [(f"production, call {i + 2}", t) for i, t in enumerate(u_again)]:
         a = t.cpu().numpy()
         bad = np.flatnonzero((a != g).any(1))
         assert bad.size == 0, f"{name}: {bad.size} of {B} queries differ from the general kernel, first {bad[:5]}, slots {n_slots[bad[:5]]}"
@@ -105,6 +106,22 @@ def test_quad_persistent_grid_many_queries(env, monkeypatch):
     """more quads than resident wavefronts: every wavefront walks several quads (the task-1 lengths, then the joint mix)"""
     three_paths(env, monkeypatch, cfg_of(2), B=200003, S_list=[2, 4, 6, 8, 10], seed=300)
     three_paths(env, monkeypatch, cfg_of(3), B=100001, S_list=[2, 4, 6, 8, 10, 14, 3, 20, 7, 64, 5, 9], seed=301)
+
+
+@pytest.mark.parametrize("mode,nb", [(2, 8), (3, 8), (10, 1), (11, 4)])
+def test_split_batch_runs_its_two_kernels_side_by_side(env, monkeypatch, mode, nb):
+    """>= 32 768 queries of mixed length: the short stories' kernel on the caller's stream, the long stories' on a second one
+    (csrc/hops_lean.h::launch_lean, fork / join by events); several forwards back to back reuse the same two events"""
+    S = [2, 4, 6, 8, 10, 14, 3, 20, 7, 64, 5, 9]
+    three_paths(env, monkeypatch, cfg_of(mode, nb=nb), B=40001, S_list=S, seed=310 + mode, repeat=4)
+    three_paths(env, monkeypatch, cfg_of(mode, nb=nb), B=33000, S_list=[3, 9, 16, 12], seed=320 + mode, max_slots=64, repeat=2)   # (nothing long: the side kernel finds an empty list)
+    monkeypatch.setenv("QMANN_NO_CORUN", "1")
+    env.model.abi.lib.qmann_tuning_reload()
+    try:
+        three_paths(env, monkeypatch, cfg_of(mode, nb=nb), B=40001, S_list=S, seed=310 + mode)
+    finally:
+        monkeypatch.delenv("QMANN_NO_CORUN")
+        env.model.abi.lib.qmann_tuning_reload()
 
 
 VARIANTS = {
