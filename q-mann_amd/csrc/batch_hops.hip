@@ -194,6 +194,19 @@ __global__ void k_check_slots(const uint32_t *__restrict__ row_off, uint32_t n_q
 
 }  // namespace
 
+// rt.h::QmSplitReady: the launch rule of hops_lean.h::launch_lean for "this batch will be split" (stories capped between 17 and 64
+// rows whose mean length is within the short form's 16), and the two lists computed ahead of the launch
+bool qm_split_applies(size_t rows_total, uint32_t n_query, uint32_t max_slots)
+{
+    return n_query && max_slots > (uint32_t)kQuadSlots && max_slots <= (uint32_t)kWave && rows_total / n_query <= (size_t)kQuadSlots &&
+           !qm_tuning().no_quad && !qm_tuning().no_lean;
+}
+
+uint32_t *qm_split_early(const uint32_t *row_off, uint32_t n_query, uint32_t max_slots, hipStream_t owner, hipStream_t run_on)
+{
+    return split_lists(row_off, n_query, max_slots, owner, run_on);
+}
+
 extern "C" {
 
 int qmann_hops_appx_impl(const qmann_net *net, const int8_t *keys, const int8_t *vals, size_t hop_stride,

@@ -1694,16 +1694,20 @@ k_embed_query_idx(const uint16_t *__restrict__ words, const int8_t *__restrict__
     const uint32_t dw = Dp / 4;
     uint32_t *tab = (uint32_t *)smem;
     if (TAB_LDS) {
+#pragma unroll 4                                                 // (eight loads in flight were the kernel's 33rd register)
         for (uint32_t i = tid; i < V * dw; i += kBlock) tab[i] = ((const uint32_t *)t_q)[i];
         __syncthreads();
     }
     const int maxw = (1 << (fw.iwl + fw.frac)) - 1;
-    const size_t per_pass = (size_t)gridDim.x * kWaves * 4;
-    for (size_t q0 = ((size_t)blockIdx.x * kWaves + tid / kWave) * 4; q0 < n_query; q0 += per_pass) {
-        const size_t q = q0 + grp;
+    const bool vec_rows = (D & 3u) == 0u && ((uintptr_t)u0 & 15u) == 0u;
+    // (a 32-bit query counter, 64-bit only where an address is formed: the kernel fits 32 registers, and its workgroups find room
+    // on a CU beside the story embedding's -- model_host.hip runs the two side by side)
+    const uint32_t per_pass = gridDim.x * kWaves * 4;
+    for (uint32_t q0 = (blockIdx.x * kWaves + tid / kWave) * 4; q0 < n_query; q0 += per_pass) {
+        const uint32_t q = q0 + grp;
         const bool q_ok = q < n_query;
         uint32_t w = 0xFFFFu;
-        if (q_ok && sub < max_words) w = words[q * max_words + sub];
+        if (q_ok && sub < max_words) w = words[(size_t)q * max_words + sub];
         const bool valid = w != 0xFFFFu && w < V;
         const uint32_t me = w | (valid ? 1u << 16 : 0u);
         // slots past the last valid word of the wavefront's four questions add nothing: the loops below stop there (the word
@@ -1754,11 +1758,18 @@ k_embed_query_idx(const uint16_t *__restrict__ words, const int8_t *__restrict__
                 }
             }
             if (q_ok && col_ok) {
+                float o[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const uint32_t col = 4 * c4 + (uint32_t)k;
                     const int v = acc[k] > maxw ? maxw : (acc[k] < -maxw ? -maxw : acc[k]);
-                    if (col < D) u0[q * D + col] = qm_scale_down((float)v, fw.frac);
+                    o[k] = qm_scale_down((float)v, fw.frac);
+                }
+                if (vec_rows) {                                          // rows of whole 16-byte groups (bAbI: D = 60): one store per lane
+                    if (4u * c4 < D) *(float4 *)(u0 + (size_t)q * D + 4u * c4) = float4{o[0], o[1], o[2], o[3]};
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (4u * c4 + (uint32_t)k < D) u0[(size_t)q * D + 4u * c4 + (uint32_t)k] = o[k];
                 }
             }
         }
@@ -2177,6 +2188,7 @@ int qmann_embed_query_idx(const qmann_net *net, const uint16_t *words, uint32_t 
     if (!fmt8(net->w[0])) return QMANN_ERANGE;
     if (n_query == 0) return QMANN_OK;
     if (net->dim_emb_pad & 3u) return QMANN_EINVAL;
+    if (n_query > 0xFFF00000u) return QMANN_ERANGE;       // (the kernel's 32-bit query counter steps past n_query by up to a grid's worth)
     const uint32_t need = (n_query + kWaves * 4 - 1) / (kWaves * 4);
     const uint32_t blocks = need < 2048u ? need : 2048u;
     const size_t tab_lds = (size_t)net->dim_input * net->dim_emb_pad;

@@ -599,8 +599,6 @@ inline void launch_lean_all(const HopArgs &a, uint32_t max_slots, uint32_t n_que
 // one-wavefront-per-query kernel below.  A batch whose bound allows both (the 20-task set: up to 64 rows, 91 % of the stories
 // <= 16) is split on the device into two index lists first (k_split_by_length); the two kernels then run one after the other
 // on the stream, each over its list.  QMANN_NO_QUAD keeps everything on the lean kernel (A/B).
-constexpr uint32_t kCorunMinQueries = 32768;          // (32 768 and 65 536 queries: the two forms time the same within 0.3 %; 262 000: +4 %)
-
 template <int MODE, int NB>
 inline void launch_lean(const HopArgs &a, uint32_t max_slots, uint32_t n_query, hipStream_t st)
 {
@@ -622,19 +620,21 @@ inline void launch_lean(const HopArgs &a, uint32_t max_slots, uint32_t n_query, 
         launch_lean_all<MODE, NB>(a, max_slots, n_query, st);
         return;
     }
-    // [0] short count, [1] long count, then the two lists
-    uint32_t *ws = qm_scratch_u32(2u + 2u * (size_t)n_query, st);
+    uint32_t *ws = nullptr;
+    {
+        const QmSplitReady r = qm_split_ready;                                // (prepared by the host model beside the story embedding)
+        qm_split_ready = QmSplitReady{nullptr, 0, 0, nullptr};
+        if (r.ws && r.row_off == a.row_off && r.n_query == n_query && r.max_slots == max_slots) ws = r.ws;
+    }
+    if (!ws) ws = split_lists(a.row_off, n_query, max_slots, st, st);
     if (!ws) { launch_lean_all<MODE, NB>(a, max_slots, n_query, st); return; }
-    QM_HIP(hipMemsetAsync(ws, 0, 2 * sizeof(uint32_t), st));
-    const uint32_t blocks = (n_query + kSplitBlock - 1u) / kSplitBlock;
-    k_split_by_length<<<blocks < 1024u ? blocks : 1024u, kSplitBlock, 0, st>>>(a.row_off, n_query, max_slots, ws, ws + 2, ws + 2 + n_query);
     // Large batches: the two kernels SIDE BY SIDE -- the long stories' kernel on a second stream (forked and joined by events, so
     // the caller's stream sees one ordered step and a stream capture takes both branches), one workgroup per CU, the short stories'
     // kernel two per CU instead of three.  Both are bound by vector issue and latency, not by a shared unit: together they fill
     // the issue slots either leaves empty alone.  Kernel trace on the 20-task set (262 000 queries, 9 % long): 433 us for both
     // (they end within 10 us of each other) against 370 + 98 us in sequence; forward 1.033 -> 0.994 ms (interleaved A/B).
     // Other splits measured: 3 + 1 per CU 1.012, 3 + 3 1.011, 2 + 2 1.003, 1 + 1 1.117 ms.  QMANN_NO_CORUN: in sequence.
-    if (n_query >= kCorunMinQueries && !qm_tuning().no_corun) {
+    if (n_query >= kQmCorunMinQueries && !qm_tuning().no_corun) {
         if (QmSide *sd = qm_side_stream(st)) {
             QM_HIP(hipEventRecord(sd->fork, st));
             QM_HIP(hipStreamWaitEvent(sd->side, sd->fork, 0));

@@ -451,6 +451,18 @@ k_split_by_length(const uint32_t *__restrict__ row_off, uint32_t n_query, uint32
     }
 }
 
+// [0] short count, [1] long count, then the two lists (n_query words each), in the scratch words of stream `owner`; the work
+// itself goes to `run_on` (the same stream, or the second one beside it -- rt.h::QmSplitReady)
+inline uint32_t *split_lists(const uint32_t *row_off, uint32_t n_query, uint32_t max_slots, hipStream_t owner, hipStream_t run_on)
+{
+    uint32_t *ws = qm_scratch_u32(2u + 2u * (size_t)n_query, owner);
+    if (!ws) return nullptr;
+    QM_HIP(hipMemsetAsync(ws, 0, 2 * sizeof(uint32_t), run_on));
+    const uint32_t blocks = (n_query + kSplitBlock - 1u) / kSplitBlock;
+    k_split_by_length<<<blocks < 1024u ? blocks : 1024u, kSplitBlock, 0, run_on>>>(row_off, n_query, max_slots, ws, ws + 2, ws + 2 + n_query);
+    return ws;
+}
+
 // what the quad kernel covers: the lean kernel's shapes (lean_supported) with word length 7 in every format of the launch, the
 // e^x softmax base without the shift-based normaliser, and planes of known size below 2 GiB (its buffer offsets are 32-bit)
 inline bool quad_supported(const HopArgs &a, int mode, uint32_t max_slots, uint32_t n_query)

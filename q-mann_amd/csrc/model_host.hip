@@ -428,11 +428,29 @@ int qmann_model_forward_words(qmann_model *m, const uint16_t *story_words, uint3
     DeviceScope on(m->device);
     int rc = ensure(m, rows_total, n_query, use_planes(m, max_slots));
     if (rc) return rc;
+    // Large batches: the question embedding on a second stream BESIDE the story embedding (forked and joined by events: one ordered
+    // step to the caller's stream, both branches to a stream capture).  The story kernels are latency-bound persistent grids that
+    // leave 32 .. 80 registers per SIMD lane unallocated; the question kernel is built to fit 32 (batch_io.hip) and is bound by its
+    // own stores, so its workgroups run in that room.  Launched AFTER the story kernel, so that one keeps its full residency.
+    QmSide *sd = (n_query >= kQmCorunMinQueries && !qm_tuning().no_corun) ? qm_side_stream((hipStream_t)stream) : nullptr;
+    if (sd) {
+        QM_HIP(hipEventRecord(sd->fork, (hipStream_t)stream));
+        QM_HIP(hipStreamWaitEvent(sd->side, sd->fork, 0));
+    }
     rc = qmann_embed_story_idx(&m->emb_net, story_words, rows_total, max_words, 1, m->t_a, m->t_c, m->keys, m->vals,
                                (size_t)rows_total * m->Dp, stream);
+    const int rc_q = qmann_embed_query_idx(&m->net, question_words, max_q_words, m->t_q, m->u0, n_query, sd ? (void *)sd->side : stream);
+    // ... and behind it, still beside the story embedding, the two index lists of a batch that the hop launch will split by
+    // story length (they depend on row_off alone; 12 us of memset + kernel + launch gaps off the caller's stream)
+    struct SplitScope { ~SplitScope() { qm_split_ready = QmSplitReady{nullptr, 0, 0, nullptr}; } } split_scope;
+    if (sd && !rc_q && qm_split_applies(rows_total, n_query, max_slots))
+        qm_split_ready = QmSplitReady{row_off, n_query, max_slots, qm_split_early(row_off, n_query, max_slots, (hipStream_t)stream, sd->side)};
+    if (sd) {                                            // (joined on every path: a capture must not end with an open branch)
+        QM_HIP(hipEventRecord(sd->join, sd->side));
+        QM_HIP(hipStreamWaitEvent((hipStream_t)stream, sd->join, 0));
+    }
     if (rc) return rc;
-    rc = qmann_embed_query_idx(&m->net, question_words, max_q_words, m->t_q, m->u0, n_query, stream);
-    if (rc) return rc;
+    if (rc_q) return rc_q;
     rc = hops_and_answer(m, rows_total, row_off, max_slots, n_query, answer, pred, cost, match, stream);
     return rc ? rc : qm_scope.rc();
 }

@@ -78,7 +78,7 @@ struct QmTuning {
     bool embed_per_hop;                               // QMANN_EMBED_PER_HOP: the joint-dictionary story embedding keeps one workgroup per hop (k_embed_story_mfma<4, 16>)
     bool answer_exact;                                // QMANN_ANSWER_EXACT: the float answer layer keeps the reference's serial order of additions (no bf16 MFMA form)
     bool no_quad_long;                                // QMANN_NO_QUAD_LONG: stories of 17 .. 64 rows keep the one-wavefront-per-query kernel (hops_quad.h's four-chunk form off)
-    bool no_corun;                                    // QMANN_NO_CORUN: the two kernels of a split batch run one after the other (no second stream)
+    bool no_corun;                                    // QMANN_NO_CORUN: no second stream (the two hop kernels of a split batch, the question embedding beside the story embedding: in sequence)
     bool no_quad;                                     // QMANN_NO_QUAD: short stories keep the one-wavefront-per-query kernel (hops_quad.h off)
     bool no_tight;                                    // QMANN_NO_TIGHT (set, any value): the lean kernels keep their four-wave (128-register) builds
     int lean_sparse;                                  // -1 = the launcher chooses, 0 / 1 forced
@@ -107,6 +107,14 @@ uint32_t *qm_scratch_u32(size_t words, hipStream_t stream);
 
 // A second stream beside `stream` with the two events that fork work onto it and join it back (cached per (device, stream)).
 struct QmSide { hipStream_t side; hipEvent_t fork, join; };
+// A batch's two index lists (stories of <= 16 rows / longer ones: hops_quad.h::k_split_by_length) prepared AHEAD of the hop launch:
+// the host model computes them on the second stream while the stories are embedded and names them here for the next hop
+// launch of this thread, which takes them if (row_off, n_query, max_slots) are the ones it was asked for.
+struct QmSplitReady { const uint32_t *row_off; uint32_t n_query, max_slots; uint32_t *ws; };
+extern thread_local QmSplitReady qm_split_ready;
+bool qm_split_applies(size_t rows_total, uint32_t n_query, uint32_t max_slots);          // (batch_hops.hip)
+uint32_t *qm_split_early(const uint32_t *row_off, uint32_t n_query, uint32_t max_slots, hipStream_t owner, hipStream_t run_on);
+constexpr uint32_t kQmCorunMinQueries = 32768;        // batches below run their kernels in sequence (measured equal at 32 768 and 65 536 queries, +4 % at 262 000)
 QmSide *qm_side_stream(hipStream_t stream);       // (tuning.hip)
 
 static inline unsigned qm_cdiv(unsigned a, unsigned b) { return (a + b - 1) / b; }

@@ -80,6 +80,8 @@ uint32_t *qm_scratch_u32(size_t words, hipStream_t stream)
     return b.p;
 }
 
+thread_local QmSplitReady qm_split_ready{nullptr, 0, 0, nullptr};
+
 QmSide *qm_side_stream(hipStream_t stream)
 {
     static std::mutex mu;
