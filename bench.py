@@ -1070,6 +1070,8 @@ def run_workload(args, name, dev, rank, world):
     survey_gbs = survey_bytes * B / (hop_ms * 1e-3) / 1e9
 
     lean = mode != 1 and S <= 64 and Dp == 64 and planes is None
+    # (csrc/hops_lean.h::launch_lean: stories of <= 16 rows four to a wavefront; uniform longer ones the four-chunk form with fixed-point scores)
+    short_kernel = "k_hops_quad" if (S <= 16 or mode == 2) else "k_hops_lean"
     if mode == 1:
         counted = "keys + values (float read-out streams both)"
     elif lean:
@@ -1082,7 +1084,8 @@ def run_workload(args, name, dev, rank, world):
         answer = {"ms": ans_ms, "int_ops": 2.0 * B * V * D, "tops": 2.0 * B * V * D / (ans_ms * 1e-3) / 1e12,
                   "mfma_int8_peak_tops": 5000.0}
     else:
-        answer = {"ms": ans_ms, "kernel": "k_answer_small (float, serial-order sums)" if V <= 256 else "k_answer (float, serial-order sums)",
+        answer = {"ms": ans_ms, "kernel": ("k_answer_mfma (float logits from a three-way bf16 split on the matrix cores, within 1e-5)" if V <= 256 and D <= 64
+                                           else "k_answer_small (float, serial-order sums)" if V <= 256 else "k_answer (float, serial-order sums)"),
                   "flop": 2.0 * B * V * D, "tflops": 2.0 * B * V * D / (ans_ms * 1e-3) / 1e12}
     out = {
         "metric": "queries/sec", "value": world * B * args.steps / elapsed, "unit": "queries/s",
@@ -1093,7 +1096,7 @@ def run_workload(args, name, dev, rank, world):
                    "queries_per_gpu": B, "format": f"Q{iwl}.{frac}", "attention_mode": mode,
                    "key_row_bytes": key_row_bytes, "answer_layer": wl["ans"], "dim_answer": V,
                    "parallelism": f"replicas x{world}, query-sharded"},
-        "roofline": {"bound": "hbm", "kernel": "k_hops_lean" if lean else KERNEL_OF_MODE[mode], "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": short_kernel if lean else KERNEL_OF_MODE[mode], "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes_per_launch": bytes_per_query * B, "bytes_per_query": bytes_per_query,
                      "bytes_per_query_padded_rows": bytes_per_query_padded,

@@ -14,6 +14,13 @@
  *
  * Inputs are DEVICE pointers (the reference's cuda_data_in pools, or word-index arrays); every call
  * takes a stream and returns without synchronising.  One object per host thread / stream.
+ *
+ * Batches of >= 32 768 queries use a SECOND stream of the library's own beside the caller's (one per device and
+ * caller stream, created on first use): the question embedding and the split of a mixed batch by story length run
+ * there while the stories are embedded, and the long stories' hop kernel runs there beside the short stories'.
+ * Every such branch is forked from and joined back into the caller's stream by events inside the call, so the
+ * caller still sees ONE ordered step on its stream, and a stream capture of a forward records both branches
+ * (tests/test_gpu_graph.py).  QMANN_NO_CORUN keeps everything on the caller's stream.
  */
 #ifndef QMANN_MODEL_H
 #define QMANN_MODEL_H
