@@ -886,44 +886,59 @@ k_embed_query(const float *__restrict__ question, const float *__restrict__ w_q,
 // words (fractional or negative entries -- position encoding --, more than 16 words) gets an empty list and is
 // recorded in `irr_rows` for the float kernel to redo.
 // ---------------------------------------------------------------------------
+// L lanes per row (16 / 32 / 64: the smallest that covers a dictionary of up to 64 words; longer rows take passes of 64),
+// 64 / L rows per wavefront.  A pass whose entries are all 0 or 1 -- every pass of a real bAbI row but the few with a word
+// said twice -- takes its positions from one ballot instead of a six-step scan.
+template <int L>
 __global__ void __launch_bounds__(kBlock)
 k_bow_to_words(const float *__restrict__ bow, uint32_t rows, uint32_t V, uint16_t *__restrict__ words,
                uint32_t *__restrict__ irr_rows, uint32_t *__restrict__ n_irr)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t buf[kWaves][16];
-    const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    for (size_t r = (size_t)blockIdx.x * kWaves + wave; r < rows; r += (size_t)gridDim.x * kWaves) {
-        if (lane < 16) buf[wave][lane] = 0xFFFFu;
+    constexpr int RPW = kWave / L;
+    constexpr uint64_t kGroupMask = L == 64 ? ~0ull : ((1ull << (L & 63)) - 1ull);
+    __shared__ __attribute__((aligned(16))) uint16_t buf[kWaves][RPW][16];
+    const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, sub = lane & (L - 1), grp = lane / L;
+    for (size_t r0 = ((size_t)blockIdx.x * kWaves + wave) * RPW; r0 < rows; r0 += (size_t)gridDim.x * kWaves * RPW) {
+        const size_t r = r0 + grp;
+        const bool r_ok = r < rows;
+        if (sub < 16) buf[wave][grp][sub] = 0xFFFFu;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         uint32_t base = 0;
         bool bad = false;
-        for (uint32_t c0 = 0; c0 < V; c0 += kWave) {                     // wavefront-uniform
-            const uint32_t k = c0 + lane;
-            const float x = k < V ? bow[r * V + k] : 0.0f;
+        for (uint32_t c0 = 0; c0 < V; c0 += L) {                         // wavefront-uniform
+            const uint32_t k = c0 + sub;
+            const float x = (r_ok && k < V) ? bow[r * V + k] : 0.0f;
             const bool nz = x != 0.0f;                                   // (a NaN is "non-zero" and fails the next test)
             const int c = (x >= 1.0f && x <= 16.0f) ? (int)x : 0;
             const bool ok = nz && c > 0 && (float)c == x;
             bad |= nz && !ok;
             const uint32_t cnt = ok ? (uint32_t)c : 0u;
-            uint32_t incl = cnt;
+            uint32_t pos;
+            if (!__any(cnt > 1u)) {
+                const uint64_t gm = (__ballot(ok) >> (grp * L)) & kGroupMask;
+                pos = base + (uint32_t)__popcll(gm & ((1ull << sub) - 1ull));
+                base += (uint32_t)__popcll(gm);
+            } else {
+                uint32_t incl = cnt;
 #pragma unroll
-            for (int o = 1; o < kWave; o <<= 1) {
-                const uint32_t t = __shfl_up(incl, o);
-                if (lane >= (uint32_t)o) incl += t;
+                for (int o = 1; o < L; o <<= 1) {
+                    const uint32_t t = __shfl_up(incl, o, L);
+                    if (sub >= (uint32_t)o) incl += t;
+                }
+                pos = base + incl - cnt;
+                base += __shfl(incl, L - 1, L);
             }
-            const uint32_t pos = base + incl - cnt;
             for (uint32_t t = 0; t < cnt; t++)
-                if (pos + t < 16u) buf[wave][pos + t] = (uint16_t)k;
-            base += __shfl(incl, kWave - 1);
+                if (pos + t < 16u) buf[wave][grp][pos + t] = (uint16_t)k;
         }
-        const bool irregular = __any(bad) || base > 16u;
+        const bool irregular = ((__ballot(bad) >> (grp * L)) & kGroupMask) != 0ull || base > 16u;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane < 8) ((uint32_t *)(words + r * 16))[lane] = irregular ? 0xFFFFFFFFu : ((const uint32_t *)buf[wave])[lane];
-        if (irregular && lane == 0) irr_rows[atomicAdd(n_irr, 1u)] = (uint32_t)r;
-        __builtin_amdgcn_wave_barrier();                                 // the next row rewrites the buffer
+        if (r_ok && sub < 8) ((uint32_t *)(words + r * 16))[sub] = irregular ? 0xFFFFFFFFu : ((const uint32_t *)buf[wave][grp])[sub];
+        if (r_ok && irregular && sub == 0) irr_rows[atomicAdd(n_irr, 1u)] = (uint32_t)r;
+        __builtin_amdgcn_wave_barrier();                                 // the next rows rewrite the buffer
     }
 }
 
@@ -2063,8 +2078,13 @@ int qmann_bow_to_words(const float *bow, uint32_t rows, uint32_t dim_input, uint
     if ((!bow && rows) || !words || !irregular_rows || !n_irregular) return QMANN_EINVAL;
     if (dim_input == 0 || dim_input >= 0xFFFFu) return QMANN_ERANGE;          // 0xFFFF marks an unused slot
     if (rows == 0) return QMANN_OK;
-    const uint32_t need = (rows + kWaves - 1) / kWaves;
-    k_bow_to_words<<<need < 16384u ? need : 16384u, kBlock, 0, (hipStream_t)stream>>>(bow, rows, dim_input, words, irregular_rows, n_irregular);
+    auto go = [&](auto kernel, uint32_t rows_per_wave) {
+        const uint32_t per_block = kWaves * rows_per_wave, need = (rows + per_block - 1) / per_block;
+        kernel<<<need < 16384u ? need : 16384u, kBlock, 0, (hipStream_t)stream>>>(bow, rows, dim_input, words, irregular_rows, n_irregular);
+    };
+    if (dim_input <= 16u) go(k_bow_to_words<16>, 4u);
+    else if (dim_input <= 32u) go(k_bow_to_words<32>, 2u);
+    else go(k_bow_to_words<64>, 1u);
     QM_LAUNCH_CHECK();
     return qm_scope.rc();
 }

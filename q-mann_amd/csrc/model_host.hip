@@ -482,21 +482,35 @@ int qmann_model_forward_bow(qmann_model *m, const float *story, uint32_t rows_to
     uint32_t *n_irr = m->bow_irr, *irr_s = m->bow_irr + 2, *irr_q = irr_s + rows_total;
     uint16_t *sw = m->bow_words, *qw = m->bow_words + (size_t)rows_total * 16;
     QM_HIP(hipMemsetAsync(n_irr, 0, 2 * sizeof(uint32_t), st));
+    // Both conversions first, then -- as in qmann_model_forward_words -- the question embedding and the length split of a mixed
+    // batch on the second stream beside the story embedding.  (The question's CONVERSION beside the story's was measured too:
+    // 0.735 against 0.714 ms on task 1 -- its workgroups sit on the CUs when the story embedding's persistent grid arrives.)
+    const size_t hop_stride = (size_t)rows_total * m->Dp;
     rc = qmann_bow_to_words(story, rows_total, m->V, sw, irr_s, n_irr, stream);
     if (rc) return rc;
     rc = qmann_bow_to_words(question, n_query, m->V, qw, irr_q, n_irr + 1, stream);
     if (rc) return rc;
-    const size_t hop_stride = (size_t)rows_total * m->Dp;
+    QmSide *sd = (n_query >= kQmCorunMinQueries && !qm_tuning().no_corun) ? qm_side_stream(st) : nullptr;
+    void *qs = sd ? (void *)sd->side : stream;
+    if (sd) {
+        QM_HIP(hipEventRecord(sd->fork, st));
+        QM_HIP(hipStreamWaitEvent(sd->side, sd->fork, 0));
+    }
     rc = qmann_embed_story_idx(&m->emb_net, sw, rows_total, 16, /*time_last=*/0, m->t_a, m->t_c, m->keys, m->vals, hop_stride, stream);
-    if (rc) return rc;
-    rc = qmann_embed_story_rows(&m->emb_net, story, rows_total, irr_s, n_irr, m->w_a, m->w_c, m->keys, m->vals, hop_stride, stream);
-    if (rc) return rc;
+    if (!rc) rc = qmann_embed_story_rows(&m->emb_net, story, rows_total, irr_s, n_irr, m->w_a, m->w_c, m->keys, m->vals, hop_stride, stream);
     qmann_net qnet = m->net;
     qnet.en_pe = 0;                                     // (position weights, if any, are IN the rows: such rows take the float kernel)
-    rc = qmann_embed_query_idx(&qnet, qw, 16, m->t_q, m->u0, n_query, stream);
+    int rc_q = qmann_embed_query_idx(&qnet, qw, 16, m->t_q, m->u0, n_query, qs);
+    if (!rc_q) rc_q = qmann_embed_query_rows(&m->net, question, irr_q, n_irr + 1, m->w_q, m->u0, n_query, qs);
+    struct SplitScope { ~SplitScope() { qm_split_ready = QmSplitReady{nullptr, 0, 0, nullptr}; } } split_scope;
+    if (sd && !rc_q && qm_split_applies(rows_total, n_query, max_slots))
+        qm_split_ready = QmSplitReady{row_off, n_query, max_slots, qm_split_early(row_off, n_query, max_slots, st, sd->side)};
+    if (sd) {                                            // (joined on every path: a capture must not end with an open branch)
+        QM_HIP(hipEventRecord(sd->join, sd->side));
+        QM_HIP(hipStreamWaitEvent(st, sd->join, 0));
+    }
     if (rc) return rc;
-    rc = qmann_embed_query_rows(&m->net, question, irr_q, n_irr + 1, m->w_q, m->u0, n_query, stream);
-    if (rc) return rc;
+    if (rc_q) return rc_q;
     rc = hops_and_answer(m, rows_total, row_off, max_slots, n_query, answer, pred, cost, match, stream);
     return rc ? rc : qm_scope.rc();
 }

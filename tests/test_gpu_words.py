@@ -450,6 +450,111 @@ def test_bow_to_words_lists(env):
     assert (w[[1, 2, 4]] == 0xFFFF).all()
 
 
+@pytest.mark.parametrize("V", [1, 7, 16, 17, 30, 32, 33, 64, 65, 130, 238])
+def test_bow_to_words_random_rows_every_group_width(env, V):
+    """dictionaries of <= 16 / <= 32 words pack four / two rows into a wavefront, longer ones take passes of 64 lanes
+    (csrc/batch_io.hip::k_bow_to_words<L>); rows with a repeated word take the scan branch, the others the ballot branch"""
+    import ctypes as C
+    torch = env.torch
+    import qmann_amd.abi as abi
+    rng = np.random.default_rng(1000 + V)
+    R = 5003
+    bow = np.zeros((R, V), np.float32)
+    kind = rng.integers(0, 10, R)
+    for r in range(R):
+        n = int(rng.integers(0, min(V, 9) + 1))
+        idx = rng.choice(V, n, replace=False)
+        bow[r, idx] = 1.0
+        if kind[r] == 0 and n:
+            bow[r, idx[0]] = float(rng.integers(2, 5))                 # a word said several times
+        elif kind[r] == 1 and n:
+            bow[r, idx[0]] = 0.25                                      # fractional: irregular
+        elif kind[r] == 2 and n:
+            bow[r, idx[0]] = 17.0                                      # beyond a list's 16 entries
+        elif kind[r] == 3 and n:
+            bow[r, idx[0]] = np.nan
+    exp = np.full((R, 16), 0xFFFF, np.uint16)
+    irregular = []
+    for r in range(R):
+        row = bow[r]
+        nzk = np.flatnonzero(row != 0)                                 # (NaN != 0)
+        good = all(1.0 <= row[k] <= 16.0 and row[k] == int(row[k]) for k in nzk)
+        lst = [k for k in nzk for _ in range(int(row[k]))] if good else []
+        if not good or len(lst) > 16:
+            irregular.append(r)
+        else:
+            exp[r, :len(lst)] = lst
+    d = torch.from_numpy(bow).to(env.dev)
+    words = torch.zeros((R, 16), dtype=torch.int16, device=env.dev)
+    irr = torch.zeros(R, dtype=torch.int32, device=env.dev)
+    n = torch.zeros(1, dtype=torch.int32, device=env.dev)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    assert abi.lib.qmann_bow_to_words(p(d), R, V, p(words), p(irr), p(n), None) == 0
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(words.cpu().numpy().view(np.uint16), exp)
+    assert sorted(irr.cpu().numpy()[:int(n.item())].tolist()) == irregular
+    assert 0 < len(irregular) < R
+
+
+@pytest.mark.parametrize("mode,nb,V", [(2, 8, 30), (3, 8, 238), (11, 4, 40)])
+def test_large_batches_on_two_streams_equal_one_stream(env, monkeypatch, mode, nb, V):
+    """>= 32 768 queries: the question branch and the length split run on the library's second stream beside the story embedding,
+    the two hop kernels of the split batch side by side (csrc/model_host.hip, csrc/hops_lean.h); QMANN_NO_CORUN keeps one stream.
+    Both wire formats, both settings, three forwards back to back: the same predictions, final states, match counts."""
+    torch, model = env.torch, env.model
+    rng = np.random.default_rng(77 + mode)
+    D, rep = 60, 20
+    sw1, qw1, n1 = random_stories(rng, 2000, V, V - 12, 8, [1, 2, 3, 5, 8, 10, 13, 4, 6, 20, 40, 7])       # mean 9.9 rows, 1 in 6 long
+    sw, qw, n_sen = np.tile(sw1, (rep, 1)), np.tile(qw1, (rep, 1)), np.tile(n1, rep)
+    B = len(n_sen)
+    assert B >= 32768
+    story, ques = np.tile(words_to_bow(sw1, V, True), (rep, 1)), np.tile(words_to_bow(qw1, V, False), (rep, 1))
+    cfg = model.babi_cfg(V, mode, 0, iwl=5, en_mq=(mode == 3))
+    cfg["num_bit"] = nb
+    H = cfg["n_hop"]
+    wts = {"w_q": rng.normal(0, 1.0, (D, V)).astype(np.float32), "w_ans": rng.normal(0, 0.3, (V, D)).astype(np.float32),
+           "w_a": [rng.normal(0, 1.0, (D, V)).astype(np.float32) for _ in range(H)],
+           "w_c": [rng.normal(0, 1.0, (D, V)).astype(np.float32) for _ in range(H)],
+           "w_h": [rng.normal(0, 1.0, (D, D)).astype(np.float32) for _ in range(H)]}
+    hm = model.HostModel(cfg, wts)
+    d_sw = torch.from_numpy(sw.view(np.int16)).to(env.dev); d_qw = torch.from_numpy(qw.view(np.int16)).to(env.dev)
+    d_st = torch.from_numpy(story).to(env.dev); d_qu = torch.from_numpy(ques).to(env.dev)
+    d_ro = torch.from_numpy(np.concatenate([[0], np.cumsum(n_sen)]).astype(np.int32)).to(env.dev)
+    d_ans = torch.from_numpy(rng.integers(0, V, B).astype(np.int32)).to(env.dev)
+    cap = int(n_sen.max())
+
+    def run(fmt):
+        outs = []
+        for _ in range(3):                                             # back to back: the fork / join events are reused
+            if fmt == "words":
+                pred, cost, match = hm.forward_words(d_sw, d_qw, d_ro, cap, d_ans)
+            else:
+                pred, cost, match = hm.forward_bow(d_st, d_qu, d_ro, cap, d_ans)
+            outs.append((pred, match))
+        torch.cuda.synchronize()
+        u = hm.last_u(B).cpu().numpy()
+        return [(p.cpu().numpy(), int(m.item())) for p, m in outs], u
+
+    got = {}
+    for setting in ("two streams", "one stream"):
+        if setting == "one stream":
+            monkeypatch.setenv("QMANN_NO_CORUN", "1")
+        model.abi.lib.qmann_tuning_reload()
+        for fmt in ("words", "bow"):
+            got[(setting, fmt)] = run(fmt)
+    monkeypatch.delenv("QMANN_NO_CORUN")
+    model.abi.lib.qmann_tuning_reload()
+    hm.close()
+    ref_outs, ref_u = got[("one stream", "words")]
+    assert len({int(x) for x in ref_outs[0][0]}) > 1
+    for key, (outs, u) in got.items():
+        for p, m in outs:
+            assert np.array_equal(p, ref_outs[0][0]) and m == ref_outs[0][1], key
+        assert np.array_equal(u, ref_u), key
+    p0 = ref_outs[0][0].reshape(rep, -1)
+    assert (p0 == p0[0]).all()                                         # (the replicas of a story answer alike)
+
+
 def test_record_file_to_predictions(env, tmp_path):
     """include/qmann_dataset.h end to end: a record file in the reference's format -> word lists -> the forward; equal to the
     float bag-of-words chain on the rows the lists stand for"""
