@@ -7,7 +7,11 @@
  * memories stored as true int8 codes of the reference's Q(iwl.frac) grid
  * values (lossless for word length 8), the multi-hop loop fused
  * into one kernel.  Plain C ABI: device pointers, sizes, an opaque stream
- * handle (hipStream_t passed as void*; NULL = the null stream).
+ * handle (hipStream_t passed as void*; NULL = the null stream).  Every call is
+ * asynchronous and, to its caller, ONE ordered step on that stream; a hop launch
+ * over >= 32 768 stories of mixed length puts one of its two kernels on a second
+ * stream of the library's own, forked from and joined back into the caller's
+ * stream by events inside the call (qmann_model.h; QMANN_NO_CORUN turns it off).
  *
  * Return value of every function: 0 on success, a negative QMANN_E* code on a
  * caller error (nothing is launched) or QMANN_EHIP when the HIP runtime fails
