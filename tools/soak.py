@@ -15,6 +15,19 @@ import test_gpu_words as TW                                  # noqa: E402
 import test_gpu_batch as TB                                  # noqa: E402
 import test_gpu_ops as TO                                    # noqa: E402
 import test_gpu_mid as TM                                    # noqa: E402
+import test_gpu_quad as TQ                                   # noqa: E402
+
+
+class _NoPatch:
+    """pytest's monkeypatch for three_paths outside pytest: environment switches set and removed by hand"""
+    def __init__(self, model):
+        self.model = model
+
+    def setenv(self, k, v):
+        os.environ[k] = v
+
+    def delenv(self, k, raising=True):
+        os.environ.pop(k, None)
 
 
 def main():
@@ -45,7 +58,7 @@ def main():
     print("soak seed base", seed, flush=True)
     while time.time() - t0 < budget:
         rng = np.random.default_rng(seed + n)
-        kind = int(os.environ["SOAK_KIND"]) if os.environ.get("SOAK_KIND") else n % 11       # SOAK_KIND=9: one kind only
+        kind = int(os.environ["SOAK_KIND"]) if os.environ.get("SOAK_KIND") else (11 if n % 97 == 96 else n % 11)       # SOAK_KIND=9: one kind only; kind 11 (large batches) once per 97 cases
         if kind == 0:                                        # lean kernel vs general kernel, random formats (fixed-point attention)
             def fmt(lo=2, hi=7):
                 wl = int(rng.integers(lo, hi + 1)); iwl = int(rng.integers(0, wl + 1))
@@ -186,6 +199,18 @@ def main():
             except AssertionError:
                 print("FAILED mixed-quantisation hamming case", n, "seed base", seed, "args", dict(mode=mode, D=D, S_list=S_list, B=Bh, seed=seed + n,
                       iwl=ia, num_bit=nb, sigma=sg, from_bytes=from_bytes), flush=True)
+                raise
+        if kind == 11:                                       # >= 32 768 stories of mixed length: split by length, the two hop kernels side by side on two streams
+            mode, nb = TQ.MODES[int(rng.integers(0, len(TQ.MODES)))]
+            n_short, n_long = int(rng.integers(3, 12)), int(rng.integers(0, 4))
+            S_list = [int(x) for x in rng.integers(0, 17, n_short)] + [int(x) for x in rng.integers(17, 65, n_long)]
+            Bq = int(rng.integers(32768, 50000))
+            cap = 64 if (n_long == 0 or rng.integers(0, 2)) else None
+            try:
+                TQ.three_paths(env, _NoPatch(model), TQ.cfg_of(mode, nb=nb, iwl=int(rng.integers(3, 7))), B=Bq, S_list=S_list, seed=seed + n,
+                               max_slots=cap, repeat=2)
+            except AssertionError:
+                print("FAILED large-batch case", n, "seed base", seed, "args", dict(mode=mode, nb=nb, S_list=S_list, B=Bq, max_slots=cap), flush=True)
                 raise
         n += 1
         if n % 100 == 0:
