@@ -52,7 +52,23 @@ struct LeanArgs {
     uint32_t lm_in_lds;       // 1: the linear maps are staged in LDS
     const uint32_t *list;     // the queries to run, by index (the long stories of a batch whose short ones take hops_quad.h); nullptr: all
     const uint32_t *n_list;   // device word with the list's length
+    const uint32_t *n_other;  // side-by-side launch (launch_lean): device word with the OTHER list's length; nullptr otherwise
 };
+
+// Two kernels side by side (launch_lean: a batch split by story length, >= 32 768 queries): each is launched with every
+// workgroup it could have resident -- three per CU for the short stories' kernel, two for the long stories' -- and trims itself
+// here, once both list lengths are known ON THE DEVICE: workgroups past the returned count leave at once and their room goes to
+// the other kernel.  A long story costs about 2.7 short ones (4.2 against 1.55 ns per query, each kernel alone on the 20-task
+// set).  Long stories' share of the work up to 0.45: one workgroup per CU for them, two for the short ones (the 20-task set:
+// 9 % long, share 0.21; measured best of 3+1 / 3+3 / 2+2 / 1+1 / 2+1); below 0.05 the short kernel keeps all three.  Above
+// 0.45 nobody trims: the two full grids then run mostly one after the other, as without the second stream -- no mix of
+// lengths makes the pair slower than that.
+__device__ __forceinline__ uint32_t corun_groups(uint32_t n_short, uint32_t n_long, uint32_t grid, bool long_side)
+{
+    const float cl = 2.7f * (float)n_long, share = cl / (cl + (float)n_short + 1.0f);
+    if (long_side) return share <= 0.45f ? grid / 2u : grid;
+    return (share >= 0.05f && share <= 0.45f) ? grid - grid / 3u : grid;
+}
 
 // Wavefront reductions on the DPP network (row shifts, then the two row broadcasts; the total lands in lane 63 and is
 // handed to every lane through an SGPR).  A shuffle-based butterfly costs no vector instructions either, but each of its
@@ -454,11 +470,16 @@ k_hops_lean(const HopArgs a, const LeanArgs la)
     const uint32_t wslice = la.rows_pad * 64u + kLwBytes;
     uint8_t *vt = wbase + wave * wslice;                                // value tile
     uint8_t *lw = vt + la.rows_pad * 64u;                               // small arrays
+    uint32_t n_groups = gridDim.x;
+    if (LIST && la.n_other) {                                           // (side by side with the short stories' kernel)
+        n_groups = corun_groups(*la.n_other, *la.n_list, gridDim.x, true);
+        if (blockIdx.x >= n_groups) return;
+    }
     lean_stage_tables(a, la, etab, lmap, tid, kLeanBlock);
     __syncthreads();
 
     // (rows_total carries the query count, < 2^24: qmann_hops_i8; with an index list the items are list[0 .. *n_list))
-    const uint32_t q_stride = gridDim.x * kLeanWaves, n_query = LIST ? *la.n_list : a.rows_total;
+    const uint32_t q_stride = n_groups * kLeanWaves, n_query = LIST ? *la.n_list : a.rows_total;
     // The next query's first key tile and its u0 are requested during the current query's last hop (its row offsets
     // a query earlier still), so a wavefront does not sit through a cold HBM round trip at every query start.
     uint32_t qi = blockIdx.x * kLeanWaves + wave;                       // item index; q: the query it names
@@ -559,10 +580,10 @@ inline bool lean_supported(const HopArgs &a, uint32_t max_slots, uint32_t key_ro
 
 template <int MODE, int NB, bool W7, bool SPARSE>
 inline void launch_lean_w(HopArgs a, uint32_t max_slots, uint32_t n_query, hipStream_t st, const uint32_t *list = nullptr,
-                          const uint32_t *n_list = nullptr, uint32_t per_cu_cap = 0)
+                          const uint32_t *n_list = nullptr, const uint32_t *n_other = nullptr)
 {
     LeanArgs la{};
-    la.list = list; la.n_list = n_list;
+    la.list = list; la.n_list = n_list; la.n_other = n_other;
     la.rows_pad = SPARSE ? 0u : ((max_slots ? max_slots : 1u) + 15u) & ~15u;       // (SPARSE: no value tile)
     la.exp_table = (MODE == kModeFixed && a.softmax_base == QMANN_SOFTMAX_EXP && !a.softmax_shift && !a.en_att_scale) ? 1u : 0u;
     la.lm_in_lds = a.en_lin_map ? 1u : 0u;
@@ -577,8 +598,7 @@ inline void launch_lean_w(HopArgs a, uint32_t max_slots, uint32_t n_query, hipSt
     const uint32_t need = (n_query + kLeanWaves - 1) / kLeanWaves;
     auto go = [&](auto kernel, int wps) {
         if (lds > kLdsDefaultLimit) QM_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        uint32_t resident = qm_resident_groups(kLeanWaves, (unsigned)wps, lds);
-        if (per_cu_cap && resident > per_cu_cap * qm_cu_count()) resident = per_cu_cap * qm_cu_count();
+        const uint32_t resident = qm_resident_groups(kLeanWaves, (unsigned)wps, lds);
         kernel<<<need < resident ? need : resident, kLeanBlock, lds, st>>>(a, la);
     };
     // the six-wave build where it buys a third workgroup per CU (every attention mode: the Hamming forms need 81-91 registers in
@@ -593,7 +613,7 @@ inline void launch_lean_w(HopArgs a, uint32_t max_slots, uint32_t n_query, hipSt
 
 template <int MODE, int NB>
 inline void launch_lean_all(const HopArgs &a, uint32_t max_slots, uint32_t n_query, hipStream_t st, const uint32_t *list = nullptr,
-                            const uint32_t *n_list = nullptr, uint32_t per_cu_cap = 0);
+                            const uint32_t *n_list = nullptr, const uint32_t *n_other = nullptr);
 
 // Short-memory launches: stories of at most 16 rows take the four-queries-per-wavefront kernel (hops_quad.h), longer ones the
 // one-wavefront-per-query kernel below.  A batch whose bound allows both (the 20-task set: up to 64 rows, 91 % of the stories
@@ -604,7 +624,7 @@ inline void launch_lean(const HopArgs &a, uint32_t max_slots, uint32_t n_query, 
 {
     if (!quad_supported(a, MODE, max_slots, n_query)) { launch_lean_all<MODE, NB>(a, max_slots, n_query, st); return; }
     if (max_slots <= kQuadSlots) {
-        launch_quad<MODE, NB, 1>(a, QuadArgs{nullptr, nullptr, n_query}, n_query, st);
+        launch_quad<MODE, NB, 1>(a, QuadArgs{nullptr, nullptr, n_query, nullptr, nullptr}, n_query, st);
         return;
     }
     // A batch is split only where short stories can be many: mean length (known from the plane size; tied hops carry none and
@@ -615,7 +635,7 @@ inline void launch_lean(const HopArgs &a, uint32_t max_slots, uint32_t n_query, 
         // (fixed-point scores only: the form is 2 % ahead of the lean kernel at 50 rows -- 7 % fewer vector instructions per query,
         // four wavefronts per SIMD against six -- which does not pay for ten more instantiations in the Hamming modes)
         if constexpr (MODE == kModeFixed) {
-            if (!qm_tuning().no_quad_long) { launch_quad<MODE, NB, 4>(a, QuadArgs{nullptr, nullptr, n_query}, n_query, st); return; }
+            if (!qm_tuning().no_quad_long) { launch_quad<MODE, NB, 4>(a, QuadArgs{nullptr, nullptr, n_query, nullptr, nullptr}, n_query, st); return; }
         }
         launch_lean_all<MODE, NB>(a, max_slots, n_query, st);
         return;
@@ -629,30 +649,45 @@ inline void launch_lean(const HopArgs &a, uint32_t max_slots, uint32_t n_query, 
     if (!ws) ws = split_lists(a.row_off, n_query, max_slots, st, st);
     if (!ws) { launch_lean_all<MODE, NB>(a, max_slots, n_query, st); return; }
     // Large batches: the two kernels SIDE BY SIDE -- the long stories' kernel on a second stream (forked and joined by events, so
-    // the caller's stream sees one ordered step and a stream capture takes both branches), one workgroup per CU, the short stories'
-    // kernel two per CU instead of three.  Both are bound by vector issue and latency, not by a shared unit: together they fill
-    // the issue slots either leaves empty alone.  Kernel trace on the 20-task set (262 000 queries, 9 % long): 433 us for both
-    // (they end within 10 us of each other) against 370 + 98 us in sequence; forward 1.033 -> 0.994 ms (interleaved A/B).
-    // Other splits measured: 3 + 1 per CU 1.012, 3 + 3 1.011, 2 + 2 1.003, 1 + 1 1.117 ms.  QMANN_NO_CORUN: in sequence.
+    // the caller's stream sees one ordered step and a stream capture takes both branches).  Both are bound by vector issue and
+    // latency, not by a shared unit: together they fill the issue slots either leaves empty alone.  How the CUs' room is divided
+    // is decided on the device from the two list lengths (corun_groups above).  Kernel trace on the 20-task set (262 000
+    // queries, 9 % long): 433 us for both (they end within 10 us of each other) against 370 + 98 us in sequence; forward
+    // 1.033 -> 0.994 ms (interleaved A/B).  The pair pays where there is enough to overlap (tools/corun_mix.py, 6- and 30-row
+    // stories, 262 144 queries, side by side against in sequence: 5 % long -0.9 %, 9 % -6.7 %, 15 % -5.0 %): it is taken when the
+    // LAST split batch on this stream -- its short-story kernel stores the two counts to pinned host memory, no copy, no
+    // synchronisation -- gave the long stories 0.12 .. 0.45 of the work; unknown (first batch) or outside (the same tool: 0 / 1 /
+    // 25 / 35 % long: +-0.2 %): in sequence.  QMANN_NO_CORUN: always in sequence.
+    uint32_t *publish = nullptr;
     if (n_query >= kQmCorunMinQueries && !qm_tuning().no_corun) {
-        if (QmSide *sd = qm_side_stream(st)) {
+        QmSide *sd = qm_side_stream(st);
+        bool pays = false;
+        if (sd) publish = (uint32_t *)sd->last_counts;
+        if (sd) {
+            const uint32_t n_short = sd->last_counts[0], n_long = sd->last_counts[1];
+            if (n_short != 0xFFFFFFFFu && n_long != 0xFFFFFFFFu) {
+                const float cl = 2.7f * (float)n_long, share = cl / (cl + (float)n_short + 1.0f);
+                pays = share >= 0.12f && share <= 0.45f;
+            }
+        }
+        if (pays) {
             QM_HIP(hipEventRecord(sd->fork, st));
             QM_HIP(hipStreamWaitEvent(sd->side, sd->fork, 0));
-            launch_lean_all<MODE, NB>(a, max_slots, n_query, sd->side, ws + 2 + n_query, ws + 1, 1u);
+            launch_lean_all<MODE, NB>(a, max_slots, n_query, sd->side, ws + 2 + n_query, ws + 1, ws);
             QM_HIP(hipEventRecord(sd->join, sd->side));
-            launch_quad<MODE, NB, 1>(a, QuadArgs{ws + 2, ws, n_query}, n_query, st, 2u);
+            launch_quad<MODE, NB, 1>(a, QuadArgs{ws + 2, ws, n_query, ws + 1, publish}, n_query, st);
             QM_HIP(hipStreamWaitEvent(st, sd->join, 0));
             return;
         }
     }
-    launch_quad<MODE, NB, 1>(a, QuadArgs{ws + 2, ws, n_query}, n_query, st);
+    launch_quad<MODE, NB, 1>(a, QuadArgs{ws + 2, ws, n_query, nullptr, publish}, n_query, st);
     // (the few long stories of such a batch: the lean kernel -- the four-chunk quad form measured 3 % SLOWER on the joint forward)
     launch_lean_all<MODE, NB>(a, max_slots, n_query, st, ws + 2 + n_query, ws + 1);
 }
 
 template <int MODE, int NB>
 inline void launch_lean_all(const HopArgs &a, uint32_t max_slots, uint32_t n_query, hipStream_t st, const uint32_t *list, const uint32_t *n_list,
-                            uint32_t per_cu_cap)
+                            const uint32_t *n_other)
 {
     bool w7 = true;
     for (uint32_t h = 0; h < a.n_hop; h++)
@@ -680,8 +715,8 @@ inline void launch_lean_all(const HopArgs &a, uint32_t max_slots, uint32_t n_que
             sparse = true;
     }
     if (qm_tuning().lean_sparse >= 0) sparse = qm_tuning().lean_sparse == 1;
-    if (w7) { if (sparse) launch_lean_w<MODE, NB, true, true>(a, max_slots, n_query, st, list, n_list, per_cu_cap); else launch_lean_w<MODE, NB, true, false>(a, max_slots, n_query, st, list, n_list, per_cu_cap); }
-    else { if (sparse) launch_lean_w<MODE, NB, false, true>(a, max_slots, n_query, st, list, n_list, per_cu_cap); else launch_lean_w<MODE, NB, false, false>(a, max_slots, n_query, st, list, n_list, per_cu_cap); }
+    if (w7) { if (sparse) launch_lean_w<MODE, NB, true, true>(a, max_slots, n_query, st, list, n_list, n_other); else launch_lean_w<MODE, NB, true, false>(a, max_slots, n_query, st, list, n_list, n_other); }
+    else { if (sparse) launch_lean_w<MODE, NB, false, true>(a, max_slots, n_query, st, list, n_list, n_other); else launch_lean_w<MODE, NB, false, false>(a, max_slots, n_query, st, list, n_list, n_other); }
 }
 
 }  // namespace

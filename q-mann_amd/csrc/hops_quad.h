@@ -35,6 +35,8 @@ struct QuadArgs {
     const uint32_t *list;                           // query indices (nullptr: queries 0 .. n_items - 1 as they are)
     const uint32_t *n_list;                         // device word with the list's length (nullptr: n_items)
     uint32_t n_items;
+    const uint32_t *n_other;                        // side-by-side launch (hops_lean.h::corun_groups): the other list's length; nullptr otherwise
+    uint32_t *publish;                              // pinned host words that receive n_list[0 .. 1] (both list lengths: rt.h::QmSide::last_counts), or nullptr
 };
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
@@ -127,11 +129,18 @@ k_hops_quad(const HopArgs a, const LeanArgs la, const QuadArgs qa)
     float *etab = (float *)smem;                                        // [H][256]
     uint8_t *lmap = smem + (la.exp_table ? H * 1024u : 0u);             // [H][64][3][64] (lean_stage_tables)
     uint8_t *lw = lmap + (la.lm_in_lds ? H * kLmHopBytes : 0u) + (wave * 4u + g) * kQwBytes;      // this lane's query: its constant images
+    // (a 25-us copy on the stream otherwise: the launcher's hint costs one lane two stores)
+    if (qa.publish && blockIdx.x == 0 && tid == 0) { qa.publish[0] = qa.n_list[0]; qa.publish[1] = qa.n_list[1]; }
+    uint32_t n_groups = gridDim.x;
+    if (qa.n_other) {                                                   // (side by side with the long stories' kernel)
+        n_groups = corun_groups(*qa.n_list, *qa.n_other, gridDim.x, false);
+        if (blockIdx.x >= n_groups) return;
+    }
     lean_stage_tables(a, la, etab, lmap, tid, kQuadBlock);
     __syncthreads();
 
     const uint32_t n_items = qa.n_list ? *qa.n_list : qa.n_items;
-    const uint32_t stride = gridDim.x * kQuadWaves * 4u;
+    const uint32_t stride = n_groups * kQuadWaves * 4u;
     const uint32_t cap = a.max_slots < kSlots ? a.max_slots : kSlots;
     uint32_t i0 = (blockIdx.x * kQuadWaves + wave) * 4u;
     if (i0 >= n_items) return;
@@ -481,7 +490,7 @@ inline bool quad_supported(const HopArgs &a, int mode, uint32_t max_slots, uint3
 }
 
 template <int MODE, int NB, int NC>
-inline void launch_quad(HopArgs a, const QuadArgs &qa, uint32_t n_max, hipStream_t st, uint32_t per_cu_cap = 0)
+inline void launch_quad(HopArgs a, const QuadArgs &qa, uint32_t n_max, hipStream_t st)
 {
     LeanArgs la{};
     la.rows_pad = 0;
@@ -492,8 +501,7 @@ inline void launch_quad(HopArgs a, const QuadArgs &qa, uint32_t n_max, hipStream
     constexpr int wps = NC == 1 ? kQuadWps : kQuadWpsLong;
     auto kernel = k_hops_quad<MODE, NB, wps, NC>;
     if (lds > kLdsDefaultLimit) QM_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    uint32_t resident = qm_resident_groups(kQuadWaves, (unsigned)wps, lds);
-    if (per_cu_cap && resident > per_cu_cap * qm_cu_count()) resident = per_cu_cap * qm_cu_count();
+    const uint32_t resident = qm_resident_groups(kQuadWaves, (unsigned)wps, lds);
     kernel<<<need < resident ? need : resident, kQuadBlock, lds, st>>>(a, la, qa);
 }
 

@@ -106,7 +106,14 @@ static inline unsigned qm_resident_groups(unsigned waves, unsigned waves_per_sim
 uint32_t *qm_scratch_u32(size_t words, hipStream_t stream);
 
 // A second stream beside `stream` with the two events that fork work onto it and join it back (cached per (device, stream)).
-struct QmSide { hipStream_t side; hipEvent_t fork, join; };
+struct QmSide {
+    hipStream_t side;
+    hipEvent_t fork, join;
+    // pinned host words: the two list lengths (short, long) of the LAST batch split by length on this stream, stored by its
+    // short-story kernel (hops_quad.h: QuadArgs::publish) -- no copy, no synchronisation; 0xFFFFFFFF until one has landed.  A hint for the next launch's choice between
+    // "side by side" and "in sequence" only -- never a result.
+    volatile uint32_t *last_counts;
+};
 // A batch's two index lists (stories of <= 16 rows / longer ones: hops_quad.h::k_split_by_length) prepared AHEAD of the hop launch:
 // the host model computes them on the second stream while the stories are embedded and names them here for the next hop
 // launch of this thread, which takes them if (row_off, n_query, max_slots) are the ones it was asked for.

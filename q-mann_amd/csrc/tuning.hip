@@ -94,7 +94,9 @@ QmSide *qm_side_stream(hipStream_t stream)
     QmSide sd{};
     if (hipStreamCreateWithFlags(&sd.side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) != hipSuccess ||
+        hipHostMalloc((void **)&sd.last_counts, 2 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    sd.last_counts[0] = sd.last_counts[1] = 0xFFFFFFFFu;
     return &(sides[{dev, stream}] = sd);
 }
 
