@@ -622,7 +622,14 @@ inline void launch_lean_all(const HopArgs &a, uint32_t max_slots, uint32_t n_que
 template <int MODE, int NB>
 inline void launch_lean(const HopArgs &a, uint32_t max_slots, uint32_t n_query, hipStream_t st)
 {
-    if (!quad_supported(a, MODE, max_slots, n_query)) { launch_lean_all<MODE, NB>(a, max_slots, n_query, st); return; }
+    // Small batches keep one story per wavefront: the GPU holds 6 144 wavefronts at once, so up to a few thousand stories each has
+    // one of its own and the batch takes ONE story's latency, where four stories per wavefront take their linear maps in turn
+    // (task-1 forward, interleaved: 256 stories 34.8 -> 27.2 us, 1 024 36.8 -> 29.3, 4 096 40.4 -> 38.9, 8 192 53.7 -> 50.0,
+    // 16 384 72.1 <- 75.2: the quad form from there on; 64-story serving batches replayed from a graph 39.2 -> 31.1 us)
+    if (!quad_supported(a, MODE, max_slots, n_query) || n_query <= qm_tuning().quad_min_queries) {
+        launch_lean_all<MODE, NB>(a, max_slots, n_query, st);
+        return;
+    }
     if (max_slots <= kQuadSlots) {
         launch_quad<MODE, NB, 1>(a, QuadArgs{nullptr, nullptr, n_query, nullptr, nullptr}, n_query, st);
         return;

@@ -82,6 +82,7 @@ struct QmTuning {
     bool no_quad;                                     // QMANN_NO_QUAD: short stories keep the one-wavefront-per-query kernel (hops_quad.h off)
     bool no_tight;                                    // QMANN_NO_TIGHT (set, any value): the lean kernels keep their four-wave (128-register) builds
     int lean_sparse;                                  // -1 = the launcher chooses, 0 / 1 forced
+    uint32_t quad_min_queries;                        // QMANN_QUAD_MIN_QUERIES (default 8192): batches of at most this many stories keep one story per wavefront (hops_lean.h)
 };
 const QmTuning &qm_tuning();                          // (tuning.hip)
 

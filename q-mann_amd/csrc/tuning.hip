@@ -27,6 +27,10 @@ void read_env(QmTuning &t)
     t.embed_per_hop = on("QMANN_EMBED_PER_HOP");
     t.answer_two_pass = on("QMANN_ANSWER_TWO_PASS");
     t.lean_sparse = tri("QMANN_LEAN_SPARSE");
+    {
+        const char *e = getenv("QMANN_QUAD_MIN_QUERIES");
+        t.quad_min_queries = (e && *e) ? (uint32_t)strtoul(e, nullptr, 10) : 8192u;
+    }
     t.no_tight = on("QMANN_NO_TIGHT");              // presence-only, like its siblings
 }
 

@@ -185,12 +185,21 @@ def test_hops_frac_zero_vector_format(env, oracle):
     run_case(env, oracle, cfg, B=8, S_list=[5, 40], seed=9, sigma_u=3.0, sigma_k=3.0)
 
 
-@pytest.mark.parametrize("S,B", [(50, 64), (200, 24)])
-def test_hops_production_kernels_at_the_metric_sizes(env, oracle, S, B):
+@pytest.mark.parametrize("S,B,min_quad", [(50, 64, "0"), (50, 64, None), (16, 64, "0"), (200, 24, None)])
+def test_hops_production_kernels_at_the_metric_sizes(env, oracle, monkeypatch, S, B, min_quad):
     """bench.py's babi_mem50 shape exactly -- |mem| = 50, D = 60, Q5.2, 64 queries, its code spreads -- and synth200_d64's: the
-    no-taps call inside run_case runs k_hops_lean (sparse read-out, six-wave build) / k_hops_mid against the oracle directly"""
-    run_case(env, oracle, cfg_synth(60, 80, 5), B=B, S_list=[S], seed=5000 + S, sigma_u=8.0, sigma_k=8.0)
-    run_case(env, oracle, cfg_synth(60, 80, 5), B=B, S_list=[S], seed=5100 + S, sigma_u=20.0, sigma_k=30.0)
+    no-taps call inside run_case runs the production kernel against the oracle directly -- k_hops_quad (the four-chunk form at 50
+    rows, the short form at 16: what a batch of > 8 192 stories takes, forced here by QMANN_QUAD_MIN_QUERIES=0), k_hops_lean (what
+    64 stories take by default: sparse read-out, six-wave build), k_hops_mid (200 rows)"""
+    if min_quad is not None:
+        monkeypatch.setenv("QMANN_QUAD_MIN_QUERIES", min_quad)
+    env.model.abi.lib.qmann_tuning_reload()
+    try:
+        run_case(env, oracle, cfg_synth(60, 80, 5), B=B, S_list=[S], seed=5000 + S, sigma_u=8.0, sigma_k=8.0)
+        run_case(env, oracle, cfg_synth(60, 80, 5), B=B, S_list=[S], seed=5100 + S, sigma_u=20.0, sigma_k=30.0)
+    finally:
+        monkeypatch.delenv("QMANN_QUAD_MIN_QUERIES", raising=False)
+        env.model.abi.lib.qmann_tuning_reload()
 
 
 def test_hops_full_size_memory(env, oracle):

@@ -24,7 +24,8 @@ def env():
     return e
 
 
-def three_paths(env, monkeypatch, cfg, B, S_list, seed, sigma_k=30.0, sigma_u=20.0, sigma_h=1.0, shuffle=True, max_slots=None, repeat=0):
+def three_paths(env, monkeypatch, cfg, B, S_list, seed, sigma_k=30.0, sigma_u=20.0, sigma_h=1.0, shuffle=True, max_slots=None, repeat=0,
+                force_quad=True):
     """general kernel (taps) == production path (quad / split) == lean kernel alone (QMANN_NO_QUAD)"""
     torch, model = env.torch, env.model
     H, D, V = cfg["n_hop"], cfg["dim_emb"], cfg["dim_input"]
@@ -54,6 +55,10 @@ def three_paths(env, monkeypatch, cfg, B, S_list, seed, sigma_k=30.0, sigma_u=20
     dk = torch.from_numpy(sk).to(env.dev); dv = torch.from_numpy(model.to_signmag(vals)).to(env.dev)
     dro = torch.from_numpy(row_off).to(env.dev); du0 = torch.from_numpy(u0).to(env.dev)
     ms = int(n_slots.max()) if max_slots is None else max_slots
+    # (batches of <= 8 192 stories keep one story per wavefront by default -- csrc/hops_lean.h::launch_lean --: the quad kernel is
+    # under test here at every batch size)
+    monkeypatch.setenv("QMANN_QUAD_MIN_QUERIES", "0" if force_quad else "8192")
+    model.abi.lib.qmann_tuning_reload()
     u_gen, _ = net.hops(dk, dv, dro, ms, du0, taps=True)        # taps: general kernel
     u_prod = net.hops(dk, dv, dro, ms, du0)                     # no taps: quad / split (where they apply)
     u_again = [net.hops(dk, dv, dro, ms, du0) for _ in range(repeat)]       # back to back, no synchronisation between the calls
@@ -61,6 +66,7 @@ def three_paths(env, monkeypatch, cfg, B, S_list, seed, sigma_k=30.0, sigma_u=20
     model.abi.lib.qmann_tuning_reload()
     u_lean = net.hops(dk, dv, dro, ms, du0)                     # the lean kernel alone
     monkeypatch.delenv("QMANN_NO_QUAD")
+    monkeypatch.delenv("QMANN_QUAD_MIN_QUERIES")
     model.abi.lib.qmann_tuning_reload()
     torch.cuda.synchronize()
     g = u_gen.cpu().numpy()
@@ -100,6 +106,13 @@ def test_mixed_batch_is_split_by_length(env, monkeypatch, mode, nb):
     three_paths(env, monkeypatch, cfg_of(mode, nb=nb), B=1003, S_list=S, seed=510 + mode)
     three_paths(env, monkeypatch, cfg_of(mode, nb=nb), B=130, S_list=[17, 64, 33, 20], seed=520 + mode)
     three_paths(env, monkeypatch, cfg_of(mode, nb=nb), B=130, S_list=[2, 9, 16], seed=530 + mode, max_slots=64)
+
+
+@pytest.mark.parametrize("B", [64, 8192, 8193])
+def test_small_batches_keep_one_story_per_wavefront_by_default(env, monkeypatch, B):
+    """the launch rule at its default threshold, on either side of it (the production call must equal the general kernel whichever form it takes)"""
+    three_paths(env, monkeypatch, cfg_of(2), B=B, S_list=[1, 3, 6, 10, 16], seed=600 + B, force_quad=False)
+    three_paths(env, monkeypatch, cfg_of(11, nb=4), B=B, S_list=[2, 9, 16, 30, 5, 7], seed=610 + B, force_quad=False)
 
 
 def test_quad_persistent_grid_many_queries(env, monkeypatch):
