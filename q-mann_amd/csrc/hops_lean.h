@@ -617,8 +617,9 @@ inline void launch_lean_all(const HopArgs &a, uint32_t max_slots, uint32_t n_que
 
 // Short-memory launches: stories of at most 16 rows take the four-queries-per-wavefront kernel (hops_quad.h), longer ones the
 // one-wavefront-per-query kernel below.  A batch whose bound allows both (the 20-task set: up to 64 rows, 91 % of the stories
-// <= 16) is split on the device into two index lists first (k_split_by_length); the two kernels then run one after the other
-// on the stream, each over its list.  QMANN_NO_QUAD keeps everything on the lean kernel (A/B).
+// <= 16) is split on the device into two index lists first (k_split_by_length); the two kernels then run each over its list --
+// one after the other on the stream, or side by side on two streams where that pays (below).  Batches of at most
+// QMANN_QUAD_MIN_QUERIES stories keep one story per wavefront.  QMANN_NO_QUAD keeps everything on the lean kernel (A/B).
 template <int MODE, int NB>
 inline void launch_lean(const HopArgs &a, uint32_t max_slots, uint32_t n_query, hipStream_t st)
 {
