@@ -887,7 +887,7 @@ k_embed_query(const float *__restrict__ question, const float *__restrict__ w_q,
 // recorded in `irr_rows` for the float kernel to redo.
 // ---------------------------------------------------------------------------
 // L lanes per row (16 / 32 / 64: the smallest that covers a dictionary of up to 64 words; longer rows take passes of 64),
-// 64 / L rows per wavefront.  A pass whose entries are all 0 or 1 -- every pass of a real bAbI row but the few with a word
+// 64 / L rows per wavefront.  A pass whose entries are all 0.0 or 1.0 -- every pass of a real bAbI row but the few with a word
 // said twice -- takes its positions from one ballot instead of a six-step scan.
 template <int L>
 __global__ void __launch_bounds__(kBlock)
@@ -896,8 +896,9 @@ k_bow_to_words(const float *__restrict__ bow, uint32_t rows, uint32_t V, uint16_
 {
     constexpr int RPW = kWave / L;
     constexpr uint64_t kGroupMask = L == 64 ? ~0ull : ((1ull << (L & 63)) - 1ull);
-    __shared__ __attribute__((aligned(16))) uint16_t buf[kWaves][RPW][16];
+    __shared__ __attribute__((aligned(16))) uint16_t buf[kWaves][RPW][24];       // 16 list slots + a dump slot (index 16) for the lanes with nothing to write
     const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, sub = lane & (L - 1), grp = lane / L;
+    const uint64_t below = (1ull << sub) - 1ull;
     for (size_t r0 = ((size_t)blockIdx.x * kWaves + wave) * RPW; r0 < rows; r0 += (size_t)gridDim.x * kWaves * RPW) {
         const size_t r = r0 + grp;
         const bool r_ok = r < rows;
@@ -908,29 +909,34 @@ k_bow_to_words(const float *__restrict__ bow, uint32_t rows, uint32_t V, uint16_
         bool bad = false;
         for (uint32_t c0 = 0; c0 < V; c0 += L) {                         // wavefront-uniform
             const uint32_t k = c0 + sub;
-            const float x = (r_ok && k < V) ? bow[r * V + k] : 0.0f;
+            float x = 0.0f;
+            if (r_ok && k < V) x = bow[r * V + k];
+            // nothing but 0.0 and 1.0 in the pass (told by the bit patterns; the compare's lane mask IS the ballot): positions from
+            // the ballot, a branch-free write; anything else -- counts, fractions, -0.0, NaN -- takes the general tests and the scan
+            const uint32_t bits = __builtin_bit_cast(uint32_t, x);
+            const bool one = bits == 0x3F800000u;
+            if (!__any(bits != 0u && !one)) {
+                const uint64_t gm = (__ballot(one) >> (grp * L)) & kGroupMask;
+                const uint32_t pos = base + (uint32_t)__popcll(gm & below);
+                buf[wave][grp][(one && pos < 16u) ? pos : 16u] = (uint16_t)k;
+                base += (uint32_t)__popcll(gm);
+                continue;
+            }
             const bool nz = x != 0.0f;                                   // (a NaN is "non-zero" and fails the next test)
             const int c = (x >= 1.0f && x <= 16.0f) ? (int)x : 0;
             const bool ok = nz && c > 0 && (float)c == x;
             bad |= nz && !ok;
             const uint32_t cnt = ok ? (uint32_t)c : 0u;
-            uint32_t pos;
-            if (!__any(cnt > 1u)) {
-                const uint64_t gm = (__ballot(ok) >> (grp * L)) & kGroupMask;
-                pos = base + (uint32_t)__popcll(gm & ((1ull << sub) - 1ull));
-                base += (uint32_t)__popcll(gm);
-            } else {
-                uint32_t incl = cnt;
+            uint32_t incl = cnt;
 #pragma unroll
-                for (int o = 1; o < L; o <<= 1) {
-                    const uint32_t t = __shfl_up(incl, o, L);
-                    if (sub >= (uint32_t)o) incl += t;
-                }
-                pos = base + incl - cnt;
-                base += __shfl(incl, L - 1, L);
+            for (int o = 1; o < L; o <<= 1) {
+                const uint32_t t = __shfl_up(incl, o, L);
+                if (sub >= (uint32_t)o) incl += t;
             }
+            const uint32_t pos = base + incl - cnt;
             for (uint32_t t = 0; t < cnt; t++)
                 if (pos + t < 16u) buf[wave][grp][pos + t] = (uint16_t)k;
+            base += __shfl(incl, L - 1, L);
         }
         const bool irregular = ((__ballot(bad) >> (grp * L)) & kGroupMask) != 0ull || base > 16u;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -939,6 +945,108 @@ k_bow_to_words(const float *__restrict__ bow, uint32_t rows, uint32_t V, uint16_
         if (r_ok && sub < 8) ((uint32_t *)(words + r * 16))[sub] = irregular ? 0xFFFFFFFFu : ((const uint32_t *)buf[wave][grp])[sub];
         if (r_ok && irregular && sub == 0) irr_rows[atomicAdd(n_irr, 1u)] = (uint32_t)r;
         __builtin_amdgcn_wave_barrier();                                 // the next rows rewrite the buffer
+    }
+}
+
+// Dictionaries of more than 64 words (the 20-task set: 238): a lane takes FOUR consecutive entries of the row in one 16-byte
+// buffer load (rows are only 4-byte aligned: 952 bytes at V = 238; the resource ends with the array, so the last rows' overhang
+// reads as zeros), a pass covers 256 entries, and the next row's load is issued before this row is worked on -- the kernel is
+// bound by the float rows it reads (0.96 ms -> see DESIGN.md for 2.44 M rows of 238).  Ascending order = lane-major, then the
+// lane's four entries: positions from four ballots (all counts 0 / 1) or from a scan of the lanes' totals.
+__global__ void __launch_bounds__(kBlock)
+k_bow_to_words_wide(const float *__restrict__ bow, uint32_t rows, uint32_t V, uint16_t *__restrict__ words,
+                    uint32_t *__restrict__ irr_rows, uint32_t *__restrict__ n_irr)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t buf[kWaves][24];    // 16 list slots + a dump slot (index 16) for the lanes with nothing to write
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const size_t stride = (size_t)gridDim.x * kWaves;
+    const size_t row_bytes = (size_t)V * 4u, total = (size_t)rows * row_bytes;
+    const uint32_t n_pass = (V + 255u) / 256u;
+    // one resource over the whole array while 32-bit offsets reach every row (< 4 GiB: 4.5 M rows of 238); per row beyond
+    const bool one_rsrc = total <= 0xFFFFFFFFull;
+    const __amdgpu_buffer_rsrc_t rs_all = __builtin_amdgcn_make_buffer_rsrc((void *)bow, 0, (int)(uint32_t)(one_rsrc ? total : 0u), kRawBufferFlags);
+    auto request = [&](size_t r, uint32_t pass) -> i32x4 {
+        const uint32_t in_row = (pass * 256u + lane * 4u) * 4u;
+        // (the row's offset in the VECTOR offset: that is the one the bounds check covers, and the last rows' overhang must read as zeros)
+        if (one_rsrc) return __builtin_amdgcn_raw_buffer_load_b128(rs_all, (int)((uint32_t)(r * row_bytes) + in_row), 0, kBufferNt);
+        const size_t off = r * row_bytes, left = total - off;           // (wavefront-uniform)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)bow + off), 0,
+                                                                             (int)(left < 0x7FFFFFFFu ? left : 0x7FFFFFFFu), kRawBufferFlags);
+        return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)in_row, 0, kBufferNt);
+    };
+    size_t r = (size_t)blockIdx.x * kWaves + wave;
+    if (r >= rows) return;
+    const uint64_t below = (1ull << lane) - 1ull;
+    i32x4 x = request(r, 0);
+    for (; r < rows; r += stride) {
+        if (lane < 16) buf[wave][lane] = 0xFFFFu;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t base = 0;
+        bool bad = false;
+        for (uint32_t pass = 0; pass < n_pass; pass++) {                 // wavefront-uniform
+            const i32x4 cur = x;
+            // the next load: this row's next pass, or the next row's first
+            if (pass + 1u < n_pass) x = request(r, pass + 1u);
+            else if (r + stride < rows) x = request(r + stride, 0);
+            const uint32_t k0 = pass * 256u + lane * 4u;
+            // almost every pass of a real row holds nothing but 0.0 and 1.0: told by the bit patterns, one compare per entry each
+            // (its lane mask IS the ballot); anything else -- counts, fractions, -0.0, NaN -- takes the general tests
+            uint32_t bits[4];
+            bool one[4], other = false;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                // (element by element, a plain `if`: `cond ? bit_cast(cur[e]) : 0` compiled to cur[0] for every e -- hipcc 7.2)
+                bits[e] = (uint32_t)cur[e];
+                if (k0 + (uint32_t)e >= V) bits[e] = 0u;                 // (past the row's end the load holds the next row's entries)
+                one[e] = bits[e] == 0x3F800000u;
+                other |= bits[e] != 0u && !one[e];
+            }
+            if (!__any(other)) {
+                const uint64_t m0 = __ballot(one[0]), m1 = __ballot(one[1]), m2 = __ballot(one[2]), m3 = __ballot(one[3]);
+                uint32_t pos = base + (uint32_t)(__popcll(m0 & below) + __popcll(m1 & below) + __popcll(m2 & below) + __popcll(m3 & below));
+#pragma unroll
+                for (int e = 0; e < 4; e++) {                            // no branches: a lane without an entry writes the dump slot
+                    buf[wave][(one[e] && pos < 16u) ? pos : 16u] = (uint16_t)(k0 + (uint32_t)e);
+                    pos += one[e] ? 1u : 0u;
+                }
+                base += (uint32_t)(__popcll(m0) + __popcll(m1) + __popcll(m2) + __popcll(m3));
+                continue;
+            }
+            uint32_t cnt[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float v = __builtin_bit_cast(float, bits[e]);
+                const bool nz = v != 0.0f;                               // (a NaN is "non-zero" and fails the next test)
+                const int c = (v >= 1.0f && v <= 16.0f) ? (int)v : 0;
+                const bool ok = nz && c > 0 && (float)c == v;
+                bad |= nz && !ok;
+                cnt[e] = ok ? (uint32_t)c : 0u;
+            }
+            const uint32_t mine = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+            uint32_t incl = mine;
+#pragma unroll
+            for (int o = 1; o < kWave; o <<= 1) {
+                const uint32_t t = __shfl_up(incl, o);
+                if (lane >= (uint32_t)o) incl += t;
+            }
+            uint32_t pos = base + incl - mine;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                for (uint32_t t = 0; t < cnt[e]; t++)
+                    if (pos + t < 16u) buf[wave][pos + t] = (uint16_t)(k0 + (uint32_t)e);
+                pos += cnt[e];
+            }
+            base += __shfl(incl, kWave - 1);
+        }
+        const bool irregular = __any(bad) || base > 16u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < 8) ((uint32_t *)(words + r * 16))[lane] = irregular ? 0xFFFFFFFFu : ((const uint32_t *)buf[wave])[lane];
+        if (irregular && lane == 0) irr_rows[atomicAdd(n_irr, 1u)] = (uint32_t)r;
+        __builtin_amdgcn_wave_barrier();                                 // the next row rewrites the buffer
     }
 }
 
@@ -2086,7 +2194,8 @@ int qmann_bow_to_words(const float *bow, uint32_t rows, uint32_t dim_input, uint
     };
     if (dim_input <= 16u) go(k_bow_to_words<16>, 4u);
     else if (dim_input <= 32u) go(k_bow_to_words<32>, 2u);
-    else go(k_bow_to_words<64>, 1u);
+    else if (dim_input <= 64u) go(k_bow_to_words<64>, 1u);
+    else go(k_bow_to_words_wide, 1u);
     QM_LAUNCH_CHECK();
     return qm_scope.rc();
 }

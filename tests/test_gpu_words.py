@@ -450,7 +450,7 @@ def test_bow_to_words_lists(env):
     assert (w[[1, 2, 4]] == 0xFFFF).all()
 
 
-@pytest.mark.parametrize("V", [1, 7, 16, 17, 30, 32, 33, 64, 65, 130, 238])
+@pytest.mark.parametrize("V", [1, 7, 16, 17, 30, 32, 33, 64, 65, 130, 238, 255, 256, 257, 300, 513, 1000])
 def test_bow_to_words_random_rows_every_group_width(env, V):
     """dictionaries of <= 16 / <= 32 words pack four / two rows into a wavefront, longer ones take passes of 64 lanes
     (csrc/batch_io.hip::k_bow_to_words<L>); rows with a repeated word take the scan branch, the others the ballot branch"""
